@@ -1,0 +1,120 @@
+"""Pin the CPU oracle to outputs of the reference's own classes (tests/golden/make_golden.py)."""
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from gnnome_amd.synth import random_state_dict
+from oracle.symgated_oracle import OracleModel, bce_loss, degree_features, model_from_state_dict, symmetry_loss
+
+# The restatement runs the same torch ops in the same order as the reference, so it must agree to
+# rounding noise, far inside the 1e-4 bar north_star puts on probabilities.
+LOGIT_TOL = 1e-5
+PROB_TOL = 1e-6
+
+
+def _check(logits, want):
+    assert logits.shape == want.shape and logits.dtype == torch.float32
+    assert (logits - want).abs().max().item() <= LOGIT_TOL * max(1.0, want.abs().max().item())
+    assert (torch.sigmoid(logits) - torch.sigmoid(want)).abs().max().item() <= PROB_TOL
+
+
+def test_g1_hand_graph(shipped_weights):
+    g = load_golden("g1_hand.pt")
+    m = model_from_state_dict(shipped_weights).eval()
+    tr = []
+    with torch.no_grad():
+        out = m((g["src"], g["dst"], g["num_nodes"]), g["x"], g["e"], trace=tr)
+    _check(out, g["logits"])
+    assert torch.allclose(tr[-1][0], g["h_final"], atol=1e-5, rtol=1e-5)
+    assert torch.allclose(tr[-1][1], g["e_final"], atol=1e-4, rtol=1e-5)
+    assert torch.equal(degree_features(g["src"], g["dst"], g["num_nodes"]), g["x"])
+
+
+def test_g2_uniform_per_layer(shipped_weights):
+    g = load_golden("g2_uniform_1k.pt")
+    m = model_from_state_dict(shipped_weights).eval()
+    tr = []
+    with torch.no_grad():
+        out = m((g["src"], g["dst"], g["num_nodes"]), g["x"], g["e"], trace=tr)
+    _check(out, g["logits"])
+    assert len(tr) == len(g["layers"]) + 1
+    for (h, e), want in zip(tr[1:], g["layers"]):
+        assert torch.allclose(h[:8], want["h_rows"], atol=1e-5, rtol=1e-5)
+        assert torch.allclose(e[:8], want["e_rows"], atol=1e-4, rtol=1e-5)
+        assert abs(h.double().sum().item() - want["h_sum"]) <= 1e-6 * h.double().abs().sum().item() + 1e-6
+        assert abs(e.double().sum().item() - want["e_sum"]) <= 1e-6 * e.double().abs().sum().item() + 1e-6
+
+
+def test_g3_train_step_grads_and_bn_buffers():
+    g = load_golden("g3_train_h64.pt")
+    m = OracleModel(2, 2, 64, 16, 8, 64, "batch", dropout=0.0)
+    m.load_state_dict(random_state_dict(64, seed=g["seed"]))
+    m.train()
+    out = m((g["src"], g["dst"], g["num_nodes"]), g["x"], g["e"])
+    loss = bce_loss(out, g["y"], g["pos_weight"])
+    loss.backward()
+    _check(out.detach(), g["logits"])
+    assert abs(loss.item() - g["loss"].item()) <= 1e-6
+    grads = dict(m.named_parameters())
+    assert set(grads) == set(g["grads"]) and len(grads) == 142
+    for k, want in g["grads"].items():
+        got = grads[k].grad
+        assert (got - want).abs().max().item() <= 1e-6 + 1e-4 * want.abs().max().item(), k
+    bufs = dict(m.named_buffers())
+    assert len(bufs) == 48
+    for k, want in g["buffers_after"].items():
+        assert torch.allclose(bufs[k].float(), want.float(), atol=1e-6, rtol=1e-5), k
+    # bn_e is applied twice per forward (gated_gcn_full.py:106,119), bn_h once (:132)
+    assert bufs["gnn.convs.0.bn_e.num_batches_tracked"].item() == 2
+    assert bufs["gnn.convs.0.bn_h.num_batches_tracked"].item() == 1
+
+
+def test_g4_reversed_pass_and_symmetry_loss():
+    g = load_golden("g4_reverse_h64.pt")
+    m = OracleModel(2, 2, 64, 16, 8, 64, "batch", dropout=0.0)
+    m.load_state_dict(random_state_dict(64, seed=g["seed"]))
+    m.eval()
+    with torch.no_grad():
+        org = m((g["src"], g["dst"], g["num_nodes"]), g["x"], g["e"])
+        rev = m((g["dst"], g["src"], g["num_nodes"]), g["x_rev"], g["e"])
+    _check(org, g["logits"])
+    _check(rev, g["logits_rev"])
+    assert torch.equal(g["x_rev"], degree_features(g["src"], g["dst"], g["num_nodes"], reverse=True))
+    sym = symmetry_loss(org.squeeze(-1), rev.squeeze(-1), g["y"], g["pos_weight"], g["alpha"])
+    assert abs(sym.item() - g["symmetry_loss"].item()) <= 1e-6
+
+
+def test_g5_wider_hidden():
+    for hidden in (128, 256):
+        g = load_golden(f"g5_eval_h{hidden}.pt")
+        m = model_from_state_dict(random_state_dict(hidden, seed=g["seed"])).eval()
+        tr = []
+        with torch.no_grad():
+            out = m((g["src"], g["dst"], g["num_nodes"]), g["x"], g["e"], trace=tr)
+        _check(out, g["logits"])
+        assert torch.allclose(tr[-1][0], g["h_final"], atol=1e-5, rtol=1e-5)
+
+
+def test_g6_layernorm():
+    g = load_golden("g6_layernorm_h64.pt")
+    sd = {k: v for k, v in random_state_dict(64, seed=g["seed"]).items() if "running_" not in k and "num_batches" not in k}
+    m = OracleModel(2, 2, 64, 16, 8, 64, "layer")
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        out = m((g["src"], g["dst"], g["num_nodes"]), g["x"], g["e"])
+    _check(out, g["logits"])
+
+
+def test_known_answers_without_any_reference(shipped_weights):
+    """edge-order equivariance, E=0, isolated nodes."""
+    g = load_golden("g2_uniform_1k.pt")
+    m = model_from_state_dict(shipped_weights).eval()
+    perm = torch.randperm(g["src"].numel(), generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        a = m((g["src"], g["dst"], g["num_nodes"]), g["x"], g["e"])
+        b = m((g["src"][perm], g["dst"][perm], g["num_nodes"]), g["x"], g["e"][perm])
+        empty = m((g["src"][:0], g["dst"][:0], 4), torch.zeros(4, 2), torch.zeros(0, 2))
+    assert (torch.sigmoid(a[perm]) - torch.sigmoid(b)).abs().max().item() < 1e-5
+    assert empty.shape == (0, 1)
+    assert F.relu(torch.tensor(-1.0)).item() == 0.0
