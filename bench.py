@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""bench.py - edges/sec of one full SymGatedGCNModel forward (encoders + 8 layers + scorer).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|10m|parity64|c4shard] [--kind banded|uniform]
+
+One "step" = one `model(graph, x, e)` on a synthetic assembly graph already resident in HBM
+(graph views prebuilt, as a caller that scores the same graph repeatedly would have them; the cold
+number including the CSR build is reported as `cold_ms`).  N>1 (launched by torch.distributed.run,
+one rank per GPU) runs the SAME graph partitioned by destination-node range (gnnome_amd/dist.py):
+strong scaling.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (nodes, edges, hidden) - BASELINE.json configs[1] is the default
+    "c2": (100_000, 1_000_000, 128),
+    "10m": (1_000_000, 10_000_000, 128),
+    "parity64": (100_000, 1_000_000, 64),
+    "c4shard": (250_000, 2_500_000, 256),  # one GPU's eighth of configs[3]
+}
+HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
+MFMA_F32_PEAK = 157.3e12  # flop/s, v_mfma_f32_32x32x2_f32
+
+
+def algorithmic_bytes(n, e, h, layers=8):
+    """B_fwd of BASELINE.md section 2.2 (s = 4 bytes)."""
+    b_enc = (2 * n + 2 * e) * 4 + (n + e) * h * 4
+    b_layer = (2 * e * h + 2 * n * h) * 4 + 2 * e * 4
+    b_pred = (e * h + n * h) * 4 + 2 * e * 4 + e * 4
+    return b_enc + layers * b_layer + b_pred
+
+
+def algorithmic_flops(n, e, h, layers=8, h_ne=16, hs=64):
+    f_enc = 2 * (n + e) * (2 * h_ne + h_ne * h)
+    f_layer = 10 * n * h * h + 2 * e * h * h
+    f_pred = 2 * e * (3 * h * hs + hs * 32 + 32)
+    return f_enc + layers * f_layer + f_pred
+
+
+class KernelTimer:
+    """HIP-event pairs around every launch of chosen gnnome_amd.ops entry points, on the launch stream."""
+
+    def __init__(self, ops_mod, names):
+        self.ops, self.names, self.events, self.orig, self.on = ops_mod, names, {n: [] for n in names}, {}, False
+
+    def __enter__(self):
+        for name in self.names:
+            fn = getattr(self.ops, name)
+            self.orig[name] = fn
+
+            def wrapped(*a, _fn=fn, _name=name, **k):
+                if not self.on:
+                    return _fn(*a, **k)
+                s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = _fn(*a, **k)
+                t.record()
+                self.events[_name].append((s, t))
+                return out
+
+            setattr(self.ops, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.orig.items():
+            setattr(self.ops, name, fn)
+
+    def mean_ms(self, name):
+        ev = self.events[name]
+        return sum(s.elapsed_time(t) for s, t in ev) / max(len(ev), 1), len(ev)
+
+
+def cpu_baseline(hidden, kind, budget_s=25.0):
+    """The oracle (torch-CPU restatement of the reference's CPU/DGL path) timed on this host's cores, on a
+    bounded sample of the workload: same generator, same width, E = 200k."""
+    from gnnome_amd.synth import make_graph, random_state_dict
+    from oracle.symgated_oracle import degree_features, model_from_state_dict
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n, e = 20_000, 200_000
+    g = make_graph(n, e, seed=1, kind=kind)
+    x = degree_features(g["src"], g["dst"], n)
+    model = model_from_state_dict(random_state_dict(hidden, seed=1)).eval()
+    graph = (g["src"], g["dst"], n)
+    times = []
+    with torch.no_grad():
+        model(graph, x, g["e"])  # warm-up
+        t_all = time.perf_counter()
+        while len(times) < 3 and (time.perf_counter() - t_all) < budget_s:
+            t0 = time.perf_counter()
+            model(graph, x, g["e"])
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {
+        "value": e / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{kind} synthetic graph N={n} E={e} H={hidden} L=8 fp32, oracle/symgated_oracle.py (torch-CPU "
+                  f"restatement; DGL 0.8.1 not installable offline), 1 warm-up + median of {len(times)}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--kind", default="banded", choices=["banded", "uniform"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import gnnome_amd
+    from gnnome_amd import _lib, ops
+    from gnnome_amd.synth import make_graph, random_state_dict
+    from gnnome_amd.features import degree_features
+    _lib.load()
+
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, e, hidden = WORKLOADS[args.workload]
+    g = make_graph(n, e, seed=1, kind=args.kind)
+    x_cpu = degree_features(g["src"], g["dst"], n)
+    model = gnnome_amd.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch").eval()
+    model.load_state_dict(random_state_dict(hidden, seed=1))
+    model.to(dev)
+
+    if world == 1:
+        src, dst = g["src"].to(dev), g["dst"].to(dev)
+        x, ef = x_cpu.to(dev), g["e"].to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        views = ops.GraphViews(src, dst, n)
+        model(views, x, ef)
+        torch.cuda.synchronize()
+        cold_ms = (time.perf_counter() - t0) * 1e3
+
+        def step():
+            return model(views, x, ef)
+
+        def barrier():
+            torch.cuda.synchronize()
+        parallelism = "single"
+    else:
+        from gnnome_amd import dist as gdist
+        plan = gdist.PartitionedGraph.from_global(g["src"], g["dst"], n, rank, world, dev)
+        runner = gdist.PartitionedRunner(model, plan, x_cpu, g["e"], dev)
+        cold_ms = None
+
+        def step():
+            return runner.forward()
+
+        def barrier():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        parallelism = f"dst-range x{world}"
+
+    timed = [] if args.no_kernel_timers or world > 1 else ["edge_gate", "node_aggregate", "linear", "edge_score", "encode"]
+    with KernelTimer(ops, timed) as kt:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        kt.on = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kt.on = False
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        b_fwd, f_fwd = algorithmic_bytes(n, e, hidden), algorithmic_flops(n, e, hidden)
+        res = {
+            "metric": "edges/sec full-graph GatedGCN fwd", "value": e / (ms * 1e-3), "unit": "edges/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {args.kind} synthetic assembly graph N={n} E={e}, SymGatedGCNModel hidden={hidden} "
+                                   f"L=8 hs=64 BatchNorm(eval), fwd only, random-init weights seed 1", "parallelism": parallelism},
+            "hbm_roofline_frac_whole_fwd": (b_fwd / (ms * 1e-3)) / (world * HBM_PEAK),
+            "mfma_f32_frac_whole_fwd": (f_fwd / (ms * 1e-3)) / (world * MFMA_F32_PEAK),
+            "algorithmic_bytes_fwd": b_fwd, "algorithmic_flops_fwd": f_fwd, "cold_ms_incl_graph_views": cold_ms,
+        }
+        if timed:
+            gate_ms, gate_n = kt.mean_ms("edge_gate")
+            gate_flops = 2.0 * e * hidden * hidden
+            res["roofline"] = {
+                "kernel": "k_edge_gate (fused B_3 GEMM + u_add_v + bn_e + relu + residual)", "bound": "mfma",
+                "achieved": gate_flops / (gate_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": gate_flops / (gate_ms * 1e-3) / MFMA_F32_PEAK, "traffic": None,
+                "avg_launch_ms": gate_ms, "launches": gate_n, "flops_per_launch": gate_flops,
+                "algorithmic_bytes_per_launch": 2.0 * e * hidden * 4 + 2 * e * 4,
+                "hbm_frac": (2.0 * e * hidden * 4 + 2 * e * 4) / (gate_ms * 1e-3) / HBM_PEAK,
+            }
+            agg_ms, agg_n = kt.mean_ms("node_aggregate")
+            agg_bytes = 2.0 * e * hidden * 4 + 3 * e * 4 + 3 * n * hidden * 4
+            lin_ms, lin_n = kt.mean_ms("linear")
+            sc_ms, sc_n = kt.mean_ms("edge_score")
+            en_ms, en_n = kt.mean_ms("encode")
+            res["kernels"] = [
+                {"kernel": "k_node_aggregate", "bound": "hbm", "avg_launch_ms": agg_ms, "launches": agg_n,
+                 "achieved": agg_bytes / (agg_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                 "frac": agg_bytes / (agg_ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": agg_bytes},
+                {"kernel": "k_linear (all calls: node projections [N,H]x[H,5H] and predictor node halves)", "bound": "mfma",
+                 "avg_launch_ms": lin_ms, "launches": lin_n},
+                {"kernel": "k_edge_score", "bound": "mfma", "avg_launch_ms": sc_ms, "launches": sc_n,
+                 "achieved": 2.0 * e * (hidden * 64 + 64 * 32 + 32) / (sc_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s"},
+                {"kernel": "k_encode (node + edge)", "bound": "hbm", "avg_launch_ms": en_ms, "launches": en_n},
+            ]
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(hidden, args.kind)
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

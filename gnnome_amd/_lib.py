@@ -1,0 +1,66 @@
+"""ctypes binding of libgnnome_hip.so (C ABI declared in include/gnnome_hip.h).
+
+There is no CPU fallback: if the library is missing, or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgnnome_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gnnome_hip.h")
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_int64
+_sz = ctypes.c_size_t
+
+# name -> argtypes, in the order of include/gnnome_hip.h
+SIGNATURES = {
+    "gnnome_abi_version": [],
+    "gnnome_last_error": [],
+    "gnnome_graph_views_workspace_bytes": [_l, _l, ctypes.POINTER(_sz)],
+    "gnnome_build_graph_views": [_p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gnnome_encode_f32": [_p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p],
+    "gnnome_linear_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
+    "gnnome_edge_gate_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p],
+    "gnnome_node_aggregate_f32": [_p, _i, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
+    "gnnome_edge_score_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    "gnnome_gather_rows_f32": [_p, _i, _p, _l, _i, _p, _i, _p],
+}
+
+ABI_VERSION = 1
+NORM_AFFINE = 0
+NORM_LAYER = 1
+
+_lib = None
+
+
+class GnnomeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise GnnomeHipError(
+            f"{LIB_PATH} not found - the HIP extension is not built. Run `make -C gnnome_amd/csrc` "
+            "(or __graft_entry__.build()). gnnome_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "gnnome_last_error" else _i
+    got = lib.gnnome_abi_version()
+    if got != ABI_VERSION:
+        raise GnnomeHipError(f"libgnnome_hip.so ABI {got} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gnnome_last_error()
+        raise GnnomeHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,63 @@
+// Shared host/device helpers for libgnnome_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gnnome_hip.h"
+
+namespace gnnome {
+
+void set_error(const char* fmt, ...);
+
+#define GN_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            ::gnnome::set_error(__VA_ARGS__); \
+            return GNNOME_EINVAL;             \
+        }                                     \
+    } while (0)
+
+#define GN_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t err__ = (call);                                                                \
+        if (err__ != hipSuccess) {                                                                \
+            ::gnnome::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, \
+                                __LINE__);                                                        \
+            return GNNOME_EHIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+#define GN_LAUNCH_CHECK() GN_HIP(hipGetLastError())
+
+constexpr int kWave = 64;       // gfx950 wavefront
+constexpr int kXcds = 8;        // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
+constexpr int kNumCUs = 256;
+constexpr float kAggEps = 1e-6f;   // gated_gcn_full.py:114,127
+constexpr float kNormEps = 1e-5f;  // torch BatchNorm1d / LayerNorm default eps
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Give each XCD (private 4 MiB L2) a contiguous range of work items so that neighbouring tiles -
+// which share destination rows and, in layout-ordered assembly graphs, nearby source rows - hit
+// the same L2.  Bijective for any n (cdna_hip_programming.md 5.5 T1).
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int xcd = bid % kXcds, q = n / kXcds, r = n % kXcds;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + bid / kXcds;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// sum over the 32 lanes that share (lane >> 5)
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    return v;
+}
+
+}  // namespace gnnome

@@ -1,0 +1,223 @@
+"""Host logic of the SymGatedGCN path: weight preparation, device staging and the kernel sequence.
+
+Data layout in HBM for one forward (N nodes, E edges, H hidden):
+    views        int32  in_ptr[N+1] srt_src[E] srt_dst[E] srt_eid[E] out_ptr[N+1] out_pos[E]
+    h            fp32   [N,H]      node state, ping-pong per layer
+    P            fp32   [N,5H]     A1h|A2h|A3h|B1h|B2h of the current layer (one GEMM)
+    e            fp32   [E,H]      edge state in DESTINATION-SORTED order, updated in place
+    Ps|Qd        fp32   [N,2*hs]   node halves of predictor.W1
+    logits       fp32   [E]        written at the ORIGINAL edge id
+The only [E,H]-sized tensor is `e`; it is written once by the edge encoder (already permuted),
+read+written once per layer by edge_gate, read twice per layer by node_aggregate, read once by
+edge_score.
+
+The kernel sequence is written against an `ops` namespace (default: gnnome_amd.ops, the HIP
+library) so that the partition / halo logic in dist.py can be unit-tested on CPU ranks with a
+checker backend injected by the tests; the product never selects anything but the HIP backend.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops as hip_ops
+from ._lib import NORM_AFFINE, NORM_LAYER
+from .graph import views_for
+
+
+class LayerWeights:
+    __slots__ = ("Wcat", "bcat", "W3", "norm", "scale_e", "shift_e", "scale_h", "shift_h")
+
+
+class Prepared:
+    """Device-resident, kernel-ready copies of a model's parameters (eval semantics)."""
+
+    def __init__(self, model, device):
+        def dev(t):
+            return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+        self.device = device
+        self.hidden = model.linear2_node.out_features
+        self.enc_node = tuple(dev(t) for t in (model.linear1_node.weight, model.linear1_node.bias,
+                                               model.linear2_node.weight, model.linear2_node.bias))
+        self.enc_edge = tuple(dev(t) for t in (model.linear1_edge.weight, model.linear1_edge.bias,
+                                               model.linear2_edge.weight, model.linear2_edge.bias))
+        self.layers = [prepare_layer(conv, device) for conv in model.gnn.convs]
+        self.predictor = prepare_predictor(model.predictor, device)
+
+
+def _norm_affine(norm_module, device):
+    """(kind, scale, shift) such that the kernels' y = norm(x) matches the torch module in eval mode."""
+    def dev(t):
+        return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    if isinstance(norm_module, torch.nn.BatchNorm1d):
+        # eval BatchNorm1d: (x - running_mean) / sqrt(running_var + eps) * weight + bias
+        rstd = torch.rsqrt(norm_module.running_var.detach().double() + norm_module.eps)
+        scale = norm_module.weight.detach().double() * rstd
+        shift = norm_module.bias.detach().double() - norm_module.running_mean.detach().double() * scale
+        return NORM_AFFINE, dev(scale.float()), dev(shift.float())
+    if isinstance(norm_module, torch.nn.LayerNorm):
+        if abs(norm_module.eps - 1e-5) > 1e-12:
+            raise ValueError("LayerNorm eps other than 1e-5 is not supported by the HIP kernels")
+        return NORM_LAYER, dev(norm_module.weight), dev(norm_module.bias)
+    raise TypeError(type(norm_module))
+
+
+def prepare_layer(conv, device):
+    def dev(t):
+        return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    lw = LayerWeights()
+    lw.Wcat = dev(torch.cat([conv.A_1.weight, conv.A_2.weight, conv.A_3.weight, conv.B_1.weight, conv.B_2.weight], 0))
+    # B_3's bias rides on the B2h rows: B1h[src] + (B2h[dst] + b3) + e*W3^T
+    lw.bcat = dev(torch.cat([conv.A_1.bias, conv.A_2.bias, conv.A_3.bias, conv.B_1.bias, conv.B_2.bias + conv.B_3.bias], 0))
+    lw.W3 = dev(conv.B_3.weight)
+    lw.norm, lw.scale_e, lw.shift_e = _norm_affine(conv.bn_e, device)
+    kind_h, lw.scale_h, lw.shift_h = _norm_affine(conv.bn_h, device)
+    assert kind_h == lw.norm
+    return lw
+
+
+def prepare_predictor(pred, device):
+    def dev(t):
+        return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    hs, h3 = pred.W1.weight.shape
+    hidden = h3 // 3
+    if pred.W2.out_features != 32 or pred.W3.in_features != 32 or pred.W3.out_features != 1:
+        raise ValueError("ScorePredictor tail must be hs -> 32 -> 1 (score_predictor.py:9-10)")
+    W1 = dev(pred.W1.weight)
+    return {
+        "hidden": hidden, "hs": hs,
+        "W1_src": W1[:, :hidden], "W1_dst": W1[:, hidden:2 * hidden], "W1_e": W1[:, 2 * hidden:],
+        "b1": dev(pred.W1.bias), "W2": dev(pred.W2.weight), "b2": dev(pred.W2.bias),
+        "W3": dev(pred.W3.weight.reshape(-1)), "b3": dev(pred.W3.bias.reshape(-1)), "_W1": W1,
+    }
+
+
+def _state_key(module, device):
+    items = [(id(t), t._version, str(t.device)) for t in list(module.parameters()) + list(module.buffers())]
+    return (str(device), tuple(items))
+
+
+def prepared_for(module, device, build):
+    key = _state_key(module, device)
+    cached = module.__dict__.get("_gnnome_prepared")
+    if cached is None or cached[0] != key:
+        cached = (key, build(module, device))
+        module.__dict__["_gnnome_prepared"] = cached
+    return cached[1]
+
+
+def compute_device(*tensors):
+    """The MI355X the call runs on: the inputs' device if they are already on one, else the current device."""
+    for t in tensors:
+        if t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError("gnnome_amd runs on an MI355X only: no HIP device is visible and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _refuse_training(module):
+    if module.training and torch.is_grad_enabled():
+        raise NotImplementedError("the training step (train-mode BatchNorm + backward kernels) is not part of this build yet; "
+                                  "call model.eval() / torch.no_grad()")
+    if module.training and any(isinstance(m, torch.nn.BatchNorm1d) for m in module.modules()):
+        raise NotImplementedError("train-mode BatchNorm statistics are not part of this build yet; call model.eval()")
+
+
+# ---------------------------------------------------------------------------------------------------
+# kernel sequences (ops = gnnome_amd.ops in the product)
+# ---------------------------------------------------------------------------------------------------
+
+def layer_step(ops, lw, views, h, e, n_out=None):
+    """One SymGatedGCN layer on sorted-order e (updated in place); returns the new h."""
+    H = h.shape[1]
+    P = ops.linear(h, lw.Wcat, lw.bcat)
+    A1, A2, A3, B1, B2 = (P[:, i * H:(i + 1) * H] for i in range(5))
+    if views.transposed:  # dgl.reverse(g): src <-> dst, see GraphViews.reversed
+        A2, A3, B1, B2 = A3, A2, B2, B1
+    ops.edge_gate(e, B1, B2, views, lw.W3, lw.norm, lw.scale_e, lw.shift_e)
+    return ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_out)
+
+
+def score_step(ops, pw, views, h, e, logits, n_edges=None):
+    hs = pw["hs"]
+    PQ = torch.empty((h.shape[0], 2 * hs), dtype=torch.float32, device=h.device)
+    ops.linear(h, pw["W1_src"], None, out=PQ[:, :hs])
+    ops.linear(h, pw["W1_dst"], pw["b1"], out=PQ[:, hs:])
+    Ps, Qd = PQ[:, :hs], PQ[:, hs:]
+    if views.transposed:
+        # x[src'] | x[dst'] = x[dst] | x[src]; b1 is added once either way
+        Ps, Qd = Qd, Ps
+    return ops.edge_score(e, Ps, Qd, views, pw["W1_e"], pw["W2"], pw["b2"], pw["W3"], pw["b3"], logits, num_edges=n_edges)
+
+
+def run_stack(ops, prep, views, x, e_raw, exchange=None, n_own=None, n_score=None, logits=None):
+    """Encoders -> L layers -> scorer.  `exchange(h)` (optional) refreshes halo rows before every
+    consumer of h; `n_own` limits the node update to the first rows, `n_score` the scorer to the first
+    sorted positions (both used by the destination-range partition, dist.py)."""
+    h = ops.encode(x, *prep.enc_node)
+    e = ops.encode(e_raw, *prep.enc_edge, gather=views.srt_eid, rows=views.num_edges)
+    for lw in prep.layers:
+        if exchange is not None:
+            h = exchange(h)
+        h = layer_step(ops, lw, views, h, e, n_out=n_own)
+    if exchange is not None:
+        h = exchange(h)
+    if logits is None:
+        logits = torch.empty(views.num_edges if n_score is None else n_score, dtype=torch.float32, device=h.device)
+    score_step(ops, prep.predictor, views, h, e, logits, n_edges=n_score)
+    return logits
+
+
+# ---------------------------------------------------------------------------------------------------
+# module entry points
+# ---------------------------------------------------------------------------------------------------
+
+def model_forward(model, graph, x, e):
+    """models/full_graph.py:22-30 on the MI355X."""
+    _refuse_training(model)
+    out_device = x.device
+    device = compute_device(x, e)
+    prep = prepared_for(model, device, Prepared)
+    views = views_for(graph, device)
+    if x.shape[0] != views.num_nodes or e.shape[0] != views.num_edges:
+        raise ValueError(f"x has {x.shape[0]} rows for {views.num_nodes} nodes, e has {e.shape[0]} rows for {views.num_edges} edges")
+    with torch.no_grad():
+        xd = x.detach().to(device=device, dtype=torch.float32).contiguous()
+        ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
+        logits = run_stack(hip_ops, prep, views, xd, ed)
+    return logits.unsqueeze(1).to(out_device)
+
+
+def layer_forward_edge_id_order(conv, g, h, e):
+    """gated_gcn_full.py:82-142 with e given and returned in edge-id order."""
+    _refuse_training(conv)
+    out_device = h.device
+    device = compute_device(h, e)
+    lw = prepared_for(conv, device, prepare_layer)
+    views = views_for(g, device)
+    with torch.no_grad():
+        hd = h.detach().to(device=device, dtype=torch.float32).contiguous()
+        ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
+        es = hip_ops.gather_rows(ed, views.srt_eid)
+        h_new = layer_step(hip_ops, lw, views, hd, es)
+        e_new = torch.empty_like(es)
+        e_new[views.srt_eid.long()] = es
+        h_new = F.dropout(h_new, conv.dropout, training=conv.training)
+    return h_new.to(out_device), e_new.to(out_device)
+
+
+def score_forward_edge_id_order(pred, graph, x, e):
+    out_device = x.device
+    device = compute_device(x, e)
+    pw = prepared_for(pred, device, prepare_predictor)
+    views = views_for(graph, device)
+    with torch.no_grad():
+        xd = x.detach().to(device=device, dtype=torch.float32).contiguous()
+        ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
+        es = hip_ops.gather_rows(ed, views.srt_eid)
+        logits = torch.empty(views.num_edges, dtype=torch.float32, device=device)
+        score_step(hip_ops, pw, views, xd, es, logits)
+    return logits.unsqueeze(1).to(out_device)

@@ -1,0 +1,60 @@
+"""Graph adapter: whatever the caller passes as `graph` -> GraphViews on the compute device.
+
+The reference hands the model a DGLGraph (inference.py:440, train.py:141,162,168).  DGL is not a
+dependency here: anything with `.edges()` -> (src, dst) and `.num_nodes()` works, as does a plain
+`(src, dst, num_nodes)` tuple or a prebuilt `GraphViews`.  Only the structure is read; ndata / edata
+are never touched, which is the observable effect of the reference's `g.local_scope()`
+(gated_gcn_full.py:84, score_predictor.py:20).
+"""
+import weakref
+
+import torch
+
+from .ops import GraphViews
+
+_cache = weakref.WeakKeyDictionary()
+
+
+def edge_list(graph):
+    if isinstance(graph, (tuple, list)):
+        src, dst, n = graph
+    else:
+        src, dst = graph.edges()
+        n = graph.num_nodes()
+    return torch.as_tensor(src), torch.as_tensor(dst), int(n)
+
+
+def views_for(graph, device):
+    """Build (or fetch the cached) views of `graph` on `device`.  Cached per graph OBJECT: callers such as
+    train.py:96 / :336 create fresh sub-graphs every step, which simply miss the cache."""
+    if isinstance(graph, GraphViews):
+        if graph.device != device:
+            raise ValueError(f"GraphViews live on {graph.device}, inputs on {device}")
+        return graph
+    key = None
+    if not isinstance(graph, (tuple, list)):
+        try:
+            hit = _cache.get(graph)
+            key = graph
+        except TypeError:  # not weak-referenceable
+            hit = None
+        if hit is not None and hit.device == device and hit.num_edges == int(graph.num_edges()) \
+                and hit.num_nodes == int(graph.num_nodes()):
+            return hit
+    src, dst, n = edge_list(graph)
+    src = src.to(device=device, dtype=torch.int32).contiguous()
+    dst = dst.to(device=device, dtype=torch.int32).contiguous()
+    views = GraphViews(src, dst, n)
+    if key is not None:
+        try:
+            _cache[key] = views
+        except TypeError:
+            pass
+    return views
+
+
+def reverse(graph, device=None):
+    """Counterpart of dgl.reverse(g, True, True) that reuses the built views (see GraphViews.reversed)."""
+    if not isinstance(graph, GraphViews):
+        graph = views_for(graph, device)
+    return graph.reversed()

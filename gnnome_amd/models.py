@@ -1,0 +1,38 @@
+"""`SymGatedGCNModel` - drop-in for the reference's models/full_graph.py:9-30.
+
+    model = SymGatedGCNModel(node_features, edge_features, hidden_features, hidden_ne_features,
+                             num_layers, hidden_edge_scores, normalization, dropout=None)
+    logits = model(graph, x, e)          # [E,1] fp32 logits in DGL edge-id order
+
+Same positional constructor (inference.py:435, train.py:248), same 190 state_dict keys as
+weights/weights.pt, same call.  Differences, all deliberate:
+  * `graph` may be a DGLGraph, any object with .edges()/.num_nodes(), a (src, dst, N) tuple or a
+    prebuilt gnnome_amd.ops.GraphViews.
+  * inputs may live on the CPU (inference.py:388 pins device='cpu'): they are staged to the current
+    HIP device and the logits are returned on the inputs' device.  The compute always runs on the
+    MI355X; without the HIP library or a GPU the call raises.
+  * the stray `print(x.shape)` of models/full_graph.py:25 is not reproduced.
+"""
+import torch.nn as nn
+
+from . import engine
+from .layers import ScorePredictor, SymGatedGCN_processor
+
+
+class SymGatedGCNModel(nn.Module):
+    def __init__(self, node_features, edge_features, hidden_features, hidden_ne_features, num_layers,
+                 hidden_edge_scores, normalization, dropout=None):
+        super().__init__()
+        self.linear1_node = nn.Linear(node_features, hidden_ne_features, bias=True)
+        self.linear2_node = nn.Linear(hidden_ne_features, hidden_features, bias=True)
+        self.linear1_edge = nn.Linear(edge_features, hidden_ne_features, bias=True)
+        self.linear2_edge = nn.Linear(hidden_ne_features, hidden_features, bias=True)
+        self.gnn = SymGatedGCN_processor(num_layers, hidden_features, normalization, dropout=dropout)
+        self.predictor = ScorePredictor(hidden_features, hidden_edge_scores)
+        self.relu = nn.ReLU()
+
+    def forward(self, graph, x, e):
+        return engine.model_forward(self, graph, x, e)
+
+
+__all__ = ["SymGatedGCNModel"]

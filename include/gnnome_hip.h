@@ -1,0 +1,131 @@
+/*
+ * gnnome_hip.h - C ABI of libgnnome_hip.so, the MI355X (gfx950) implementation of GNNome's
+ * SymGatedGCN edge-scoring path.
+ *
+ * The reference (lbcb-sci/GNNome) has no FFI seam for this path: the seam is the Python module
+ * `models.SymGatedGCNModel.forward(graph, x, e)` (models/full_graph.py:22-30), whose native work
+ * is done by two third-party wheels (DGL 0.8.1 graph kernels, PyTorch 1.9 dense/elementwise ops).
+ * Each entry point below names the reference call sites it replaces.  The Python host module
+ * `gnnome_amd.models.SymGatedGCNModel` binds them through ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is stream-ordered,
+ *     nothing synchronises the host
+ *   - matrices are row-major fp32; `ld*` arguments are row strides in ELEMENTS
+ *   - graph indices are int32 (the reference casts graphs with g.int(), utils/data_utils.py:32)
+ *   - return value: 0 on success, a negative GNNOME_E* code otherwise; gnnome_last_error() returns a
+ *     thread-local message for the last failure
+ *   - "sorted position" p in [0,E) is an edge's slot in destination-sorted (CSR-by-dst) order; all
+ *     [E,H] edge tensors handed to the kernels live in that order
+ */
+#ifndef GNNOME_HIP_H
+#define GNNOME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNOME_ABI_VERSION 1
+
+#define GNNOME_OK 0
+#define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
+#define GNNOME_EHIP (-2)      /* a HIP runtime call or a kernel launch failed                     */
+#define GNNOME_EWORKSPACE (-3) /* workspace too small                                             */
+
+/* normalisation applied inside the fused kernels (gated_gcn_full.py:37-42) */
+#define GNNOME_NORM_AFFINE 0  /* y = x*scale[c] + shift[c]: eval-mode BatchNorm1d folded to an affine,
+                                 or train-mode BatchNorm1d once the batch statistics are known     */
+#define GNNOME_NORM_LAYER 1   /* y = (x-mean_row)/sqrt(var_row+1e-5)*scale[c] + shift[c]: LayerNorm */
+
+int gnnome_abi_version(void);
+const char* gnnome_last_error(void);
+
+/* ---- graph views -------------------------------------------------------------------------------
+ * Replaces what DGL builds lazily inside g.update_all / dgl.reverse (gated_gcn_full.py:99,112-113,
+ * 125-126): the in-edge (by dst) and out-edge (by src) orderings of one edge list.
+ *   src,dst      int32[E]   edge endpoints in edge-id order (graph.edges())
+ *   in_ptr       int32[N+1] CSR offsets by destination over sorted positions
+ *   srt_src/dst  int32[E]   endpoints of the edge at sorted position p
+ *   srt_eid      int32[E]   original edge id of sorted position p (stable: ties keep edge-id order)
+ *   out_ptr      int32[N+1] CSR offsets by source
+ *   out_pos      int32[E]   for each node, the sorted positions of its out-edges (ascending)
+ */
+int gnnome_graph_views_workspace_bytes(int64_t num_nodes, int64_t num_edges, size_t* bytes_host);
+int gnnome_build_graph_views(const int32_t* src, const int32_t* dst, int64_t num_nodes, int64_t num_edges,
+                             int32_t* in_ptr, int32_t* srt_src, int32_t* srt_dst, int32_t* srt_eid,
+                             int32_t* out_ptr, int32_t* out_pos, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/* ---- encoders ----------------------------------------------------------------------------------
+ * out[r,:] = W2 * relu(W1 * in[row(r),:] + b1) + b2, row(r) = gather ? gather[r] : r.
+ * Replaces linear2_*(relu(linear1_*(.))) at models/full_graph.py:26-27.  `gather` = srt_eid turns
+ * the edge-id-ordered e[E,F] into the sorted-order e0[E,H] without a separate permute pass.
+ *   in [rows_in,F]  W1 [M,F]  b1 [M]  W2 [H,M]  b2 [H]  out [rows,H];  F <= 8, M <= 64
+ */
+int gnnome_encode_f32(const float* in, int64_t rows, int in_features, const int32_t* gather,
+                      const float* W1, const float* b1, int hidden_ne, const float* W2, const float* b2,
+                      int hidden, float* out, void* stream);
+
+/* ---- dense linear on the matrix cores -----------------------------------------------------------
+ * C[M,Nout] = A[M,K] * W[Nout,K]^T + bias (torch nn.Linear layout), exact fp32 (v_mfma_f32_32x32x2_f32).
+ * Replaces the five node projections A_1,A_2,A_3,B_1,B_2 (gated_gcn_full.py:91-96, one call with the
+ * weights concatenated) and the node halves of predictor.W1 (score_predictor.py:13-14).
+ *   K % 8 == 0; bias may be NULL
+ */
+int gnnome_linear_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias,
+                      int Nout, float* C, int ldc, void* stream);
+
+/* ---- fused edge gate ----------------------------------------------------------------------------
+ * For every sorted position p:
+ *   e_out[p,:] = relu(norm_e(B1h[srt_src[p],:] + B2h[srt_dst[p],:] + e_in[p,:] * W3^T)) + e_in[p,:]
+ * i.e. B_3(e), u_add_v, bn_e, relu and the residual of gated_gcn_full.py:97,104-110 (and the
+ * bit-identical second evaluation at :117-122) in one pass.  B_3's bias must already be folded into
+ * B2h.  e_out may alias e_in.  H in {32,64,128,256}.
+ */
+int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num_edges, int hidden,
+                         const float* B1h, const float* B2h, int ld_node, const int32_t* srt_src,
+                         const int32_t* srt_dst, const float* W3, int ldw, int norm_kind,
+                         const float* norm_scale, const float* norm_shift, void* stream);
+
+/* ---- fused gated aggregation + node update -------------------------------------------------------
+ * For every node i < num_nodes_out, with s_p = sigmoid(e[p,:]):
+ *   fwd = sum_{p in in(i)}  s_p * A2h[srt_src[p],:] / (sum_{p in in(i)}  s_p + 1e-6)
+ *   bwd = sum_{p in out(i)} s_p * A3h[srt_dst[p],:] / (sum_{p in out(i)} s_p + 1e-6)
+ *   h_out[i,:] = relu(norm_h(A1h[i,:] + fwd + bwd)) + h_in[i,:]
+ * Replaces sigmoid + both update_all pairs + the node epilogue, gated_gcn_full.py:111-114,124-137.
+ * Sums run in ascending sorted position, sequentially per node: bit-reproducible.
+ */
+int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num_nodes_out, const float* A1h,
+                              const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
+                              const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
+                              const int32_t* srt_dst, const float* h_in, int ld_h, float* h_out, int norm_kind,
+                              const float* norm_scale, const float* norm_shift, void* stream);
+
+/* ---- fused edge scorer --------------------------------------------------------------------------
+ * For every sorted position p < num_edges:
+ *   z1 = relu(Ps[srt_src[p],:] + Qd[srt_dst[p],:] + e[p,:] * W1e^T)        (b1 folded into Qd)
+ *   logits[eid(p)] = W3 . relu(W2 * z1 + b2) + b3,   eid(p) = srt_eid ? srt_eid[p] : p
+ * Replaces ScorePredictor.apply_edges (score_predictor.py:12-17) without materialising the
+ * [E,3H] concatenation; W1e is the third column block of predictor.W1 (row stride ldw1 = 3H).
+ *   hidden in {32,64,128,256}; hidden_edge_scores in {32,64,128}; W2 is [32,hs], W3 is [32]
+ */
+int gnnome_edge_score_f32(const float* e, int64_t num_edges, int hidden, int hidden_edge_scores,
+                          const float* Ps, const float* Qd, int ld_node, const int32_t* srt_src,
+                          const int32_t* srt_dst, const int32_t* srt_eid, const float* W1e, int ldw1,
+                          const float* W2, const float* b2, const float* W3, const float* b3, float* logits,
+                          void* stream);
+
+/* ---- row gather (halo packing for the destination-range partition) ------------------------------
+ * out[r,:] = in[idx[r],:]   rows of `width` floats, width % 4 == 0
+ */
+int gnnome_gather_rows_f32(const float* in, int ld_in, const int32_t* idx, int64_t rows, int width, float* out,
+                           int ld_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNOME_HIP_H */

@@ -1,0 +1,120 @@
+"""CPU-side checks: C-ABI exports, module/state_dict contract, and the host kernel sequence
+(gnnome_amd/engine.py) replayed over the checker backend against golden vectors."""
+import ctypes
+import re
+
+import pytest
+import torch
+
+import cpu_ops
+import gnnome_amd
+from conftest import load_golden
+from gnnome_amd import _lib, engine
+from gnnome_amd.synth import random_state_dict
+
+CPU = torch.device("cpu")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(_lib.HEADER_PATH).read()
+    declared = set(re.findall(r"\b(gnnome_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().gnnome_abi_version() == _lib.ABI_VERSION
+    m = re.search(r"#define GNNOME_ABI_VERSION (\d+)", header)
+    assert int(m.group(1)) == _lib.ABI_VERSION
+
+
+def test_argument_validation_without_a_gpu():
+    lib = _lib.load()
+    rc = lib.gnnome_linear_f32(None, 4, 60, 60, None, 60, None, 8, None, 8, None)
+    assert rc == -1 and b"null" in lib.gnnome_last_error()
+    rc = lib.gnnome_edge_gate_f32(None, None, 0, 64, None, None, 64, None, None, None, 64, 0, None, None, None)
+    assert rc == 0  # E == 0 is a no-op
+    one = ctypes.c_void_p(16)
+    rc = lib.gnnome_edge_gate_f32(one, one, 5, 96, one, one, 96, one, one, one, 96, 0, one, one, None)
+    assert rc == -1 and b"hidden=96" in lib.gnnome_last_error()
+    with pytest.raises(_lib.GnnomeHipError):
+        _lib.check(rc, "edge_gate")
+
+
+def test_module_contract_matches_shipped_weights(shipped_weights):
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 8, 64, "batch", dropout=0.2)
+    assert list(m.state_dict().keys()) == list(shipped_weights.keys())
+    assert all(m.state_dict()[k].shape == v.shape and m.state_dict()[k].dtype == v.dtype for k, v in shipped_weights.items())
+    m.load_state_dict(shipped_weights)
+    assert sum(p.numel() for p in m.parameters()) == 218465
+    assert len(list(m.parameters())) == 142 and len(list(m.buffers())) == 48
+    assert m.gnn.convs[0].dropout == 0.2
+    with pytest.raises(ValueError):
+        gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 1, 64, "none")
+
+
+def test_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 1, 64, "batch").eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m((torch.tensor([0]), torch.tensor([1]), 2), torch.zeros(2, 2), torch.zeros(1, 2))
+
+
+def _host_forward(sd, g, normalization="batch", reverse=False, layers=8):
+    hidden = sd["linear2_node.weight"].shape[0]
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, layers, 64, normalization).eval()
+    m.load_state_dict(sd)
+    prep = engine.Prepared(m, CPU)
+    views = cpu_ops.CpuViews(g["src"], g["dst"], g["num_nodes"])
+    x = g["x"]
+    if reverse:
+        views, x = views.reversed(), g["x_rev"]
+    return engine.run_stack(cpu_ops, prep, views, x, g["e"]).unsqueeze(1)
+
+
+# north_star's bar: max |sigmoid(logit) - sigmoid(reference logit)| < 1e-4.  The reference's own fp32
+# result sits 4.9e-5 from an fp64 evaluation of the same network on G2 (|e| reaches ~470 by layer 8),
+# so a re-associated fp32 evaluation cannot be expected to agree much better than a few 1e-5.
+def _close(got, want, tol=1e-4):
+    assert got.shape == want.shape
+    assert (torch.sigmoid(got) - torch.sigmoid(want)).abs().max().item() < tol
+
+
+def test_host_sequence_matches_reference_goldens(shipped_weights):
+    _close(_host_forward(shipped_weights, load_golden("g1_hand.pt")), load_golden("g1_hand.pt")["logits"])
+    _close(_host_forward(shipped_weights, load_golden("g2_uniform_1k.pt")), load_golden("g2_uniform_1k.pt")["logits"])
+    for hidden in (128, 256):
+        g = load_golden(f"g5_eval_h{hidden}.pt")
+        _close(_host_forward(random_state_dict(hidden, seed=g["seed"]), g), g["logits"])
+
+
+def test_host_sequence_layernorm_and_reversed_graph():
+    g = load_golden("g6_layernorm_h64.pt")
+    sd = {k: v for k, v in random_state_dict(64, seed=g["seed"]).items() if "running_" not in k and "num_batches" not in k}
+    _close(_host_forward(sd, g, normalization="layer"), g["logits"])
+    g = load_golden("g4_reverse_h64.pt")
+    sd = random_state_dict(64, seed=g["seed"])
+    _close(_host_forward(sd, g), g["logits"])
+    # dgl.reverse(g, True, True) (train.py:165) through the free "transposed" views
+    _close(_host_forward(sd, g, reverse=True), g["logits_rev"])
+
+
+def test_views_definition():
+    g = load_golden("g1_hand.pt")
+    v = cpu_ops.CpuViews(g["src"], g["dst"], g["num_nodes"])
+    src, dst = g["src"].long(), g["dst"].long()
+    assert torch.equal(v.srt_dst.long(), dst[v.srt_eid.long()]) and torch.equal(v.srt_src.long(), src[v.srt_eid.long()])
+    assert (v.srt_dst[1:] >= v.srt_dst[:-1]).all()
+    for i in range(g["num_nodes"]):
+        ins = range(int(v.in_ptr[i]), int(v.in_ptr[i + 1]))
+        assert all(int(v.srt_dst[p]) == i for p in ins) and len(ins) == int((dst == i).sum())
+        outs = v.out_pos[int(v.out_ptr[i]):int(v.out_ptr[i + 1])].long()
+        assert all(int(v.srt_src[p]) == i for p in outs) and len(outs) == int((src == i).sum())
+        assert (outs[1:] > outs[:-1]).all()
+
+
+def test_feature_prep_matches_golden_inputs():
+    from gnnome_amd.features import degree_features
+    g = load_golden("g4_reverse_h64.pt")
+    assert torch.equal(degree_features(g["src"], g["dst"], g["num_nodes"]), g["x"])
+    assert torch.equal(degree_features(g["src"], g["dst"], g["num_nodes"], reverse=True), g["x_rev"])
