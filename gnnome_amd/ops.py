@@ -74,7 +74,8 @@ class GraphViews:
         the contiguous (by-dst) and permuted (by-src) runs exchanged by the caller (`transposed`)."""
         r = object.__new__(GraphViews)
         for k in GraphViews.__slots__:
-            setattr(r, k, getattr(self, k))
+            if k != "__weakref__":
+                setattr(r, k, getattr(self, k))
         r.transposed = not self.transposed
         return r
 
