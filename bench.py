@@ -79,31 +79,39 @@ class KernelTimer:
         return sum(s.elapsed_time(t) for s, t in ev) / max(len(ev), 1), len(ev)
 
 
-def cpu_baseline(hidden, kind, budget_s=25.0):
+def cpu_baseline(hidden, kind, budget_s=30.0):
     """The oracle (torch-CPU restatement of the reference's CPU/DGL path) timed on this host's cores, on a
-    bounded sample of the workload: same generator, same width, E = 200k."""
+    bounded sample of the workload: same generator, same width, E = 100k.  The reference's CPU path is
+    torch + DGL-OpenMP with the library default thread count; torch's intra-op pool is tried at 8, 32 and
+    all cores and the FASTEST setting is the one reported (oversubscribed pools are much slower)."""
     from gnnome_amd.synth import make_graph, random_state_dict
     from oracle.symgated_oracle import degree_features, model_from_state_dict
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    n, e = 20_000, 200_000
+    n, e = 10_000, 100_000
     g = make_graph(n, e, seed=1, kind=kind)
     x = degree_features(g["src"], g["dst"], n)
     model = model_from_state_dict(random_state_dict(hidden, seed=1)).eval()
     graph = (g["src"], g["dst"], n)
-    times = []
-    with torch.no_grad():
-        model(graph, x, g["e"])  # warm-up
-        t_all = time.perf_counter()
-        while len(times) < 3 and (time.perf_counter() - t_all) < budget_s:
-            t0 = time.perf_counter()
-            model(graph, x, g["e"])
-            times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2]
+    best = None
+    t_all = time.perf_counter()
+    for threads in sorted({min(8, cores), min(32, cores), cores}):
+        if best is not None and time.perf_counter() - t_all > budget_s:
+            break
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            model(graph, x, g["e"])  # warm-up
+            times = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                model(graph, x, g["e"])
+                times.append(time.perf_counter() - t0)
+        if best is None or min(times) < best[0]:
+            best = (min(times), threads)
     return {
-        "value": e / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{kind} synthetic graph N={n} E={e} H={hidden} L=8 fp32, oracle/symgated_oracle.py (torch-CPU "
-                  f"restatement; DGL 0.8.1 not installable offline), 1 warm-up + median of {len(times)}",
+        "value": e / best[0], "unit": "edges/s", "cores": best[1], "kind": "port",
+        "sample": f"{kind} synthetic graph N={n} E={e} H={hidden} L=8 fp32 through oracle/symgated_oracle.py (torch-CPU "
+                  f"restatement of the reference path; DGL 0.8.1 is not installable offline); 1 warm-up + best of 2 per "
+                  f"thread setting, best of 8/32/{cores} threads on a {cores}-core host",
     }
 
 

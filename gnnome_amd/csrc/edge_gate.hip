@@ -99,6 +99,154 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_gate(const float* e_in, f
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Persistent, weight-stationary variant for H <= 128 and the affine norm (the default model).
+//
+// One 8-wave workgroup per CU keeps W3 (H x H, padded) in LDS for its whole life and walks a contiguous
+// run of 32*RB-edge tiles.  Wave (rb, cb) owns the 32x32 block (row block rb, column block cb) of the
+// tile: one v_mfma_f32_32x32x2_f32 accumulator, K = H in one sweep, two waves per SIMD.  The e tile is
+// double-buffered in LDS: tile t+1 sits in registers while tile t is multiplied and is written to the
+// other buffer after tile t's epilogue, so its HBM latency is covered by a whole tile of MFMA work;
+// the B1h[src] / B2h[dst] gathers of tile t are issued before its MFMA sweep and consumed after it;
+// the residual e_in is re-read from the LDS tile, not from memory.  HBM traffic per edge is exactly
+// one read and one write of an H-float row plus two int32 indices.
+// ---------------------------------------------------------------------------------------------------
+template <int CB, int RB>
+struct GateP {
+    static constexpr int H = 32 * CB, TM = 32 * RB, NW = CB * RB, NT = 64 * NW, LDK = H + 4;
+    static constexpr int kPieces = TM * (H / 4) / NT;  // float4 per thread per tile (= 4)
+    static constexpr int kWPieces = H * (H / 4) / NT;
+    static constexpr int kLdsFloats = (H + 2 * TM) * LDK;
+};
+
+template <int CB, int RB>
+__global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_persistent(
+    const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
+    const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
+    const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block) {
+    using P = GateP<CB, RB>;
+    constexpr int H = P::H, TM = P::TM, NT = P::NT, LDK = P::LDK;
+    __shared__ __attribute__((aligned(16))) float lds[P::kLdsFloats];
+    float* Ws = lds;
+    float* As0 = lds + H * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = wave % RB, cb = wave / RB, cl = lane & 31, half = lane >> 5;
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = min(num_tiles, t_begin + tiles_per_block);
+    if (t_begin >= t_end) return;
+
+    // W3 -> LDS, once
+#pragma unroll
+    for (int it = 0; it < P::kWPieces; ++it) {
+        const int f = tid + NT * it, row = f / (H / 4), c4 = f % (H / 4);
+        *reinterpret_cast<f32x4*>(Ws + row * LDK + 4 * c4) = *reinterpret_cast<const f32x4*>(W3 + (int64_t)row * ldw + 4 * c4);
+    }
+    const float sc = scale[32 * cb + cl], sh = shift[32 * cb + cl];
+
+    auto load_tile = [&](int t, f32x4 (&r)[P::kPieces]) {
+        const int64_t row0 = (int64_t)t * TM;
+        const int valid = (int)min((int64_t)TM, E - row0);
+#pragma unroll
+        for (int it = 0; it < P::kPieces; ++it) {
+            const int f = tid + NT * it, row = min(f / (H / 4), valid - 1), c4 = f % (H / 4);
+            r[it] = *reinterpret_cast<const f32x4*>(e_in + (row0 + row) * H + 4 * c4);
+        }
+    };
+    auto store_tile = [&](float* buf, const f32x4 (&r)[P::kPieces]) {
+#pragma unroll
+        for (int it = 0; it < P::kPieces; ++it) {
+            const int f = tid + NT * it, row = f / (H / 4), c4 = f % (H / 4);
+            *reinterpret_cast<f32x4*>(buf + row * LDK + 4 * c4) = r[it];
+        }
+    };
+    // lane l < 32 holds srt_src, lane l >= 32 srt_dst of row (32*rb + (l & 31)) of tile t
+    auto load_idx = [&](int t) {
+        const int64_t row0 = (int64_t)t * TM;
+        const int valid = (int)min((int64_t)TM, E - row0);
+        const int64_t row = row0 + min(32 * rb + cl, valid - 1);
+        return half ? srt_dst[row] : srt_src[row];
+    };
+
+    f32x4 stage[P::kPieces];
+    load_tile(t_begin, stage);
+    int idx_cur = load_idx(t_begin);
+    store_tile(As0, stage);
+    int idx_next = 0;
+    if (t_begin + 1 < t_end) {
+        load_tile(t_begin + 1, stage);
+        idx_next = load_idx(t_begin + 1);
+    }
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        float* buf = As0 + ((t - t_begin) & 1) * TM * LDK;
+        const int64_t row0 = (int64_t)t * TM;
+        const int valid = (int)min((int64_t)TM, E - row0);
+
+        // gathers for this tile: issued now, consumed after the MFMA sweep
+        float g1[16], g2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = cd_row(r, lane);  // row inside this wave's 32-row block
+            const int s_i = __shfl(idx_cur, lr), d_i = __shfl(idx_cur, 32 + lr);
+            g1[r] = B1h[(int64_t)s_i * ldn + 32 * cb + cl];
+            g2[r] = B2h[(int64_t)d_i * ldn + 32 * cb + cl];
+        }
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* ap = buf + (32 * rb + cl) * LDK + 4 * half;
+        const float* wp = Ws + (32 * cb + cl) * LDK + 4 * half;
+#pragma unroll 4
+        for (int q = 0; q < H / 8; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * q);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(wp + 8 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
+        }
+
+        float* eout_tile = e_out + row0 * H;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = 32 * rb + cd_row(r, lane);
+            const float x = acc[r] + (g1[r] + g2[r]);
+            const float y = fmaxf(x * sc + sh, 0.f) + buf[lr * LDK + 32 * cb + cl];
+            if (lr < valid) eout_tile[(uint32_t)(lr * H + 32 * cb + cl)] = y;
+        }
+
+        // hand tile t+1 to the other buffer (its last readers finished before the previous barrier),
+        // then start fetching tile t+2
+        if (t + 1 < t_end) {
+            store_tile(As0 + ((t + 1 - t_begin) & 1) * TM * LDK, stage);
+            idx_cur = idx_next;
+            if (t + 2 < t_end) {
+                load_tile(t + 2, stage);
+                idx_next = load_idx(t + 2);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int CB, int RB>
+static int launch_gate_persistent(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
+                                  const int32_t* ss, const int32_t* sd, const float* W3, int ldw, const float* scale,
+                                  const float* shift, hipStream_t s) {
+    using P = GateP<CB, RB>;
+    const int64_t tiles = (E + P::TM - 1) / P::TM;
+    GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
+    const int grid_max = kNumCUs;  // one resident workgroup per CU (LDS-limited)
+    const int tpb = (int)((tiles + grid_max - 1) / grid_max);
+    const int grid = (int)((tiles + tpb - 1) / tpb);
+    hipLaunchKernelGGL((k_edge_gate_persistent<CB, RB>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd,
+                       W3, ldw, scale, shift, (int)tiles, tpb);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
 template <int NB>
 static int launch_gate(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
                        const int32_t* ss, const int32_t* sd, const float* W3, int ldw, int norm, const float* scale,
@@ -131,6 +279,10 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
     GN_REQUIRE(ld_node >= hidden && ldw >= hidden && ldw % 4 == 0, "edge_gate: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0), "edge_gate: e_in and W3 must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (norm_kind == GNNOME_NORM_AFFINE && hidden == 128)
+        return launch_gate_persistent<4, 2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
+    if (norm_kind == GNNOME_NORM_AFFINE && hidden == 64)
+        return launch_gate_persistent<2, 4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
     switch (hidden) {
         case 64: return launch_gate<2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);
         case 128: return launch_gate<4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);

@@ -80,8 +80,8 @@ extern "C" int gnnome_graph_views_workspace_bytes(int64_t num_nodes, int64_t num
 
 extern "C" int gnnome_build_graph_views(const int32_t* src, const int32_t* dst, int64_t num_nodes, int64_t num_edges,
                                         int32_t* in_ptr, int32_t* srt_src, int32_t* srt_dst, int32_t* srt_eid,
-                                        int32_t* out_ptr, int32_t* out_pos, void* workspace, size_t workspace_bytes,
-                                        void* stream) {
+                                        int32_t* out_ptr, int32_t* out_pos, int32_t* out_dst, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
     using namespace gnnome;
     GN_REQUIRE(num_nodes >= 0 && num_edges >= 0 && num_nodes < (1ll << 31) && num_edges < (1ll << 31),
                "graph_views: N=%lld E=%lld out of int32 range", (long long)num_nodes, (long long)num_edges);
@@ -93,7 +93,7 @@ extern "C" int gnnome_build_graph_views(const int32_t* src, const int32_t* dst, 
         GN_HIP(hipMemsetAsync(out_ptr, 0, (size_t)(N + 1) * sizeof(int32_t), s));
         return GNNOME_OK;
     }
-    GN_REQUIRE(src && dst && srt_src && srt_dst && srt_eid && out_pos && workspace, "graph_views: null pointer");
+    GN_REQUIRE(src && dst && srt_src && srt_dst && srt_eid && out_pos && out_dst && workspace, "graph_views: null pointer");
     const unsigned bits = key_bits(N);
     size_t sort_bytes = 0;
     {
@@ -122,6 +122,8 @@ extern "C" int gnnome_build_graph_views(const int32_t* src, const int32_t* dst, 
     GN_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, (const int32_t*)srt_src, keys_tmp, (const int32_t*)iota, out_pos,
                                      (size_t)E, 0u, bits, s));
     hipLaunchKernelGGL(k_lower_bound, dim3(grid_for(N + 1)), dim3(256), 0, s, (const int32_t*)keys_tmp, E, out_ptr, N);
+    GN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_take, dim3(grid_for(E)), dim3(256), 0, s, (const int32_t*)srt_dst, (const int32_t*)out_pos, out_dst, E);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

@@ -13,55 +13,14 @@
 // e rows as whole H*4-byte lines.  Bound: HBM - 2 reads of e[E,H] per layer (8*H bytes per edge).
 //
 // Lane mapping: a row of H floats is covered by H/4 lanes holding a float4 each; a wave64 therefore
-// walks 64/(H/4) edges at once (4 at H=64, 2 at H=128, 1 at H=256) and the lane groups are combined
-// with __shfl_xor at the end.  Summation order is fixed by the graph, not by scheduling.
+// walks G = 64/(H/4) edges at once (4 at H=64, 2 at H=128, 1 at H=256), lane group g taking every
+// G-th item of the node's list, and the groups are combined with __shfl_xor at the end.  The
+// summation order is a function of the graph alone, never of scheduling: results are bit-reproducible.
 #include "common.h"
 
 namespace gnnome {
 
 constexpr int kAggThreads = 256;
-
-template <int H, bool VIA_POS>
-__device__ __forceinline__ void accumulate(f32x4& num, f32x4& den, const float* __restrict__ e,
-                                           const float* __restrict__ table, int ldn, const int32_t* __restrict__ nbr,
-                                           const int32_t* __restrict__ pos, int begin, int end, int group, int c) {
-    constexpr int G = 64 / (H / 4);
-    // two edges per group in flight
-    int q = begin + group;
-    for (; q + G < end; q += 2 * G) {
-        const int p0 = VIA_POS ? pos[q] : q;
-        const int p1 = VIA_POS ? pos[q + G] : q + G;
-        const int n0 = nbr[p0], n1 = nbr[p1];
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(e + (int64_t)p0 * H + c);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(e + (int64_t)p1 * H + c);
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(table + (int64_t)n0 * ldn + c);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(table + (int64_t)n1 * ldn + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float s0 = sigmoidf_(x0[j]);
-            num[j] += s0 * a0[j];
-            den[j] += s0;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float s1 = sigmoidf_(x1[j]);
-            num[j] += s1 * a1[j];
-            den[j] += s1;
-        }
-    }
-    if (q < end) {
-        const int p0 = VIA_POS ? pos[q] : q;
-        const int n0 = nbr[p0];
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(e + (int64_t)p0 * H + c);
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(table + (int64_t)n0 * ldn + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float s0 = sigmoidf_(x0[j]);
-            num[j] += s0 * a0[j];
-            den[j] += s0;
-        }
-    }
-}
 
 template <int H>
 __device__ __forceinline__ float group_sum(float v) {
@@ -81,39 +40,87 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
+// One wave per node.  The node's in-edges and out-edges form ONE work list of (sorted position,
+// neighbour row, direction) items; each lane first fetches the indices of one item (so the dependent
+// index loads happen once per 64 items, not once per edge), then the wave walks the list with U items
+// per lane group in flight: 2*U*G independent H*4-byte row loads per wave.
 template <int H, int NORM>
 __global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
     const float* __restrict__ e, int64_t n_out, const float* __restrict__ A1h, const float* __restrict__ A2h,
     const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src,
-    const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos, const int32_t* __restrict__ srt_dst,
+    const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_dst,
     const float* __restrict__ h_in, int ldh, float* __restrict__ h_out, const float* __restrict__ scale,
     const float* __restrict__ shift, int total_blocks) {
-    constexpr int LPR = H / 4;
+    constexpr int LPR = H / 4, G = 64 / LPR, U = (H == 256) ? 8 : 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t node = (int64_t)xcd_remap(blockIdx.x, total_blocks) * (kAggThreads / 64) + wave;
     if (node >= n_out) return;
     const int group = lane / LPR, c = (lane % LPR) * 4;
 
-    f32x4 nf = {0.f, 0.f, 0.f, 0.f}, df = nf, nb = nf, db = nf;
-    accumulate<H, false>(nf, df, e, A2h, ldn, srt_src, nullptr, in_ptr[node], in_ptr[node + 1], group, c);
-    accumulate<H, true>(nb, db, e, A3h, ldn, srt_dst, out_pos, out_ptr[node], out_ptr[node + 1], group, c);
-
+    const int ib = in_ptr[node], din = in_ptr[node + 1] - ib;
+    const int ob = out_ptr[node], cnt = din + out_ptr[node + 1] - ob;
     const f32x4 a1 = *reinterpret_cast<const f32x4*>(A1h + node * ldn + c);
+
+    f32x4 nf = {0.f, 0.f, 0.f, 0.f}, df = nf, nb = nf, db = nf;
+    for (int base = 0; base < cnt; base += 64) {
+        // lane l owns item base + l
+        const int j = base + lane;
+        int my_p = 0, my_n = 0;
+        if (j < din) {
+            my_p = ib + j;
+            my_n = srt_src[my_p];
+        } else if (j < cnt) {
+            my_p = out_pos[ob + j - din];
+            my_n = out_dst[ob + j - din];
+        }
+        const int m = min(64, cnt - base);
+        for (int j0 = 0; j0 < m; j0 += G * U) {
+            f32x4 x[U], a[U];
+            bool live[U], fwd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int item = j0 + u * G + group;
+                live[u] = item < m;
+                const int it = live[u] ? item : 0;
+                const int p = __shfl(my_p, it), nn = __shfl(my_n, it);
+                fwd[u] = base + it < din;
+                const float* tb = fwd[u] ? A2h : A3h;
+                x[u] = *reinterpret_cast<const f32x4*>(e + (int64_t)p * H + c);
+                a[u] = *reinterpret_cast<const f32x4*>(tb + (int64_t)nn * ldn + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (live[u]) {
+                    f32x4 s;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] = sigmoidf_(x[u][k]);
+                    if (fwd[u]) {
+                        nf += s * a[u];
+                        df += s;
+                    } else {
+                        nb += s * a[u];
+                        db += s;
+                    }
+                }
+            }
+        }
+    }
+
     f32x4 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float num_f = group_sum<H>(nf[j]), den_f = group_sum<H>(df[j]);
-        const float num_b = group_sum<H>(nb[j]), den_b = group_sum<H>(db[j]);
-        v[j] = a1[j] + num_f / (den_f + kAggEps) + num_b / (den_b + kAggEps);
+    for (int k = 0; k < 4; ++k) {
+        const float num_f = group_sum<H>(nf[k]), den_f = group_sum<H>(df[k]);
+        const float num_b = group_sum<H>(nb[k]), den_b = group_sum<H>(db[k]);
+        v[k] = a1[k] + num_f / (den_f + kAggEps) + num_b / (den_b + kAggEps);
     }
     if (NORM == GNNOME_NORM_LAYER) {
         const float mean = row_sum<H>(v[0] + v[1] + v[2] + v[3]) * (1.0f / H);
         float s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s2 += (v[j] - mean) * (v[j] - mean);
+        for (int k = 0; k < 4; ++k) s2 += (v[k] - mean) * (v[k] - mean);
         const float rstd = rsqrtf(row_sum<H>(s2) * (1.0f / H) + kNormEps);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (v[j] - mean) * rstd;
+        for (int k = 0; k < 4; ++k) v[k] = (v[k] - mean) * rstd;
     }
     if (group == 0) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
         const f32x4 hi = *reinterpret_cast<const f32x4*>(h_in + node * ldh + c);
         f32x4 y;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = fmaxf(v[j] * sc[j] + sh[j], 0.f) + hi[j];
+        for (int k = 0; k < 4; ++k) y[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f) + hi[k];
         *reinterpret_cast<f32x4*>(h_out + node * H + c) = y;
     }
 }
@@ -129,17 +136,17 @@ __global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
 template <int H>
 static int launch_agg(const float* e, int64_t n_out, const float* A1h, const float* A2h, const float* A3h, int ldn,
                       const int32_t* in_ptr, const int32_t* ss, const int32_t* out_ptr, const int32_t* out_pos,
-                      const int32_t* sd, const float* h_in, int ldh, float* h_out, int norm, const float* scale,
+                      const int32_t* od, const float* h_in, int ldh, float* h_out, int norm, const float* scale,
                       const float* shift, hipStream_t s) {
     const int64_t blocks = (n_out + (kAggThreads / 64) - 1) / (kAggThreads / 64);
     GN_REQUIRE(blocks < (1ll << 31), "node_aggregate: too many nodes");
     if (norm == GNNOME_NORM_AFFINE) {
         hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
-                           n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, sd, h_in, ldh, h_out, scale, shift,
+                           n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
                            (int)blocks);
     } else {
         hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_LAYER>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
-                           n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, sd, h_in, ldh, h_out, scale, shift,
+                           n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
                            (int)blocks);
     }
     GN_LAUNCH_CHECK();
@@ -151,12 +158,12 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
 extern "C" int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num_nodes_out, const float* A1h,
                                          const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
                                          const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
-                                         const int32_t* srt_dst, const float* h_in, int ld_h, float* h_out,
+                                         const int32_t* out_dst, const float* h_in, int ld_h, float* h_out,
                                          int norm_kind, const float* norm_scale, const float* norm_shift, void* stream) {
     using namespace gnnome;
     GN_REQUIRE(num_nodes_out >= 0, "node_aggregate: negative node count");
     if (num_nodes_out == 0) return GNNOME_OK;
-    // e / srt_src / srt_dst / out_pos may be NULL for a graph without edges (never dereferenced then)
+    // e / srt_src / out_pos / out_dst may be NULL for a graph without edges (never dereferenced then)
     GN_REQUIRE(A1h && A2h && A3h && in_ptr && out_ptr && h_in && h_out && norm_scale && norm_shift,
                "node_aggregate: null pointer");
     GN_REQUIRE(norm_kind == GNNOME_NORM_AFFINE || norm_kind == GNNOME_NORM_LAYER, "node_aggregate: bad norm_kind %d",
@@ -167,9 +174,9 @@ extern "C" int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num
                "node_aggregate: tensors must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     switch (hidden) {
-        case 64: return launch_agg<64>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, srt_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
-        case 128: return launch_agg<128>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, srt_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
-        case 256: return launch_agg<256>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, srt_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
+        case 64: return launch_agg<64>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
+        case 128: return launch_agg<128>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
+        case 256: return launch_agg<256>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
         default: set_error("node_aggregate: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
 }

@@ -39,7 +39,7 @@ def _rows(t, name):
 class GraphViews:
     """In-edge / out-edge orderings of one edge list (see include/gnnome_hip.h, "graph views")."""
 
-    __slots__ = ("num_nodes", "num_edges", "in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "device",
+    __slots__ = ("num_nodes", "num_edges", "in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst", "device",
                  "transposed", "__weakref__")
 
     def __init__(self, src, dst, num_nodes):
@@ -57,14 +57,15 @@ class GraphViews:
         self.num_nodes, self.num_edges, self.device, self.transposed = n, e, dev, False
         mk = lambda k: torch.empty(k, dtype=torch.int32, device=dev)  # noqa: E731
         self.in_ptr, self.out_ptr = mk(n + 1), mk(n + 1)
-        self.srt_src, self.srt_dst, self.srt_eid, self.out_pos = mk(e), mk(e), mk(e), mk(e)
+        self.srt_src, self.srt_dst, self.srt_eid, self.out_pos, self.out_dst = mk(e), mk(e), mk(e), mk(e), mk(e)
         need = ctypes.c_size_t(0)
         with torch.cuda.device(dev):
             _lib.check(lib.gnnome_graph_views_workspace_bytes(n, e, ctypes.byref(need)), "graph_views_workspace_bytes")
             ws = torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=dev)
             _lib.check(lib.gnnome_build_graph_views(_ptr(src), _ptr(dst), n, e, _ptr(self.in_ptr), _ptr(self.srt_src),
                                                     _ptr(self.srt_dst), _ptr(self.srt_eid), _ptr(self.out_ptr),
-                                                    _ptr(self.out_pos), _ptr(ws), ws.numel(), _stream(dev)),
+                                                    _ptr(self.out_pos), _ptr(self.out_dst), _ptr(ws), ws.numel(),
+                                                    _stream(dev)),
                        "build_graph_views")
             ws.record_stream(torch.cuda.current_stream(dev))
 
@@ -137,7 +138,7 @@ def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_n
     with torch.cuda.device(h_in.device):
         _lib.check(lib.gnnome_node_aggregate_f32(_ptr(e), hidden, n_out, _ptr(A1h), _ptr(A2h), _ptr(A3h), ldn,
                                                  _ptr(views.in_ptr), _ptr(views.srt_src), _ptr(views.out_ptr),
-                                                 _ptr(views.out_pos), _ptr(views.srt_dst), _ptr(h_in), ldh, _ptr(h_out),
+                                                 _ptr(views.out_pos), _ptr(views.out_dst), _ptr(h_in), ldh, _ptr(h_out),
                                                  norm_kind, _ptr(scale), _ptr(shift), _stream(h_in.device)),
                    "node_aggregate_f32")
     return h_out

@@ -53,12 +53,13 @@ const char* gnnome_last_error(void);
  *   srt_eid      int32[E]   original edge id of sorted position p (stable: ties keep edge-id order)
  *   out_ptr      int32[N+1] CSR offsets by source
  *   out_pos      int32[E]   for each node, the sorted positions of its out-edges (ascending)
+ *   out_dst      int32[E]   out_dst[q] = srt_dst[out_pos[q]], the far endpoint of that out-edge
  */
 int gnnome_graph_views_workspace_bytes(int64_t num_nodes, int64_t num_edges, size_t* bytes_host);
 int gnnome_build_graph_views(const int32_t* src, const int32_t* dst, int64_t num_nodes, int64_t num_edges,
                              int32_t* in_ptr, int32_t* srt_src, int32_t* srt_dst, int32_t* srt_eid,
-                             int32_t* out_ptr, int32_t* out_pos, void* workspace, size_t workspace_bytes,
-                             void* stream);
+                             int32_t* out_ptr, int32_t* out_pos, int32_t* out_dst, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- encoders ----------------------------------------------------------------------------------
  * out[r,:] = W2 * relu(W1 * in[row(r),:] + b1) + b2, row(r) = gather ? gather[r] : r.
@@ -74,7 +75,7 @@ int gnnome_encode_f32(const float* in, int64_t rows, int in_features, const int3
  * C[M,Nout] = A[M,K] * W[Nout,K]^T + bias (torch nn.Linear layout), exact fp32 (v_mfma_f32_32x32x2_f32).
  * Replaces the five node projections A_1,A_2,A_3,B_1,B_2 (gated_gcn_full.py:91-96, one call with the
  * weights concatenated) and the node halves of predictor.W1 (score_predictor.py:13-14).
- *   K % 8 == 0; bias may be NULL
+ *   K % 64 == 0; bias may be NULL; A and W 16-byte aligned with lda, ldw % 4 == 0
  */
 int gnnome_linear_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias,
                       int Nout, float* C, int ldc, void* stream);
@@ -84,7 +85,7 @@ int gnnome_linear_f32(const float* A, int64_t M, int K, int lda, const float* W,
  *   e_out[p,:] = relu(norm_e(B1h[srt_src[p],:] + B2h[srt_dst[p],:] + e_in[p,:] * W3^T)) + e_in[p,:]
  * i.e. B_3(e), u_add_v, bn_e, relu and the residual of gated_gcn_full.py:97,104-110 (and the
  * bit-identical second evaluation at :117-122) in one pass.  B_3's bias must already be folded into
- * B2h.  e_out may alias e_in.  H in {32,64,128,256}.
+ * B2h.  e_out may alias e_in.  H in {64,128,256}.
  */
 int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num_edges, int hidden,
                          const float* B1h, const float* B2h, int ld_node, const int32_t* srt_src,
@@ -94,15 +95,16 @@ int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num_edges, int
 /* ---- fused gated aggregation + node update -------------------------------------------------------
  * For every node i < num_nodes_out, with s_p = sigmoid(e[p,:]):
  *   fwd = sum_{p in in(i)}  s_p * A2h[srt_src[p],:] / (sum_{p in in(i)}  s_p + 1e-6)
- *   bwd = sum_{p in out(i)} s_p * A3h[srt_dst[p],:] / (sum_{p in out(i)} s_p + 1e-6)
+ *   bwd = sum_{q in out(i)} s_p * A3h[out_dst[q],:] / (sum_{q in out(i)} s_p + 1e-6),  p = out_pos[q]
  *   h_out[i,:] = relu(norm_h(A1h[i,:] + fwd + bwd)) + h_in[i,:]
  * Replaces sigmoid + both update_all pairs + the node epilogue, gated_gcn_full.py:111-114,124-137.
- * Sums run in ascending sorted position, sequentially per node: bit-reproducible.
+ * The summation order depends on the graph only (never on scheduling): bit-reproducible.
+ * h_out is dense [num_nodes_out, H]; it must not alias h_in.
  */
 int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num_nodes_out, const float* A1h,
                               const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
                               const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
-                              const int32_t* srt_dst, const float* h_in, int ld_h, float* h_out, int norm_kind,
+                              const int32_t* out_dst, const float* h_in, int ld_h, float* h_out, int norm_kind,
                               const float* norm_scale, const float* norm_shift, void* stream);
 
 /* ---- fused edge scorer --------------------------------------------------------------------------
@@ -111,7 +113,7 @@ int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num_nodes_out,
  *   logits[eid(p)] = W3 . relu(W2 * z1 + b2) + b3,   eid(p) = srt_eid ? srt_eid[p] : p
  * Replaces ScorePredictor.apply_edges (score_predictor.py:12-17) without materialising the
  * [E,3H] concatenation; W1e is the third column block of predictor.W1 (row stride ldw1 = 3H).
- *   hidden in {32,64,128,256}; hidden_edge_scores in {32,64,128}; W2 is [32,hs], W3 is [32]
+ *   hidden in {64,128,256}; hidden_edge_scores in {32,64,128}; W2 is [32,hs], W3 is [32]
  */
 int gnnome_edge_score_f32(const float* e, int64_t num_edges, int hidden, int hidden_edge_scores,
                           const float* Ps, const float* Qd, int ld_node, const int32_t* srt_src,

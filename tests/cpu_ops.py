@@ -21,6 +21,7 @@ class CpuViews:
         pos = torch.sort(src[order], stable=True).indices
         self.out_pos = pos.int()
         self.out_ptr = torch.searchsorted(src[order][pos].contiguous(), torch.arange(n + 1)).int()
+        self.out_dst = dst[order][pos].int()
 
     def reversed(self):
         r = object.__new__(CpuViews)

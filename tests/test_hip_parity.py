@@ -50,7 +50,7 @@ def test_graph_views_bit_exact(n, e):
     src, dst = _rand_graph(n, e, seed=n + e, isolated=n > 8)
     gv, cv = _views_pair(src, dst, n)
     torch.cuda.synchronize()
-    for name in ("in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos"):
+    for name in ("in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst"):
         assert torch.equal(getattr(gv, name).cpu(), getattr(cv, name)), name
 
 
