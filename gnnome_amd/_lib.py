@@ -18,6 +18,7 @@ _sz = ctypes.c_size_t
 SIGNATURES = {
     "gnnome_abi_version": [],
     "gnnome_last_error": [],
+    "gnnome_set_tuning": [_i, _i],
     "gnnome_graph_views_workspace_bytes": [_l, _l, ctypes.POINTER(_sz)],
     "gnnome_build_graph_views": [_p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_encode_f32": [_p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p],

@@ -10,6 +10,10 @@ namespace gnnome {
 
 void set_error(const char* fmt, ...);
 
+// Tuning knobs (gnnome_set_tuning): variant selection for A/B measurements; 0 = the shipped default.
+enum { kTuneGateVariant = 0, kTuneGateAblation = 1, kTuneCount = 8 };
+int tuning(int key);
+
 #define GN_REQUIRE(cond, ...)                 \
     do {                                      \
         if (!(cond)) {                        \

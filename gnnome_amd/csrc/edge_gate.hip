@@ -187,12 +187,21 @@ __global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_persistent(
 
         // gathers for this tile: issued now, consumed after the MFMA sweep
         float g1[16], g2[16];
+        {
+            // all cross-lane index fetches first, then all loads: one exposed LDS round trip per tile
+            int s_i[16], d_i[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = cd_row(r, lane);  // row inside this wave's 32-row block
-            const int s_i = __shfl(idx_cur, lr), d_i = __shfl(idx_cur, 32 + lr);
-            g1[r] = B1h[(int64_t)s_i * ldn + 32 * cb + cl];
-            g2[r] = B2h[(int64_t)d_i * ldn + 32 * cb + cl];
+            for (int r = 0; r < 16; ++r) {
+                const int lr = cd_row(r, lane);  // row inside this wave's 32-row block
+                s_i[r] = __shfl(idx_cur, lr);
+                d_i[r] = __shfl(idx_cur, 32 + lr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                g1[r] = B1h[(int64_t)s_i[r] * ldn + 32 * cb + cl];
+                g2[r] = B2h[(int64_t)d_i[r] * ldn + 32 * cb + cl];
+            }
         }
 
         f32x16 acc;
@@ -231,6 +240,171 @@ __global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_persistent(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Software-pipelined form of the persistent kernel.  A single wave's accumulator chain already
+// saturates its SIMD's matrix pipe (v_mfma_f32_32x32x2_f32: issue interval = dependent latency = 64
+// cycles), so the second wave on the SIMD adds no MFMA throughput and, in the kernel above, the
+// workgroup barrier keeps both waves in the same phase: gathers, MFMA and epilogue run one after the
+// other and the matrix pipe idles a third of the time (SQ_WAIT_ANY = 34 % of SQ_WAVE_CYCLES measured).
+// Here each wave overlaps phases ITSELF: while tile t is multiplied, the epilogue of tile t-1 (its raw
+// product, gathered node terms and residual all kept in registers) is woven between the MFMAs, one
+// accumulator element per k-step, and the node gathers of tile t are issued at the top of the sweep
+// and only consumed one tile later.
+// ---------------------------------------------------------------------------------------------------
+// ABL: ablation mask for measurements only (1 = no node gathers, 2 = no e_out stores, 4 = no HBM tile loads,
+// 8 = no MFMA); the shipped instance is ABL = 0.
+template <int CB, int RB, int ABL>
+__global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_pipelined(
+    const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
+    const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
+    const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block) {
+    using P = GateP<CB, RB>;
+    constexpr int H = P::H, TM = P::TM, NT = P::NT, LDK = P::LDK, QS = H / 8, EPQ = 16 / QS;
+    __shared__ __attribute__((aligned(16))) float lds[P::kLdsFloats];
+    float* Ws = lds;
+    float* As0 = lds + H * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = wave % RB, cb = wave / RB, cl = lane & 31, half = lane >> 5;
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = min(num_tiles, t_begin + tiles_per_block);
+    if (t_begin >= t_end) return;
+
+#pragma unroll
+    for (int it = 0; it < P::kWPieces; ++it) {
+        const int f = tid + NT * it, row = f / (H / 4), c4 = f % (H / 4);
+        *reinterpret_cast<f32x4*>(Ws + row * LDK + 4 * c4) = *reinterpret_cast<const f32x4*>(W3 + (int64_t)row * ldw + 4 * c4);
+    }
+    const float sc = scale[32 * cb + cl], sh = shift[32 * cb + cl];
+    const int col = 32 * cb + cl;
+
+    auto load_tile = [&](int t, f32x4 (&r)[P::kPieces]) {
+        const int64_t row0 = (int64_t)t * TM;
+        const int valid = (int)min((int64_t)TM, E - row0);
+#pragma unroll
+        for (int it = 0; it < P::kPieces; ++it) {
+            const int f = tid + NT * it, row = min(f / (H / 4), valid - 1), c4 = f % (H / 4);
+            r[it] = *reinterpret_cast<const f32x4*>(e_in + (row0 + row) * H + 4 * c4);
+        }
+    };
+    auto store_tile = [&](float* buf, const f32x4 (&r)[P::kPieces]) {
+#pragma unroll
+        for (int it = 0; it < P::kPieces; ++it) {
+            const int f = tid + NT * it, row = f / (H / 4), c4 = f % (H / 4);
+            *reinterpret_cast<f32x4*>(buf + row * LDK + 4 * c4) = r[it];
+        }
+    };
+    auto load_idx = [&](int t) {
+        const int64_t row0 = (int64_t)t * TM;
+        const int valid = (int)min((int64_t)TM, E - row0);
+        const int64_t row = row0 + min(32 * rb + cl, valid - 1);
+        return half ? srt_dst[row] : srt_src[row];
+    };
+
+    f32x4 stage[P::kPieces];
+    load_tile(t_begin, stage);
+    int idx_cur = load_idx(t_begin);
+    store_tile(As0, stage);
+    int idx_next = 0;
+    if (t_begin + 1 < t_end) {
+        load_tile(t_begin + 1, stage);
+        idx_next = load_idx(t_begin + 1);
+    }
+    __syncthreads();
+
+    // tile t-1, waiting for its epilogue
+    float accp[16], gp[16], resp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = gp[r] = resp[r] = 0.f;
+    float* eout_p = e_out;
+    int valid_p = 0;
+
+    for (int t = t_begin; t < t_end; ++t) {
+        float* buf = As0 + ((t - t_begin) & 1) * TM * LDK;
+        const int64_t row0 = (int64_t)t * TM;
+        const int valid = (int)min((int64_t)TM, E - row0);
+
+        // this tile's node gathers: issued now, needed one tile from now
+        float g1[16], g2[16];
+        if (ABL & 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g1[r] = g2[r] = 0.f;
+        } else {
+            // all cross-lane index fetches first, then all loads: one exposed LDS round trip per tile
+            int s_i[16], d_i[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = cd_row(r, lane);
+                s_i[r] = __shfl(idx_cur, lr);
+                d_i[r] = __shfl(idx_cur, 32 + lr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                g1[r] = B1h[(int64_t)s_i[r] * ldn + col];
+                g2[r] = B2h[(int64_t)d_i[r] * ldn + col];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* ap = buf + (32 * rb + cl) * LDK + 4 * half;
+        const float* wp = Ws + col * LDK + 4 * half;
+#pragma unroll
+        for (int q = 0; q < QS; ++q) {
+            if (!(ABL & 8)) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * q);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(wp + 8 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
+            }
+            // epilogue of the previous tile, EPQ accumulator elements per k-step
+#pragma unroll
+            for (int j = 0; j < EPQ; ++j) {
+                const int r = q * EPQ + j;
+                const int lr = 32 * rb + cd_row(r, lane);
+                const float y = fmaxf((accp[r] + gp[r]) * sc + sh, 0.f) + resp[r];
+                if (ABL & 2) {
+                    asm volatile("" ::"v"(y));
+                } else if (lr < valid_p) {
+                    eout_p[(uint32_t)(lr * H + col)] = y;
+                }
+            }
+        }
+
+        // rotate: tile t becomes the pending one (its residual is still intact in the LDS tile)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accp[r] = acc[r];
+            gp[r] = g1[r] + g2[r];
+            resp[r] = buf[(32 * rb + cd_row(r, lane)) * LDK + col];
+        }
+        eout_p = e_out + row0 * H;
+        valid_p = valid;
+
+        if (t + 1 < t_end) {
+            store_tile(As0 + ((t + 1 - t_begin) & 1) * TM * LDK, stage);
+            idx_cur = idx_next;
+            if (t + 2 < t_end) {
+                if (!(ABL & 4)) load_tile(t + 2, stage);
+                idx_next = load_idx(t + 2);
+            }
+        }
+        __syncthreads();
+    }
+
+    // drain the last tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lr = 32 * rb + cd_row(r, lane);
+        const float y = fmaxf((accp[r] + gp[r]) * sc + sh, 0.f) + resp[r];
+        if (lr < valid_p) eout_p[(uint32_t)(lr * H + col)] = y;
+    }
+}
+
 template <int CB, int RB>
 static int launch_gate_persistent(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
                                   const int32_t* ss, const int32_t* sd, const float* W3, int ldw, const float* scale,
@@ -241,8 +415,23 @@ static int launch_gate_persistent(const float* e_in, float* e_out, int64_t E, co
     const int grid_max = kNumCUs;  // one resident workgroup per CU (LDS-limited)
     const int tpb = (int)((tiles + grid_max - 1) / grid_max);
     const int grid = (int)((tiles + tpb - 1) / tpb);
-    hipLaunchKernelGGL((k_edge_gate_persistent<CB, RB>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd,
-                       W3, ldw, scale, shift, (int)tiles, tpb);
+    if (tuning(kTuneGateVariant) == 2) {
+        hipLaunchKernelGGL((k_edge_gate_persistent<CB, RB>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss,
+                           sd, W3, ldw, scale, shift, (int)tiles, tpb);
+    } else {
+#define GN_GATE_ABL(M)                                                                                                      \
+    case M:                                                                                                                 \
+        hipLaunchKernelGGL((k_edge_gate_pipelined<CB, RB, M>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, \
+                           ss, sd, W3, ldw, scale, shift, (int)tiles, tpb);                                                \
+        break;
+        switch (tuning(kTuneGateAblation)) {
+            GN_GATE_ABL(1) GN_GATE_ABL(2) GN_GATE_ABL(4) GN_GATE_ABL(8) GN_GATE_ABL(7) GN_GATE_ABL(15)
+            default:
+                hipLaunchKernelGGL((k_edge_gate_pipelined<CB, RB, 0>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h,
+                                   ldn, ss, sd, W3, ldw, scale, shift, (int)tiles, tpb);
+        }
+#undef GN_GATE_ABL
+    }
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
@@ -279,9 +468,10 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
     GN_REQUIRE(ld_node >= hidden && ldw >= hidden && ldw % 4 == 0, "edge_gate: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0), "edge_gate: e_in and W3 must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    if (norm_kind == GNNOME_NORM_AFFINE && hidden == 128)
+    const bool tiled_only = tuning(kTuneGateVariant) == 1;
+    if (!tiled_only && norm_kind == GNNOME_NORM_AFFINE && hidden == 128)
         return launch_gate_persistent<4, 2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
-    if (norm_kind == GNNOME_NORM_AFFINE && hidden == 64)
+    if (!tiled_only && norm_kind == GNNOME_NORM_AFFINE && hidden == 64)
         return launch_gate_persistent<2, 4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
     switch (hidden) {
         case 64: return launch_gate<2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);

@@ -13,7 +13,18 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+int tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key] : 0; }
 }  // namespace gnnome
+
+extern "C" int gnnome_set_tuning(int key, int value) {
+    if (key < 0 || key >= 8) {
+        gnnome::set_error("set_tuning: key %d out of range", key);
+        return GNNOME_EINVAL;
+    }
+    gnnome::g_tuning[key] = value;
+    return GNNOME_OK;
+}
 
 extern "C" int gnnome_abi_version(void) { return GNNOME_ABI_VERSION; }
 extern "C" const char* gnnome_last_error(void) { return gnnome::g_err; }

@@ -81,6 +81,11 @@ class GraphViews:
         return r
 
 
+def set_tuning(key, value):
+    """Select a kernel variant for A/B measurements (see gnnome_set_tuning in include/gnnome_hip.h)."""
+    _lib.check(_lib.load().gnnome_set_tuning(int(key), int(value)), "set_tuning")
+
+
 def encode(x, W1, b1, W2, b2, gather=None, rows=None):
     lib = _lib.load()
     x, _ = _rows(x.contiguous(), "encode.in")

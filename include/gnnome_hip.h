@@ -44,6 +44,11 @@ extern "C" {
 int gnnome_abi_version(void);
 const char* gnnome_last_error(void);
 
+/* Measurement knob, not part of the reference-facing contract: selects a kernel variant for A/B runs.
+ *   key 0 (edge gate): 0 = default (software-pipelined persistent kernel where applicable),
+ *                      1 = one-tile-per-workgroup kernel, 2 = persistent kernel without pipelining */
+int gnnome_set_tuning(int key, int value);
+
 /* ---- graph views -------------------------------------------------------------------------------
  * Replaces what DGL builds lazily inside g.update_all / dgl.reverse (gated_gcn_full.py:99,112-113,
  * 125-126): the in-edge (by dst) and out-edge (by src) orderings of one edge list.

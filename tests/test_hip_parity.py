@@ -125,8 +125,9 @@ def _layer_inputs(hidden, n, e, seed):
 
 @pytest.mark.parametrize("hidden", [64, 128, 256])
 @pytest.mark.parametrize("norm", [0, 1])
-def test_edge_gate(hidden, norm):
-    n, e = 500, 1000 + hidden  # not a multiple of the 128-edge tile
+@pytest.mark.parametrize("e_base", [1000, 70_001])  # one tile per workgroup / several tiles per persistent workgroup
+def test_edge_gate(hidden, norm, e_base):
+    n, e = 500, e_base + hidden  # not a multiple of the tile height
     src, dst, t = _layer_inputs(hidden, n, e, seed=hidden + norm)
     gv, cv = _views_pair(src, dst, n)
     H = hidden
