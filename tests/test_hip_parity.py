@@ -308,6 +308,20 @@ def test_empty_graph_and_training_refusal(shipped_weights):
         m((torch.tensor([0]), torch.tensor([1]), 2), torch.zeros(2, 2).to(dev()), torch.zeros(1, 2).to(dev()))
 
 
+def test_partitioned_runner_world1_equals_plain_forward():
+    """The dist.py kernel sequence (owned/halo split, prefix scoring, global-id scatter) on the HIP backend."""
+    from gnnome_amd import dist as gdist
+    n, e, hidden = 30000, 300000, 128
+    gr = make_graph(n, e, seed=7, kind="banded")
+    x = degree_features(gr["src"], gr["dst"], n)
+    m = _model(random_state_dict(hidden, seed=1), hidden)
+    part = gdist.PartitionedGraph.from_global(gr["src"], gr["dst"], n, 0, 1, dev())
+    assert part.n_own == n and part.n_score == e and part.n_local == n
+    got = gdist.PartitionedRunner(m, part, x, gr["e"], dev()).forward()
+    want = m((gr["src"], gr["dst"], n), x.to(dev()), gr["e"].to(dev()))
+    assert torch.equal(got, want)
+
+
 # ------------------------------------------------------------------------------------ vs oracle, mid size
 
 @pytest.mark.parametrize("hidden,kind", [(64, "banded"), (128, "banded"), (128, "uniform"), (256, "banded")])
