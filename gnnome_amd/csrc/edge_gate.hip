@@ -405,6 +405,169 @@ __global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_pipelined(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Staged" form: every global access is a 16-byte-per-lane row access.
+//
+// Ablating the pipelined kernel (tools/kernel_ab.py; E = 1M, H = 128) gave MFMA+LDS alone 0.27 ms, the
+// memory side alone 0.25 ms, both together 0.42 ms.  In the MFMA C/D layout a lane owns one column of
+// 16 scattered rows, so node gathers and e' stores are dword accesses: 52 vector-memory instructions
+// per wave per tile, each costing ~20 cycles of address processing whatever its size.  Here the
+// workgroup moves whole rows instead: the B1h[src] + B2h[dst] rows of a tile are fetched as float4
+// pieces (32 lanes per 512-byte row), summed and parked in an LDS tile GY; the epilogue reads its
+// C/D-layout elements from GY and writes e' back INTO GY; the tile then leaves row-wise as dwordx4
+// stores.  17 vector-memory instructions per wave per tile for the same bytes.
+//
+// LDS: W3 [H][H+4] + A tile [TM][H+4] + GY [TM][H+4] (135 KiB at H = 128).  Iteration i, three phases
+// separated by workgroup barriers:
+//   P1  MFMA sweep of tile i (A tile) with the epilogue of tile i-1 woven in (G(i-1) -> e'(i-1) in GY)
+//   P2  read-out: GY rows -> HBM (e' of tile i-1); residual of tile i: A tile -> registers
+//   P3  write-in: A(i+1) registers -> A tile, G(i) registers -> GY; issue loads of A(i+2), G(i+1), idx(i+2)
+// so every HBM / L2 load has a full tile of MFMA work to land in.
+// ---------------------------------------------------------------------------------------------------
+template <int CB, int RB>
+__global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_staged(
+    const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
+    const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
+    const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block) {
+    using P = GateP<CB, RB>;
+    constexpr int H = P::H, TM = P::TM, NT = P::NT, LDK = P::LDK, QS = H / 8, EPQ = 16 / QS, NP = P::kPieces;
+    __shared__ __attribute__((aligned(16))) float lds[(H + 2 * TM) * LDK];
+    float* Ws = lds;
+    float* As = lds + H * LDK;
+    float* GY = As + TM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = wave % RB, cb = wave / RB, cl = lane & 31, half = lane >> 5;
+    const int col = 32 * cb + cl;
+    const int t0 = blockIdx.x * tiles_per_block;
+    const int t_end = min(num_tiles, t0 + tiles_per_block);
+    if (t0 >= t_end) return;
+
+#pragma unroll
+    for (int it = 0; it < P::kWPieces; ++it) {
+        const int f = tid + NT * it, row = f / (H / 4), c4 = f % (H / 4);
+        *reinterpret_cast<f32x4*>(Ws + row * LDK + 4 * c4) = *reinterpret_cast<const f32x4*>(W3 + (int64_t)row * ldw + 4 * c4);
+    }
+    const float sc = scale[col], sh = shift[col];
+
+    // piece `it` of this thread is row prow, float4 column pc4 of a tile (32 lanes = one 512-byte row at H = 128)
+    int prow[NP], pc4[NP];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        prow[it] = (tid + NT * it) / (H / 4);
+        pc4[it] = (tid + NT * it) % (H / 4);
+    }
+    auto tile_valid = [&](int t) { return (int)min((int64_t)TM, E - (int64_t)t * TM); };
+    auto load_a = [&](int t, f32x4 (&r)[NP]) {
+        const int64_t row0 = (int64_t)t * TM;
+        const int valid = tile_valid(t);
+#pragma unroll
+        for (int it = 0; it < NP; ++it)
+            r[it] = *reinterpret_cast<const f32x4*>(e_in + (row0 + min(prow[it], valid - 1)) * H + 4 * pc4[it]);
+    };
+    auto load_idx = [&](int t, int (&si)[NP], int (&di)[NP]) {
+        const int64_t row0 = (int64_t)t * TM;
+        const int valid = tile_valid(t);
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int64_t row = row0 + min(prow[it], valid - 1);
+            si[it] = srt_src[row];
+            di[it] = srt_dst[row];
+        }
+    };
+    auto load_g = [&](const int (&si)[NP], const int (&di)[NP], f32x4 (&a)[NP], f32x4 (&b)[NP]) {
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            a[it] = *reinterpret_cast<const f32x4*>(B1h + (int64_t)si[it] * ldn + 4 * pc4[it]);
+            b[it] = *reinterpret_cast<const f32x4*>(B2h + (int64_t)di[it] * ldn + 4 * pc4[it]);
+        }
+    };
+    auto put_rows = [&](float* buf, const f32x4 (&r)[NP]) {
+#pragma unroll
+        for (int it = 0; it < NP; ++it) *reinterpret_cast<f32x4*>(buf + prow[it] * LDK + 4 * pc4[it]) = r[it];
+    };
+    auto epilogue_elem = [&](int r, float prod, float res) {
+        float* gy = GY + (32 * rb + cd_row(r, lane)) * LDK + col;
+        *gy = fmaxf((prod + *gy) * sc + sh, 0.f) + res;
+    };
+    auto flush = [&](int t) {
+        const int valid = tile_valid(t);
+        float* out = e_out + (int64_t)t * TM * H;
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(GY + prow[it] * LDK + 4 * pc4[it]);
+            if (prow[it] < valid) *reinterpret_cast<f32x4*>(out + (uint32_t)(prow[it] * H + 4 * pc4[it])) = y;
+        }
+    };
+
+    // ---- prologue: A(t0) -> LDS; registers: g = G(t0), stage = A(t0+1), idx = idx(t0+1)
+    f32x4 stage[NP], g1[NP], g2[NP];
+    int si[NP], di[NP];
+    load_a(t0, stage);
+    load_idx(t0, si, di);
+    put_rows(As, stage);
+    load_g(si, di, g1, g2);
+    if (t0 + 1 < t_end) {
+        load_a(t0 + 1, stage);
+        load_idx(t0 + 1, si, di);
+    }
+    __syncthreads();
+
+    float accp[16], resp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = resp[r] = 0.f;
+
+    for (int t = t0; t < t_end; ++t) {
+        const bool pending = t > t0;  // workgroup-uniform
+        // ---- P1
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* ap = As + (32 * rb + cl) * LDK + 4 * half;
+        const float* wp = Ws + col * LDK + 4 * half;
+#pragma unroll
+        for (int q = 0; q < QS; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * q);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(wp + 8 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
+            if (pending) {
+#pragma unroll
+                for (int j = 0; j < EPQ; ++j) epilogue_elem(q * EPQ + j, accp[q * EPQ + j], resp[q * EPQ + j]);
+            }
+        }
+        __syncthreads();
+        // ---- P2
+        if (pending) flush(t - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accp[r] = acc[r];
+            resp[r] = As[(32 * rb + cd_row(r, lane)) * LDK + col];
+        }
+        __syncthreads();
+        // ---- P3
+#pragma unroll
+        for (int it = 0; it < NP; ++it) g1[it] += g2[it];
+        put_rows(GY, g1);  // G(t)
+        if (t + 1 < t_end) {
+            put_rows(As, stage);        // A(t+1)
+            load_g(si, di, g1, g2);     // G(t+1)
+            if (t + 2 < t_end) {
+                load_a(t + 2, stage);
+                load_idx(t + 2, si, di);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- drain: epilogue and read-out of the last tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) epilogue_elem(r, accp[r], resp[r]);
+    __syncthreads();
+    flush(t_end - 1);
+}
+
 template <int CB, int RB>
 static int launch_gate_persistent(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
                                   const int32_t* ss, const int32_t* sd, const float* W3, int ldw, const float* scale,
@@ -415,7 +578,10 @@ static int launch_gate_persistent(const float* e_in, float* e_out, int64_t E, co
     const int grid_max = kNumCUs;  // one resident workgroup per CU (LDS-limited)
     const int tpb = (int)((tiles + grid_max - 1) / grid_max);
     const int grid = (int)((tiles + tpb - 1) / tpb);
-    if (tuning(kTuneGateVariant) == 2) {
+    if (tuning(kTuneGateVariant) == 4) {
+        hipLaunchKernelGGL((k_edge_gate_staged<CB, RB>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd,
+                           W3, ldw, scale, shift, (int)tiles, tpb);
+    } else if (tuning(kTuneGateVariant) == 2) {
         hipLaunchKernelGGL((k_edge_gate_persistent<CB, RB>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss,
                            sd, W3, ldw, scale, shift, (int)tiles, tpb);
     } else {

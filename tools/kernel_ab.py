@@ -72,7 +72,7 @@ def main():
         ts = sorted(s.elapsed_time(t) for s, t in evs)
         print(f"  in-layer  {name:16s} {ts[len(ts) // 2]:.3f} / {ts[0]:.3f}")
     # edge-gate variants, interleaved rounds (cdna_hip_programming.md 5.4 rule 24)
-    names = {1: "tile-per-workgroup", 2: "persistent", 0: "persistent+pipelined (default)"}
+    names = {1: "tile-per-workgroup", 2: "persistent", 3: "persistent+pipelined", 4: "staged (row-wise gathers/stores via LDS)", 0: "default"}
     res = {k: [] for k in names}
     for _ in range(5):
         for k in names:
@@ -80,7 +80,7 @@ def main():
             res[k].append(timed(gate, 5)[0])
     ops.set_tuning(0, 0)
     for k, v in res.items():
-        print(f"  edge_gate variant {names[k]:32s} median {sorted(v)[len(v) // 2]:.3f}  min {min(v):.3f} ms")
+        print(f"  edge_gate variant {names[k]:44s} median {sorted(v)[len(v) // 2]:.3f}  min {min(v):.3f} ms")
     # ablations of the pipelined gate (results are wrong by construction; timing only)
     abl = {0: "full", 1: "no node gathers", 2: "no e_out stores", 4: "no HBM tile loads", 8: "no MFMA", 7: "MFMA + LDS only",
            15: "loop skeleton only"}
