@@ -539,6 +539,15 @@ __global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_staged(
         }
         __syncthreads();
         // ---- P2
+        // The loads issued in P3 of the previous iteration (a whole MFMA sweep ago) are claimed HERE, before
+        // this iteration's stores are issued: hipcc cannot count outstanding operations across the loop
+        // back-edge and waits vmcnt(0) at the first use, which would otherwise also wait for the
+        // acknowledgement of the stores below (vmcnt counts stores on gfx950).
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            asm volatile("" : "+v"(g1[it]), "+v"(g2[it]), "+v"(stage[it]));
+            asm volatile("" : "+v"(si[it]), "+v"(di[it]));
+        }
         if (pending) flush(t - 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -168,10 +168,8 @@ def run_partitioned(ops, prep, part, x_local, e_local, group=None, reduce_result
     xchg.start(h)
     pw = prep.predictor
     hs = pw["hs"]
-    PQ = torch.empty((h.shape[0], 2 * hs), dtype=torch.float32, device=h.device)
     xchg.finish()
-    ops.linear(h, pw["W1_src"], None, out=PQ[:, :hs])
-    ops.linear(h, pw["W1_dst"], pw["b1"], out=PQ[:, hs:])
+    PQ = ops.linear(h, pw["W_nodes"], pw["b_nodes"])
     logits = torch.zeros(part.num_edges_global, dtype=torch.float32, device=h.device)
     if part.n_score > 0:
         # scatter straight to GLOBAL edge ids: a GraphViews-like shim whose srt_eid is the global map

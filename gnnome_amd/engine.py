@@ -86,10 +86,12 @@ def prepare_predictor(pred, device):
     if pred.W2.out_features != 32 or pred.W3.in_features != 32 or pred.W3.out_features != 1:
         raise ValueError("ScorePredictor tail must be hs -> 32 -> 1 (score_predictor.py:9-10)")
     W1 = dev(pred.W1.weight)
+    # node halves stacked into one [2*hs, H] projection: rows 0..hs-1 act on x[src], rows hs.. on x[dst] (+ b1)
+    W_nodes = torch.cat([W1[:, :hidden], W1[:, hidden:2 * hidden]], 0).contiguous()
+    b_nodes = torch.cat([torch.zeros_like(pred.W1.bias), pred.W1.bias]).detach()
     return {
-        "hidden": hidden, "hs": hs,
-        "W1_src": W1[:, :hidden], "W1_dst": W1[:, hidden:2 * hidden], "W1_e": W1[:, 2 * hidden:],
-        "b1": dev(pred.W1.bias), "W2": dev(pred.W2.weight), "b2": dev(pred.W2.bias),
+        "hidden": hidden, "hs": hs, "W_nodes": W_nodes, "b_nodes": dev(b_nodes), "W1_e": W1[:, 2 * hidden:],
+        "W2": dev(pred.W2.weight), "b2": dev(pred.W2.bias),
         "W3": dev(pred.W3.weight.reshape(-1)), "b3": dev(pred.W3.bias.reshape(-1)), "_W1": W1,
     }
 
@@ -143,9 +145,7 @@ def layer_step(ops, lw, views, h, e, n_out=None):
 
 def score_step(ops, pw, views, h, e, logits, n_edges=None):
     hs = pw["hs"]
-    PQ = torch.empty((h.shape[0], 2 * hs), dtype=torch.float32, device=h.device)
-    ops.linear(h, pw["W1_src"], None, out=PQ[:, :hs])
-    ops.linear(h, pw["W1_dst"], pw["b1"], out=PQ[:, hs:])
+    PQ = ops.linear(h, pw["W_nodes"], pw["b_nodes"])
     Ps, Qd = PQ[:, :hs], PQ[:, hs:]
     if views.transposed:
         # x[src'] | x[dst'] = x[dst] | x[src]; b1 is added once either way

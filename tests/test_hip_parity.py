@@ -85,7 +85,8 @@ def test_encode_wide_hidden_ne_and_features():
     _assert_close(ops.encode(*(t.to(dev()) for t in (x, W1, b1, W2, b2))), want)
 
 
-@pytest.mark.parametrize("m,k,nout", [(1000, 64, 320), (333, 128, 640), (129, 256, 1280), (128, 64, 64), (5, 128, 32), (2000, 128, 96)])
+@pytest.mark.parametrize("m,k,nout", [(1000, 64, 320), (333, 128, 640), (129, 256, 1280), (128, 64, 64), (5, 128, 32), (2000, 128, 96),
+                                      (40_000, 128, 640), (33_333, 64, 320), (70_001, 128, 128)])
 def test_linear(m, k, nout):
     g = torch.Generator().manual_seed(m + k + nout)
     A, W, b = torch.randn(m, k, generator=g), torch.randn(nout, k, generator=g), torch.randn(nout, generator=g)
@@ -97,6 +98,11 @@ def test_linear(m, k, nout):
     A2[torch.arange(m), torch.arange(m) % k] = 1.0
     got2 = ops.linear(A2.to(dev()), W.to(dev()), None)
     assert torch.equal(got2.cpu(), W.t()[torch.arange(m) % k])
+    try:  # the one-tile-per-workgroup variant behind the same entry point
+        ops.set_tuning(2, 1)
+        _assert_close(ops.linear(A.to(dev()), W.to(dev()), b.to(dev())), want, scale=float(k) ** 0.5 * 4)
+    finally:
+        ops.set_tuning(2, 0)
 
 
 def test_linear_strided_views():

@@ -81,6 +81,15 @@ def main():
     ops.set_tuning(0, 0)
     for k, v in res.items():
         print(f"  edge_gate variant {names[k]:44s} median {sorted(v)[len(v) // 2]:.3f}  min {min(v):.3f} ms")
+    lv = {1: "tile kernel", 0: "weight-stationary (default)"}
+    res = {k: [] for k in lv}
+    for _ in range(5):
+        for k in lv:
+            ops.set_tuning(2, k)
+            res[k].append(timed(lin, 5)[0])
+    ops.set_tuning(2, 0)
+    for k, v in res.items():
+        print(f"  linear [N,{H}]x[{H},{5 * H}] variant {lv[k]:28s} median {sorted(v)[len(v) // 2]:.3f}  min {min(v):.3f} ms")
     # ablations of the pipelined gate (results are wrong by construction; timing only)
     abl = {0: "full", 1: "no node gathers", 2: "no e_out stores", 4: "no HBM tile loads", 8: "no MFMA", 7: "MFMA + LDS only",
            15: "loop skeleton only"}
