@@ -49,8 +49,10 @@ def algorithmic_flops(n, e, h, layers=8, h_ne=16, hs=64):
 class KernelTimer:
     """HIP-event pairs around every launch of chosen gnnome_amd.ops entry points, on the launch stream."""
 
-    def __init__(self, ops_mod, names):
+    def __init__(self, ops_mod, names, every=1):
+        """every=k: instrument only every k-th launch of each entry point (k = 8 -> one layer's launch per step)."""
         self.ops, self.names, self.events, self.orig, self.on = ops_mod, names, {n: [] for n in names}, {}, False
+        self.every, self.calls = every, {n: 0 for n in names}
 
     def __enter__(self):
         for name in self.names:
@@ -59,6 +61,9 @@ class KernelTimer:
 
             def wrapped(*a, _fn=fn, _name=name, **k):
                 if not self.on:
+                    return _fn(*a, **k)
+                self.calls[_name] += 1
+                if self.calls[_name] % self.every:
                     return _fn(*a, **k)
                 s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
@@ -183,10 +188,11 @@ def main():
             torch.cuda.synchronize()
         parallelism = f"dst-range x{world}"
 
-    # HIP events in the timed region go around the dominant kernel only (8 launches per step): event
-    # pairs around every launch cost ~1.6 ms per step here and distort what they measure.
+    # HIP events in the timed region go around ONE launch of the dominant kernel per step (the 8 layers launch
+    # the same shape): a pair around every launch of every kernel cost ~1.6 ms per step here (56 events, ~28 us
+    # of pipeline bubble each) and inflated what it measured; a pair per gate launch still cost ~0.4 ms.
     dominant = [] if args.no_kernel_timers or world > 1 else ["edge_gate"]
-    with KernelTimer(ops, dominant) as kt:
+    with KernelTimer(ops, dominant, every=8) as kt:
         for _ in range(args.warmup):
             step()
         barrier()

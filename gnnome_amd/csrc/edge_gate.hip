@@ -577,6 +577,271 @@ __global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_staged(
     flush(t_end - 1);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wave-specialised form (the default for H <= 128 with the affine norm).
+//
+// What the variants above taught (tools/kernel_ab.py, profiles/): the MFMA side alone needs 0.27 ms and
+// the memory side alone 0.25 ms per launch (E = 1M, H = 128), but in one instruction stream they add up
+// (0.42 ms) instead of overlapping.  Two reasons.  (1) A wave's vector loads return IN ORDER, so any
+// wait on a young L2 gather also waits for the older HBM tile prefetch: one tile (~4 us) is all the
+// latency a single stream tolerates, and that is about what HBM needs under this load.  (2) hipcc cannot
+// count outstanding loads across a loop back-edge and waits vmcnt(0) at the first cross-iteration use.
+// Both disappear if no wave both computes and loads:
+//
+//   * 4 COMPUTE waves, one per SIMD: wave (rb, cb) keeps its 32 columns of W3 in 64 VGPRs for its whole
+//     life (no LDS reads for the B operand), sweeps K with one accumulator - a single dependent MFMA chain
+//     already saturates the SIMD's matrix pipe - and weaves the epilogue of the previous tile between the
+//     MFMAs.  It issues stores but NEVER a load, so it never waits on memory.
+//   * 8 LOAD waves in 4 groups.  Group g owns every 4th tile: it fetches the tile's e rows and the
+//     B1h[src] / B2h[dst] rows as float4 row pieces (16 bytes per lane), and only FOUR iterations later
+//     sums the gathers and writes both tiles into the LDS ring.  A group has exactly one batch in flight,
+//     so the compiler's conservative vmcnt(0) is exact, and 4 x 48 KiB are in flight per CU.
+//   * LDS is a 4-deep ring of (e tile, G tile) slots; one workgroup barrier per tile.
+//
+//   iteration i:   load group (i+1)%4 : registers -> slot (i+1)%4, then issue the loads of tile i+5
+//                  compute waves      : MFMA sweep of tile i (slot i%4) + epilogue of tile i-1 (slot (i-1)%4)
+// ---------------------------------------------------------------------------------------------------
+template <int CB, int RB>
+struct GateWS {
+    static_assert(CB * RB == 4, "four compute waves");
+    static constexpr int H = 32 * CB, TM = 32 * RB, LDK = H + 4, RING = 4, NGROUPS = 4, LWAVES = 2;
+    static constexpr int NT = 64 * (4 + NGROUPS * LWAVES);           // 768 threads
+    static constexpr int NP = TM * (H / 4) / (64 * LWAVES);          // float4 pieces per load lane per tile (= 8)
+    static constexpr int kSlotFloats = TM * LDK;
+    static constexpr int kLdsFloats = RING * 2 * kSlotFloats;
+};
+
+// One compute wave, one tile: acc = A_tile[32 rows] * W3[32 cols]^T over K = H, with the epilogue of the PREVIOUS tile
+// (product accp, G rows Gp, residual rows Ap, all per-lane base pointers) spread between the MFMAs.
+// FULL = every row of the previous tile exists: unconditional stores, so a k-step is one basic block and the
+// sched_group_barrier pattern below can place the epilogue's LDS reads / VALU / store in the issue gaps that the
+// dependent MFMA chain leaves (an MFMA blocks only the next MFMA; anything else issues under it).
+template <int H, bool FULL, int ABL>
+__device__ __forceinline__ void gate_ws_sweep(f32x16& acc, const float* ap, const f32x4 (&wv)[H / 8], const float (&accp)[16],
+                                              const float* Gp, const float* Ap, float* out_p, uint32_t lane_glb, int valid_p,
+                                              float sc, float sh) {
+    constexpr int LDK = H + 4, QS = H / 8, EPQ = 16 / QS;
+    auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
+    f32x4 a_cur = *reinterpret_cast<const f32x4*>(ap);  // (ABL: measurement-only ablation mask, 0 in the shipped kernel)
+    float g_cur[EPQ], r_cur[EPQ];
+#pragma unroll
+    for (int j = 0; j < EPQ; ++j) {
+        g_cur[j] = Gp[crow(j) * LDK];
+        r_cur[j] = Ap[crow(j) * LDK];
+    }
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+        // operands of the NEXT k-step: A fragment and the epilogue's LDS values
+        const int qn = q + 1 < QS ? q + 1 : q;
+        const f32x4 a_nxt = *reinterpret_cast<const f32x4*>(ap + 8 * qn);
+        float g_nxt[EPQ], r_nxt[EPQ];
+#pragma unroll
+        for (int j = 0; j < EPQ; ++j) {
+            g_nxt[j] = Gp[crow(qn * EPQ + j) * LDK];
+            r_nxt[j] = Ap[crow(qn * EPQ + j) * LDK];
+        }
+        if (!(ABL & 8)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[k], wv[q][k], acc, 0, 0, 0);
+        } else {
+            asm volatile("" ::"v"(a_cur));
+        }
+#pragma unroll
+        for (int j = 0; j < EPQ; ++j) {
+            const int r = q * EPQ + j;
+            const float y = fmaxf((accp[r] + g_cur[j]) * sc + sh, 0.f) + r_cur[j];
+            if (ABL & 2) {
+                asm volatile("" ::"v"(y));
+            } else if (FULL || crow(r) < valid_p) {
+                if (ABL & 16) {
+                    __builtin_nontemporal_store(y, out_p + crow(r) * H + lane_glb);
+                } else {
+                    (out_p + crow(r) * H)[lane_glb] = y;
+                }
+            }
+        }
+        if (FULL) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + 2 * EPQ, 0);  // LDS reads for the next step
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4 * EPQ, 0);      // epilogue VALU
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x040, EPQ, 0);          // e' store
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        a_cur = a_nxt;
+#pragma unroll
+        for (int j = 0; j < EPQ; ++j) {
+            g_cur[j] = g_nxt[j];
+            r_cur[j] = r_nxt[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int CB, int RB, int ABL>
+__global__ __launch_bounds__(768) void k_edge_gate_ws(
+    const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
+    const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
+    const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block, int interleave) {
+    using P = GateWS<CB, RB>;
+    constexpr int H = P::H, TM = P::TM, LDK = P::LDK, QS = H / 8, EPQ = 16 / QS, NP = P::NP, SLOT = P::kSlotFloats;
+    __shared__ __attribute__((aligned(16))) float lds[P::kLdsFloats];
+    float* Aring = lds;                       // [RING][TM][LDK]  e tiles
+    float* Gring = lds + P::RING * SLOT;      // [RING][TM][LDK]  B1h[src] + B2h[dst]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Tile order.  chunked: workgroup b owns the contiguous run [b*tpb, (b+1)*tpb).  interleaved: in round r the
+    // whole chip works on ONE contiguous window of gridDim.x tiles (DRAM row locality for the e stream in and
+    // out), and inside the window every XCD (blocks b % 8) gets a contiguous sub-window so that neighbouring
+    // tiles - which share B2h[dst] rows and nearby B1h[src] rows - meet in the same L2.
+    const int per_xcd = gridDim.x / kXcds;
+    const int first = interleave ? (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds) : (int)blockIdx.x * tiles_per_block;
+    const int stride = interleave ? (int)gridDim.x : 1;
+    int n;  // tiles of this workgroup
+    if (interleave) {
+        n = first < num_tiles ? (num_tiles - first + stride - 1) / stride : 0;
+    } else {
+        n = min(num_tiles, first + tiles_per_block) - first;
+    }
+    if (n <= 0) return;
+    auto tile_of = [&](int r) { return first + r * stride; };
+    auto tile_valid = [&](int r) { return (int)min((int64_t)TM, E - (int64_t)tile_of(r) * TM); };
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ compute wave
+        const int rb = wave % RB, cb = wave / RB, cl = lane & 31, half = lane >> 5;
+        const int col = 32 * cb + cl;
+        f32x4 wv[QS];  // this lane's B operands: W3[col][8q + 4*half .. +3]
+#pragma unroll
+        for (int q = 0; q < QS; ++q) wv[q] = *reinterpret_cast<const f32x4*>(W3 + (int64_t)col * ldw + 8 * q + 4 * half);
+        const float sc = scale[col], sh = shift[col];
+        float accp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+
+        // row / column of this lane's accumulator elements: element r sits in tile row lrow + crow(r)
+        const int lrow = 32 * rb + 4 * half;
+        const int lane_lds = lrow * LDK + col;
+        const uint32_t lane_glb = (uint32_t)(lrow * H + col);
+        auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
+
+        __syncthreads();  // iteration -1: the load waves hand over tile 0
+        for (int i = 0; i < n; ++i) {
+            const float* As = Aring + (i & 3) * SLOT;
+            // previous tile (i-1): its G rows and its e rows (the residual) are still in the ring
+            const float* Gp = Gring + ((i - 1) & 3) * SLOT + lane_lds;
+            const float* Ap = Aring + ((i - 1) & 3) * SLOT + lane_lds;
+            const int valid_p = (i >= 1 ? tile_valid(i - 1) : 0) - lrow;
+            float* out_p = e_out + (int64_t)tile_of(max(i - 1, 0)) * TM * H;
+
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ap = As + (32 * rb + cl) * LDK + 4 * half;
+            if (valid_p + lrow >= TM) {  // wave-uniform: every row of the previous tile exists
+                gate_ws_sweep<H, true, ABL>(acc, ap, wv, accp, Gp, Ap, out_p, lane_glb, valid_p, sc, sh);
+            } else {                     // first iteration (nothing pending) or the ragged last tile
+                gate_ws_sweep<H, false, ABL>(acc, ap, wv, accp, Gp, Ap, out_p, lane_glb, valid_p, sc, sh);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accp[r] = acc[r];
+            __syncthreads();
+        }
+        // drain: epilogue of the last tile
+        {
+            const float* Gp = Gring + ((n - 1) & 3) * SLOT + lane_lds;
+            const float* Ap = Aring + ((n - 1) & 3) * SLOT + lane_lds;
+            const int valid_p = tile_valid(n - 1) - lrow;
+            float* out_p = e_out + (int64_t)tile_of(n - 1) * TM * H;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (crow(r) < valid_p) {
+                    const float x = accp[r] + Gp[crow(r) * LDK];
+                    (out_p + crow(r) * H)[lane_glb] = fmaxf(x * sc + sh, 0.f) + Ap[crow(r) * LDK];
+                }
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ load wave
+        const int group = (wave - 4) / P::LWAVES;
+        const int gl = ((wave - 4) % P::LWAVES) * 64 + lane;  // lane index inside the group, 0..127
+        // piece p of this lane: row r0 + p * RSTEP, float4 column c4 (the group's 128 lanes cover RSTEP whole rows)
+        constexpr int RSTEP = 64 * P::LWAVES / (H / 4);
+        const int r0 = gl / (H / 4), c4 = gl % (H / 4);
+        f32x4 a[NP], g1[NP], g2[NP];
+        if (ABL & 5) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[p] = g1[p] = g2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        auto issue = [&](int r) {  // start fetching relative tile r
+            const int64_t row0 = (int64_t)tile_of(r) * TM;
+            const int valid = tile_valid(r);
+            int si[NP], di[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
+                si[p] = srt_src[row];
+                di[p] = srt_dst[row];
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
+                if (!(ABL & 4)) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(e_in + row * H + 4 * c4);
+                    a[p] = (ABL & 16) ? __builtin_nontemporal_load(src) : *src;  // 16: streamed once, keep it out of L1
+                }
+                if (!(ABL & 1)) {
+                    g1[p] = *reinterpret_cast<const f32x4*>(B1h + (int64_t)si[p] * ldn + 4 * c4);
+                    g2[p] = *reinterpret_cast<const f32x4*>(B2h + (int64_t)di[p] * ldn + 4 * c4);
+                }
+            }
+        };
+        if (group < n) issue(group);
+        for (int i = -1; i < n; ++i) {
+            const int r = i + 1;  // tile to hand over this iteration
+            if (r < n && (r & 3) == group) {
+                float* As = Aring + (r & 3) * SLOT;
+                float* Gs = Gring + (r & 3) * SLOT;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    *reinterpret_cast<f32x4*>(As + (r0 + p * RSTEP) * LDK + 4 * c4) = a[p];
+                    *reinterpret_cast<f32x4*>(Gs + (r0 + p * RSTEP) * LDK + 4 * c4) = g1[p] + g2[p];
+                }
+                if (r + 4 < n) issue(r + 4);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int CB, int RB>
+static int launch_gate_ws(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
+                          const int32_t* ss, const int32_t* sd, const float* W3, int ldw, const float* scale,
+                          const float* shift, hipStream_t s) {
+    using P = GateWS<CB, RB>;
+    const int64_t tiles = (E + P::TM - 1) / P::TM;
+    GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
+    const int tpb = (int)((tiles + kNumCUs - 1) / kNumCUs);  // one resident workgroup per CU (LDS-limited)
+    const int interleave = tuning(kTuneGateTileOrder) == 1 ? 0 : 1;
+    const int grid = interleave ? kNumCUs : (int)((tiles + tpb - 1) / tpb);
+#define GN_WS_ABL(M)                                                                                                        \
+    case M:                                                                                                                 \
+        hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, M>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd, \
+                           W3, ldw, scale, shift, (int)tiles, tpb, interleave);                                            \
+        break;
+    switch (tuning(kTuneGateAblation)) {
+        GN_WS_ABL(1) GN_WS_ABL(2) GN_WS_ABL(4) GN_WS_ABL(8) GN_WS_ABL(7) GN_WS_ABL(15) GN_WS_ABL(16)
+        default:
+            hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss,
+                               sd, W3, ldw, scale, shift, (int)tiles, tpb, interleave);
+    }
+#undef GN_WS_ABL
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
 template <int CB, int RB>
 static int launch_gate_persistent(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
                                   const int32_t* ss, const int32_t* sd, const float* W3, int ldw, const float* scale,
@@ -643,11 +908,22 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
     GN_REQUIRE(ld_node >= hidden && ldw >= hidden && ldw % 4 == 0, "edge_gate: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0), "edge_gate: e_in and W3 must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const bool tiled_only = tuning(kTuneGateVariant) == 1;
-    if (!tiled_only && norm_kind == GNNOME_NORM_AFFINE && hidden == 128)
-        return launch_gate_persistent<4, 2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
-    if (!tiled_only && norm_kind == GNNOME_NORM_AFFINE && hidden == 64)
-        return launch_gate_persistent<2, 4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
+    // variant 0 = shipped default: wave-specialised kernel where it applies, else the tile kernel
+    const int variant = tuning(kTuneGateVariant);
+    const bool rows16 = ld_node % 4 == 0 && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0);
+    const bool persistent_ok = norm_kind == GNNOME_NORM_AFFINE && (hidden == 64 || hidden == 128);
+    if (persistent_ok && variant != 1) {
+        if ((variant == 0 || variant == 5) && rows16) {
+            if (hidden == 128)
+                return launch_gate_ws<4, 1>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
+            return launch_gate_ws<2, 2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
+        }
+        if (variant != 4 || rows16) {  // 2 = persistent, 3 = pipelined, 4 = staged (selected inside)
+            if (hidden == 128)
+                return launch_gate_persistent<4, 2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
+            return launch_gate_persistent<2, 4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
+        }
+    }
     switch (hidden) {
         case 64: return launch_gate<2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);
         case 128: return launch_gate<4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);

@@ -68,14 +68,62 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(const float* __restrict_
     }
 }
 
+// Register-only fast path for the reference's shapes (in_features = 2, hidden_ne = 16; hyperparameters.py:23-26):
+// each lane keeps its four W2 rows (64 floats) in VGPRs and recomputes the 16 hidden units of its row itself
+// (32 FMAs) - no LDS reads, no cross-lane traffic; the general kernel above spends 16 ds_read_b128 + 16
+// ds_bpermute per row and tops out near 2 TB/s of output.
+template <int H>
+__global__ __launch_bounds__(kEncThreads) void k_encode_f2m16(const float* __restrict__ in, int64_t rows,
+                                                              const int32_t* __restrict__ gather,
+                                                              const float* __restrict__ W1, const float* __restrict__ b1,
+                                                              const float* __restrict__ W2, const float* __restrict__ b2,
+                                                              float* __restrict__ out) {
+    constexpr int LPR = H / 4, RPB = kEncThreads / LPR, M = 16;
+    const int tid = threadIdx.x, li = tid % LPR, rg = tid / LPR, c = 4 * li;
+    float w1a[M], w1b[M], bb[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        w1a[j] = W1[2 * j];
+        w1b[j] = W1[2 * j + 1];
+        bb[j] = b1[j];
+    }
+    f32x4 w2[M];  // w2[j][i] = W2[c + i][j]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j4 = 0; j4 < M / 4; ++j4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(W2 + (c + i) * M + 4 * j4);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) w2[4 * j4 + jj][i] = v[jj];
+        }
+    }
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + c);
+    for (int64_t r = (int64_t)blockIdx.x * RPB + rg; r < rows; r += (int64_t)gridDim.x * RPB) {
+        const int64_t rin = gather != nullptr ? (int64_t)gather[r] : r;
+        const float x0 = in[2 * rin], x1 = in[2 * rin + 1];
+        f32x4 acc = bias;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const float t = fmaxf(fmaf(w1b[j], x1, fmaf(w1a[j], x0, bb[j])), 0.f);
+            acc += t * w2[j];
+        }
+        *reinterpret_cast<f32x4*>(out + r * H + c) = acc;
+    }
+}
+
 template <int H>
 static int launch_encode(const float* in, int64_t rows, int F, const int32_t* gather, const float* W1, const float* b1,
                          int M, const float* W2, const float* b2, float* out, hipStream_t s) {
     constexpr int RPB = kEncThreads / (H / 4);
     int64_t blocks = (rows + RPB - 1) / RPB;
     if (blocks > kNumCUs * 8) blocks = kNumCUs * 8;  // grid-stride beyond 8 blocks per CU
-    hipLaunchKernelGGL(k_encode<H>, dim3((unsigned)blocks), dim3(kEncThreads), 0, s, in, rows, F, gather, W1, b1, M, W2,
-                       b2, out);
+    if (F == 2 && M == 16 && ((uintptr_t)W2 % 16 == 0)) {
+        hipLaunchKernelGGL(k_encode_f2m16<H>, dim3((unsigned)blocks), dim3(kEncThreads), 0, s, in, rows, gather, W1, b1, W2, b2,
+                           out);
+    } else {
+        hipLaunchKernelGGL(k_encode<H>, dim3((unsigned)blocks), dim3(kEncThreads), 0, s, in, rows, F, gather, W1, b1, M, W2,
+                           b2, out);
+    }
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

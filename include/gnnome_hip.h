@@ -44,9 +44,15 @@ extern "C" {
 int gnnome_abi_version(void);
 const char* gnnome_last_error(void);
 
-/* Measurement knob, not part of the reference-facing contract: selects a kernel variant for A/B runs.
- *   key 0 (edge gate): 0 = default (software-pipelined persistent kernel where applicable),
- *                      1 = one-tile-per-workgroup kernel, 2 = persistent kernel without pipelining */
+/* Measurement knobs, not part of the reference-facing contract: select kernel variants for A/B runs
+ * (tools/kernel_ab.py).  0 is always the shipped default.
+ *   key 0 edge gate variant : 1 tile-per-workgroup, 2 persistent, 3 persistent + software-pipelined,
+ *                             4 staged (row-wise gathers / stores through LDS), 5 wave-specialised (= default
+ *                             for H in {64,128} with the affine norm)
+ *   key 1 edge gate ablation: bit mask, timing only (results are wrong): 1 no node gathers, 2 no stores,
+ *                             4 no e loads, 8 no MFMA, 16 nontemporal e loads / e' stores
+ *   key 2 linear variant    : 1 tile kernel
+ *   key 3 gate tile order   : 1 contiguous run per workgroup (default: interleaved, XCD-contiguous) */
 int gnnome_set_tuning(int key, int value);
 
 /* ---- graph views -------------------------------------------------------------------------------

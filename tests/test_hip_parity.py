@@ -149,7 +149,7 @@ def test_edge_gate(hidden, norm, e_base):
     assert torch.equal(out, e_dev)
     # every kernel variant behind the entry point (gnnome_set_tuning key 0) must meet the same contract
     try:
-        for variant in (1, 2, 3, 4):
+        for variant in (1, 2, 3, 4, 5):
             ops.set_tuning(0, variant)
             e_var = d["e"].clone()
             ops.edge_gate(e_var, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], norm, d["scale"], d["shift"])

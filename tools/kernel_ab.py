@@ -72,7 +72,7 @@ def main():
         ts = sorted(s.elapsed_time(t) for s, t in evs)
         print(f"  in-layer  {name:16s} {ts[len(ts) // 2]:.3f} / {ts[0]:.3f}")
     # edge-gate variants, interleaved rounds (cdna_hip_programming.md 5.4 rule 24)
-    names = {1: "tile-per-workgroup", 2: "persistent", 3: "persistent+pipelined", 4: "staged (row-wise gathers/stores via LDS)", 0: "default"}
+    names = {1: "tile-per-workgroup", 2: "persistent", 3: "persistent+pipelined", 4: "staged (row-wise gathers/stores via LDS)", 5: "wave-specialised (compute + load waves)", 0: "default"}
     res = {k: [] for k in names}
     for _ in range(5):
         for k in names:
@@ -81,6 +81,16 @@ def main():
     ops.set_tuning(0, 0)
     for k, v in res.items():
         print(f"  edge_gate variant {names[k]:44s} median {sorted(v)[len(v) // 2]:.3f}  min {min(v):.3f} ms")
+    ops.set_tuning(0, 5)
+    for order, nm in ((1, "chunked"), (0, "interleaved, XCD-contiguous")):
+        ops.set_tuning(3, order)
+        print(f"  wave-specialised gate, tile order {nm:28s} median {timed(gate, 10)[0]:.3f} ms")
+    ops.set_tuning(3, 0)
+    for abl_, nm in ((0, "plain loads/stores"), (16, "nontemporal e loads + e' stores")):
+        ops.set_tuning(1, abl_)
+        print(f"  wave-specialised gate, {nm:36s} median {timed(gate, 10)[0]:.3f} ms")
+    ops.set_tuning(1, 0)
+    ops.set_tuning(0, 0)
     lv = {1: "tile kernel", 0: "weight-stationary (default)"}
     res = {k: [] for k in lv}
     for _ in range(5):
@@ -101,6 +111,16 @@ def main():
     ops.set_tuning(1, 0)
     for k, v in res.items():
         print(f"  pipelined gate ablation {abl[k]:24s} median {sorted(v)[len(v) // 2]:.3f} ms")
+    ops.set_tuning(0, 5)
+    res = {k: [] for k in abl}
+    for _ in range(3):
+        for k in abl:
+            ops.set_tuning(1, k)
+            res[k].append(timed(gate, 5)[0])
+    ops.set_tuning(1, 0)
+    ops.set_tuning(0, 0)
+    for k, v in res.items():
+        print(f"  wave-specialised gate ablation {abl[k]:24s} median {sorted(v)[len(v) // 2]:.3f} ms")
     # raw copy bandwidth reference on the same tensors
     dst = torch.empty_like(ee)
     med, mn = timed(lambda: dst.copy_(ee), a.reps)
