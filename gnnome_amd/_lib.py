@@ -25,11 +25,26 @@ SIGNATURES = {
     "gnnome_linear_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "gnnome_edge_gate_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p],
     "gnnome_node_aggregate_f32": [_p, _i, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
-    "gnnome_edge_score_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    "gnnome_edge_score_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
+    "gnnome_edge_gate_raw_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p],
+    "gnnome_node_aggregate_raw_f32": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "gnnome_colsum2_f32": [_p, _p, _l, _i, _p, _p, _p, _p],
+    "gnnome_bn_relu_res_f32": [_p, _p, _p, _p, _l, _i, _p, _p],
+    "gnnome_bn_bwd_stats_f32": [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p],
+    "gnnome_bn_bwd_apply_f32": [_p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
+    "gnnome_mul23_f32": [_p, _p, _p, _l, _p, _p, _p],
+    "gnnome_add_f32": [_p, _p, _l, _p, _p],
+    "gnnome_relu_bwd_f32": [_p, _p, _l, _p, _p],
+    "gnnome_segment_sum_f32": [_p, _i, _p, _p, _l, _p, _i, _p],
+    "gnnome_wgrad_workspace_bytes": [_l, _i, _i, ctypes.POINTER(_sz)],
+    "gnnome_wgrad_f32": [_p, _i, _i, _p, _i, _i, _l, _p, _i, _p, _sz, _p],
+    "gnnome_score_tail_bwd_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
+    "gnnome_agg_edge_bwd_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
+    "gnnome_encode_hidden_f32": [_p, _l, _i, _p, _p, _p, _i, _p, _p],
     "gnnome_gather_rows_f32": [_p, _i, _p, _l, _i, _p, _i, _p],
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

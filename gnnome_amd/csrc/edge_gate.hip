@@ -64,8 +64,8 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_gate(const float* e_in, f
     float sc[NB], sh[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        sc[nb] = scale[32 * nb + cl];
-        sh[nb] = shift[32 * nb + cl];
+        sc[nb] = NORM == 2 ? 1.f : scale[32 * nb + cl];
+        sh[nb] = NORM == 2 ? 0.f : shift[32 * nb + cl];
     }
     const float* ein_tile = e_in + row0 * H;
     float* eout_tile = e_out + row0 * H;
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_gate(const float* e_in, f
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const uint32_t off = (uint32_t)(lr * H + 32 * nb + cl);
-                const float y = fmaxf(v[nb] * sc[nb] + sh[nb], 0.f) + ein_tile[off];
+                // NORM == 2 ("raw"): the pre-normalisation sum B1h[src] + B2h[dst] + e*W3^T, for train-mode BatchNorm
+                const float y = NORM == 2 ? v[nb] : fmaxf(v[nb] * sc[nb] + sh[nb], 0.f) + ein_tile[off];
                 eout_tile[off] = y;
             }
         }
@@ -882,7 +883,10 @@ static int launch_gate(const float* e_in, float* e_out, int64_t E, const float* 
                        const float* shift, hipStream_t s) {
     const int64_t tiles = (E + kTileM - 1) / kTileM;
     GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
-    if (norm == GNNOME_NORM_AFFINE) {
+    if (norm == 2) {
+        hipLaunchKernelGGL((k_edge_gate<NB, 2>), dim3((unsigned)tiles), dim3(kGemmThreads), 0, s, e_in, e_out, E, B1h, B2h, ldn,
+                           ss, sd, W3, ldw, scale, shift, (int)tiles);
+    } else if (norm == GNNOME_NORM_AFFINE) {
         hipLaunchKernelGGL((k_edge_gate<NB, GNNOME_NORM_AFFINE>), dim3((unsigned)tiles), dim3(kGemmThreads), 0, s, e_in,
                            e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, scale, shift, (int)tiles);
     } else {
@@ -929,5 +933,23 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
         case 128: return launch_gate<4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);
         case 256: return launch_gate<8>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);
         default: set_error("edge_gate: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
+    }
+}
+
+extern "C" int gnnome_edge_gate_raw_f32(const float* e_in, float* x_out, int64_t num_edges, int hidden, const float* B1h,
+                                        const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
+                                        const float* W3, int ldw, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(num_edges >= 0, "edge_gate_raw: negative edge count");
+    if (num_edges == 0) return GNNOME_OK;
+    GN_REQUIRE(e_in && x_out && x_out != e_in && B1h && B2h && srt_src && srt_dst && W3, "edge_gate_raw: bad pointers");
+    GN_REQUIRE(ld_node >= hidden && ldw >= hidden && ldw % 4 == 0, "edge_gate_raw: bad strides");
+    GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0), "edge_gate_raw: e_in and W3 must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (hidden) {
+        case 64: return launch_gate<2>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, 2, nullptr, nullptr, s);
+        case 128: return launch_gate<4>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, 2, nullptr, nullptr, s);
+        case 256: return launch_gate<8>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, 2, nullptr, nullptr, s);
+        default: set_error("edge_gate_raw: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
 }

@@ -24,7 +24,8 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_score(
     const float* __restrict__ e, int64_t E, const float* __restrict__ Ps, const float* __restrict__ Qd, int ldn,
     const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const int32_t* __restrict__ srt_eid,
     const float* __restrict__ W1e, int ldw1, const float* __restrict__ W2, const float* __restrict__ b2,
-    const float* __restrict__ W3, const float* __restrict__ b3, float* __restrict__ logits, int total_tiles) {
+    const float* __restrict__ W3, const float* __restrict__ b3, float* __restrict__ logits, int total_tiles,
+    float* __restrict__ z1_out) {
     constexpr int H = 32 * NBH, HS = 32 * NBS, LDZ = HS + 4;
     constexpr int kGemmFloats = (kTileM + HS) * kLdk;
     constexpr int kStage2Floats = (kTileM + 32) * LDZ;
@@ -69,6 +70,12 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_score(
     }
     for (int i = tid; i < 32 * HS; i += kGemmThreads) W2s[(i / HS) * LDZ + (i % HS)] = W2[i];
     __syncthreads();
+    if (z1_out != nullptr) {  // training: keep relu(z1) for the backward of the tail
+        for (int i = tid; i < kTileM * (HS / 4); i += kGemmThreads) {
+            const int row = i / (HS / 4), q4 = i % (HS / 4);
+            if (row < valid) *reinterpret_cast<f32x4*>(z1_out + (row0 + row) * HS + 4 * q4) = *reinterpret_cast<const f32x4*>(Zs + row * LDZ + 4 * q4);
+        }
+    }
 
     f32x16 acc2;
     const float bias2 = b2[cl];
@@ -104,11 +111,11 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_score(
 template <int NBH, int NBS>
 static int launch_score(const float* e, int64_t E, const float* Ps, const float* Qd, int ldn, const int32_t* ss,
                         const int32_t* sd, const int32_t* se, const float* W1e, int ldw1, const float* W2, const float* b2,
-                        const float* W3, const float* b3, float* logits, hipStream_t s) {
+                        const float* W3, const float* b3, float* logits, hipStream_t s, float* z1_out) {
     const int64_t tiles = (E + kTileM - 1) / kTileM;
     GN_REQUIRE(tiles < (1ll << 31), "edge_score: too many tiles");
     hipLaunchKernelGGL((k_edge_score<NBH, NBS>), dim3((unsigned)tiles), dim3(kGemmThreads), 0, s, e, E, Ps, Qd, ldn, ss, sd,
-                       se, W1e, ldw1, W2, b2, W3, b3, logits, (int)tiles);
+                       se, W1e, ldw1, W2, b2, W3, b3, logits, (int)tiles, z1_out);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
@@ -116,11 +123,11 @@ static int launch_score(const float* e, int64_t E, const float* Ps, const float*
 template <int NBH>
 static int dispatch_hs(int hs, const float* e, int64_t E, const float* Ps, const float* Qd, int ldn, const int32_t* ss,
                        const int32_t* sd, const int32_t* se, const float* W1e, int ldw1, const float* W2, const float* b2,
-                       const float* W3, const float* b3, float* logits, hipStream_t s) {
+                       const float* W3, const float* b3, float* logits, hipStream_t s, float* z1_out) {
     switch (hs) {
-        case 32: return launch_score<NBH, 1>(e, E, Ps, Qd, ldn, ss, sd, se, W1e, ldw1, W2, b2, W3, b3, logits, s);
-        case 64: return launch_score<NBH, 2>(e, E, Ps, Qd, ldn, ss, sd, se, W1e, ldw1, W2, b2, W3, b3, logits, s);
-        case 128: return launch_score<NBH, 4>(e, E, Ps, Qd, ldn, ss, sd, se, W1e, ldw1, W2, b2, W3, b3, logits, s);
+        case 32: return launch_score<NBH, 1>(e, E, Ps, Qd, ldn, ss, sd, se, W1e, ldw1, W2, b2, W3, b3, logits, s, z1_out);
+        case 64: return launch_score<NBH, 2>(e, E, Ps, Qd, ldn, ss, sd, se, W1e, ldw1, W2, b2, W3, b3, logits, s, z1_out);
+        case 128: return launch_score<NBH, 4>(e, E, Ps, Qd, ldn, ss, sd, se, W1e, ldw1, W2, b2, W3, b3, logits, s, z1_out);
         default: set_error("edge_score: hidden_edge_scores=%d not in {32,64,128}", hs); return GNNOME_EINVAL;
     }
 }
@@ -131,7 +138,7 @@ extern "C" int gnnome_edge_score_f32(const float* e, int64_t num_edges, int hidd
                                      const float* Ps, const float* Qd, int ld_node, const int32_t* srt_src,
                                      const int32_t* srt_dst, const int32_t* srt_eid, const float* W1e, int ldw1,
                                      const float* W2, const float* b2, const float* W3, const float* b3, float* logits,
-                                     void* stream) {
+                                     float* z1_out, void* stream) {
     using namespace gnnome;
     GN_REQUIRE(num_edges >= 0, "edge_score: negative edge count");
     if (num_edges == 0) return GNNOME_OK;
@@ -140,9 +147,9 @@ extern "C" int gnnome_edge_score_f32(const float* e, int64_t num_edges, int hidd
     GN_REQUIRE(((uintptr_t)e % 16 == 0) && ((uintptr_t)W1e % 16 == 0), "edge_score: e and W1e must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     switch (hidden) {
-        case 64: return dispatch_hs<2>(hidden_edge_scores, e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s);
-        case 128: return dispatch_hs<4>(hidden_edge_scores, e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s);
-        case 256: return dispatch_hs<8>(hidden_edge_scores, e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s);
+        case 64: return dispatch_hs<2>(hidden_edge_scores, e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s, z1_out);
+        case 128: return dispatch_hs<4>(hidden_edge_scores, e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s, z1_out);
+        case 256: return dispatch_hs<8>(hidden_edge_scores, e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s, z1_out);
         default: set_error("edge_score: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
 }

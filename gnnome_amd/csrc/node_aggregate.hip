@@ -44,13 +44,17 @@ __device__ __forceinline__ float row_sum(float v) {
 // neighbour row, direction) items; each lane first fetches the indices of one item (so the dependent
 // index loads happen once per 64 items, not once per edge), then the wave walks the list with U items
 // per lane group in flight: 2*U*G independent H*4-byte row loads per wave.
-template <int H, int NORM>
+// MODE 0: the fused inference update.  MODE 1 (train forward): h_out = A1h + fwd + bwd (pre-normalisation) and the
+// four node tables the backward needs (aux0..3 = fwd, 1/(den_f+eps), bwd, 1/(den_b+eps)).  MODE 2 (aggregation
+// backward): aux0 = sum_in s*A2h[src], aux2 = sum_out s*A3h[dst], the raw gated sums with caller-chosen tables.
+template <int H, int NORM, int MODE>
 __global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
     const float* __restrict__ e, int64_t n_out, const float* __restrict__ A1h, const float* __restrict__ A2h,
     const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src,
     const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_dst,
     const float* __restrict__ h_in, int ldh, float* __restrict__ h_out, const float* __restrict__ scale,
-    const float* __restrict__ shift, int total_blocks) {
+    const float* __restrict__ shift, int total_blocks, float* __restrict__ aux0, float* __restrict__ aux1,
+    float* __restrict__ aux2, float* __restrict__ aux3) {
     constexpr int LPR = H / 4, G = 64 / LPR, U = (H == 256) ? 8 : 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t node = (int64_t)xcd_remap(blockIdx.x, total_blocks) * (kAggThreads / 64) + wave;
@@ -59,7 +63,8 @@ __global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
 
     const int ib = in_ptr[node], din = in_ptr[node + 1] - ib;
     const int ob = out_ptr[node], cnt = din + out_ptr[node + 1] - ob;
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(A1h + node * ldn + c);
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+    if (MODE != 2) a1 = *reinterpret_cast<const f32x4*>(A1h + node * ldn + c);
 
     f32x4 nf = {0.f, 0.f, 0.f, 0.f}, df = nf, nb = nf, db = nf;
     for (int base = 0; base < cnt; base += 64) {
@@ -106,12 +111,33 @@ __global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
         }
     }
 
-    f32x4 v;
+    f32x4 v, t0, t1, t2, t3;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float num_f = group_sum<H>(nf[k]), den_f = group_sum<H>(df[k]);
         const float num_b = group_sum<H>(nb[k]), den_b = group_sum<H>(db[k]);
         v[k] = a1[k] + num_f / (den_f + kAggEps) + num_b / (den_b + kAggEps);
+        if (MODE == 1) {
+            t0[k] = num_f / (den_f + kAggEps);
+            t1[k] = 1.0f / (den_f + kAggEps);
+            t2[k] = num_b / (den_b + kAggEps);
+            t3[k] = 1.0f / (den_b + kAggEps);
+        } else if (MODE == 2) {
+            t0[k] = num_f;
+            t2[k] = num_b;
+        }
+    }
+    if (MODE != 0) {
+        if (group == 0) {
+            *reinterpret_cast<f32x4*>(aux0 + node * H + c) = t0;
+            *reinterpret_cast<f32x4*>(aux2 + node * H + c) = t2;
+            if (MODE == 1) {
+                *reinterpret_cast<f32x4*>(aux1 + node * H + c) = t1;
+                *reinterpret_cast<f32x4*>(aux3 + node * H + c) = t3;
+                *reinterpret_cast<f32x4*>(h_out + node * H + c) = v;
+            }
+        }
+        return;
     }
     if (NORM == GNNOME_NORM_LAYER) {
         const float mean = row_sum<H>(v[0] + v[1] + v[2] + v[3]) * (1.0f / H);
@@ -137,17 +163,26 @@ template <int H>
 static int launch_agg(const float* e, int64_t n_out, const float* A1h, const float* A2h, const float* A3h, int ldn,
                       const int32_t* in_ptr, const int32_t* ss, const int32_t* out_ptr, const int32_t* out_pos,
                       const int32_t* od, const float* h_in, int ldh, float* h_out, int norm, const float* scale,
-                      const float* shift, hipStream_t s) {
+                      const float* shift, hipStream_t s, int mode = 0, float* aux0 = nullptr, float* aux1 = nullptr,
+                      float* aux2 = nullptr, float* aux3 = nullptr) {
     const int64_t blocks = (n_out + (kAggThreads / 64) - 1) / (kAggThreads / 64);
     GN_REQUIRE(blocks < (1ll << 31), "node_aggregate: too many nodes");
-    if (norm == GNNOME_NORM_AFFINE) {
-        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
+    if (mode == 1) {
+        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 1>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
                            n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
-                           (int)blocks);
+                           (int)blocks, aux0, aux1, aux2, aux3);
+    } else if (mode == 2) {
+        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 2>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
+                           n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
+                           (int)blocks, aux0, aux1, aux2, aux3);
+    } else if (norm == GNNOME_NORM_AFFINE) {
+        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 0>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
+                           n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
+                           (int)blocks, aux0, aux1, aux2, aux3);
     } else {
-        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_LAYER>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
+        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_LAYER, 0>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
                            n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
-                           (int)blocks);
+                           (int)blocks, aux0, aux1, aux2, aux3);
     }
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
@@ -178,5 +213,24 @@ extern "C" int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num
         case 128: return launch_agg<128>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
         case 256: return launch_agg<256>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
         default: set_error("node_aggregate: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
+    }
+}
+
+extern "C" int gnnome_node_aggregate_raw_f32(const float* e, int hidden, int64_t num_nodes, int mode, const float* A1h,
+                                             const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
+                                             const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
+                                             const int32_t* out_dst, float* v_out, float* aux0, float* aux1, float* aux2,
+                                             float* aux3, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(num_nodes >= 0 && (mode == 1 || mode == 2), "node_aggregate_raw: mode must be 1 or 2");
+    if (num_nodes == 0) return GNNOME_OK;
+    GN_REQUIRE(A2h && A3h && in_ptr && out_ptr && aux0 && aux2 && ld_node >= hidden && ld_node % 4 == 0, "node_aggregate_raw: bad arguments");
+    GN_REQUIRE(mode == 2 || (A1h && v_out && aux1 && aux3), "node_aggregate_raw: mode 1 needs A1h, v_out, aux1, aux3");
+    hipStream_t s = (hipStream_t)stream;
+    switch (hidden) {
+        case 64: return launch_agg<64>(e, num_nodes, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, nullptr, hidden, v_out, 0, nullptr, nullptr, s, mode, aux0, aux1, aux2, aux3);
+        case 128: return launch_agg<128>(e, num_nodes, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, nullptr, hidden, v_out, 0, nullptr, nullptr, s, mode, aux0, aux1, aux2, aux3);
+        case 256: return launch_agg<256>(e, num_nodes, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, nullptr, hidden, v_out, 0, nullptr, nullptr, s, mode, aux0, aux1, aux2, aux3);
+        default: set_error("node_aggregate_raw: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
 }

@@ -1,0 +1,259 @@
+// Training-step support kernels that are pure streaming work (HBM-bound): BatchNorm statistics and
+// application, BatchNorm backward, segment sums over the graph views.
+//
+// Reference semantics: torch.nn.BatchNorm1d in training mode as used at gated_gcn_full.py:106,119 (bn_e
+// over all E edge rows, called twice per layer) and :132 (bn_h over all N node rows); autograd through
+// relu / residual (:107-110, :134-137).  The layer's backward is restated in gnnome_amd/train.py; these
+// kernels are its building blocks.  All reductions over rows are per-channel column sums.
+#include "common.h"
+
+namespace gnnome {
+
+constexpr int kEwThreads = 256;
+
+// Column reduction skeleton: thread t owns float4 column group (t % (H/4)) and walks rows r = r0 + k*stride;
+// per-thread partials are combined through LDS and one atomicAdd per column per workgroup.
+template <int NACC, class F>
+__device__ __forceinline__ void column_reduce(int64_t rows, int H, float* const (&out)[NACC], F&& per_row) {
+    __shared__ float red[NACC][kEwThreads * 4];
+    const int lpr = H / 4, tid = threadIdx.x;
+    const int c4 = tid % lpr, rsub = tid / lpr, rpb = kEwThreads / lpr;
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = (int64_t)blockIdx.x * rpb + rsub; r < rows; r += (int64_t)gridDim.x * rpb) per_row(r, 4 * c4, acc);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[a][(4 * c4 + j) * rpb + rsub] = acc[a][j];
+    __syncthreads();
+    for (int c = tid; c < H; c += kEwThreads) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            float s = 0.f;
+            for (int k = 0; k < rpb; ++k) s += red[a][c * rpb + k];
+            atomicAdd(out[a] + c, s);
+        }
+    }
+}
+
+// s1[c] += sum_r x'[r,c];  s2[c] += sum_r x'[r,c] * y'[r,c],  x' = x - center[c] (center NULL: 0), y' likewise when
+// y aliases x.  With center = the column mean this is the second pass of a two-pass variance: sum (x-mean)^2 has
+// none of the cancellation of sum x^2 / n - mean^2 (the edge state reaches |e| ~ 500 with a spread of a few units).
+__global__ __launch_bounds__(kEwThreads) void k_colsum2(const float* __restrict__ x, const float* __restrict__ y, int64_t rows,
+                                                        int H, const float* __restrict__ center, float* __restrict__ s1,
+                                                        float* __restrict__ s2) {
+    float* const out[2] = {s1, s2};
+    const bool same = x == y;
+    column_reduce<2>(rows, H, out, [&](int64_t r, int c, f32x4 (&acc)[2]) {
+        f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * H + c);
+        f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * H + c);
+        if (center != nullptr) {
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(center + c);
+            xv -= cv;
+            if (same) yv -= cv;
+        }
+        acc[0] += xv;
+        acc[1] += xv * yv;
+    });
+}
+
+// BatchNorm backward statistics through the relu:  m = (x*scale + shift > 0), the forward's own expression
+// (recovering the mask from out - res would lose activations smaller than an ulp of the residual)
+//   s1[c] += sum_r dy*m ;  s2[c] += sum_r dy*m*(x - mean[c])
+__global__ __launch_bounds__(kEwThreads) void k_bn_bwd_stats(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, int64_t rows, int H,
+                                                             float* __restrict__ s1, float* __restrict__ s2) {
+    float* const o[2] = {s1, s2};
+    column_reduce<2>(rows, H, o, [&](int64_t r, int c, f32x4 (&acc)[2]) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + r * H + c);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * H + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g = (xv[j] * scale[c + j] + shift[c + j] > 0.f) ? d[j] : 0.f;
+            acc[0][j] += g;
+            acc[1][j] += g * (xv[j] - mean[c + j]);
+        }
+    });
+}
+
+// dx = a[c] * (dy*m - c1[c] - (x - mean[c]) * rstd[c] * c2[c]),  m = (x*scale + shift > 0)
+__global__ __launch_bounds__(kEwThreads) void k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int64_t rows, int H, const float* __restrict__ a,
+                                                             const float* __restrict__ c1, const float* __restrict__ c2,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float* __restrict__ dx) {
+    const int64_t total = rows * (H / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (H / 4)) * 4;
+        const int64_t off = (i / (H / 4)) * H + c;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + off);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g = (xv[j] * scale[c + j] + shift[c + j] > 0.f) ? d[j] : 0.f;
+            o[j] = a[c + j] * (g - c1[c + j] - (xv[j] - mean[c + j]) * rstd[c + j] * c2[c + j]);
+        }
+        *reinterpret_cast<f32x4*>(dx + off) = o;
+    }
+}
+
+// out = relu(x * scale + shift) + res
+__global__ __launch_bounds__(kEwThreads) void k_bn_relu_res(const float* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ res,
+                                                            int64_t rows, int H, float* __restrict__ out) {
+    const int64_t total = rows * (H / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (H / 4)) * 4;
+        const int64_t off = (i / (H / 4)) * H + c;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(xv[j] * scale[c + j] + shift[c + j], 0.f) + rv[j];
+        *reinterpret_cast<f32x4*>(out + off) = o;
+    }
+}
+
+// out = a + b
+__global__ __launch_bounds__(kEwThreads) void k_add(const float* __restrict__ a, const float* __restrict__ b, int64_t n4,
+                                                    float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+}
+
+// o1 = a*b ; o2 = a*b*c   (node-sized helper of the aggregation backward)
+__global__ __launch_bounds__(kEwThreads) void k_mul23(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ c, int64_t n4, float* __restrict__ o1,
+                                                      float* __restrict__ o2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 av = reinterpret_cast<const f32x4*>(a)[i], bv = reinterpret_cast<const f32x4*>(b)[i];
+        const f32x4 cv = reinterpret_cast<const f32x4*>(c)[i];
+        const f32x4 t = av * bv;
+        reinterpret_cast<f32x4*>(o1)[i] = t;
+        reinterpret_cast<f32x4*>(o2)[i] = t * cv;
+    }
+}
+
+// out[i,:] = sum_{q in [ptr[i], ptr[i+1])} X[pos ? pos[q] : q, :]   one wave per node, W/4 lanes per row
+template <int W>
+__global__ __launch_bounds__(256) void k_segment_sum(const float* __restrict__ X, const int32_t* __restrict__ ptr,
+                                                     const int32_t* __restrict__ pos, int64_t n_nodes, float* __restrict__ out,
+                                                     int ld_out) {
+    constexpr int LPR = W / 4, G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= n_nodes) return;
+    const int group = lane / LPR, c = (lane % LPR) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int b = ptr[node], e = ptr[node + 1];
+    for (int q = b + group; q < e; q += G) {
+        const int64_t p = pos != nullptr ? pos[q] : q;
+        acc += *reinterpret_cast<const f32x4*>(X + p * W + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1) acc[j] += __shfl_xor(acc[j], m);
+    if (group == 0) *reinterpret_cast<f32x4*>(out + node * ld_out + c) = acc;
+}
+
+static unsigned ew_grid(int64_t work_items) {
+    int64_t b = (work_items + kEwThreads - 1) / kEwThreads;
+    if (b < 1) b = 1;
+    if (b > kNumCUs * 8) b = kNumCUs * 8;
+    return (unsigned)b;
+}
+
+static bool ok_width(int H) { return H == 16 || H == 32 || H == 64 || H == 128 || H == 256; }
+
+}  // namespace gnnome
+
+using namespace gnnome;
+
+extern "C" int gnnome_colsum2_f32(const float* x, const float* y, int64_t rows, int hidden, const float* center, float* s1,
+                                  float* s2, void* stream) {
+    GN_REQUIRE(rows >= 0 && ok_width(hidden), "colsum2: hidden=%d not in {16,32,64,128,256}", hidden);
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(x && s1 && s2, "colsum2: null pointer");
+    const int rpb = kEwThreads / (hidden / 4);
+    hipLaunchKernelGGL(k_colsum2, dim3(ew_grid((rows + rpb - 1) / rpb * kEwThreads / 4)), dim3(kEwThreads), 0, (hipStream_t)stream,
+                       x, y ? y : x, rows, hidden, center, s1, s2);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_bn_bwd_stats_f32(const float* dy, const float* x, const float* scale, const float* shift,
+                                       const float* mean, int64_t rows, int hidden, float* s1, float* s2, void* stream) {
+    GN_REQUIRE(rows >= 0 && ok_width(hidden), "bn_bwd_stats: hidden=%d not in {16,32,64,128,256}", hidden);
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(dy && x && scale && shift && mean && s1 && s2, "bn_bwd_stats: null pointer");
+    const int rpb = kEwThreads / (hidden / 4);
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(ew_grid((rows + rpb - 1) / rpb * kEwThreads / 4)), dim3(kEwThreads), 0,
+                       (hipStream_t)stream, dy, x, scale, shift, mean, rows, hidden, s1, s2);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const float* scale, const float* shift, int64_t rows,
+                                       int hidden, const float* a, const float* c1, const float* c2, const float* mean,
+                                       const float* rstd, float* dx, void* stream) {
+    GN_REQUIRE(rows >= 0 && hidden > 0 && hidden % 4 == 0, "bn_bwd_apply: bad shape");
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(dy && x && scale && shift && a && c1 && c2 && mean && rstd && dx, "bn_bwd_apply: null pointer");
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(rows * (hidden / 4))), dim3(kEwThreads), 0, (hipStream_t)stream, dy, x, scale,
+                       shift, rows, hidden, a, c1, c2, mean, rstd, dx);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_bn_relu_res_f32(const float* x, const float* scale, const float* shift, const float* res, int64_t rows,
+                                      int hidden, float* out, void* stream) {
+    GN_REQUIRE(rows >= 0 && hidden > 0 && hidden % 4 == 0, "bn_relu_res: bad shape");
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(x && scale && shift && res && out, "bn_relu_res: null pointer");
+    hipLaunchKernelGGL(k_bn_relu_res, dim3(ew_grid(rows * (hidden / 4))), dim3(kEwThreads), 0, (hipStream_t)stream, x, scale, shift,
+                       res, rows, hidden, out);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_mul23_f32(const float* a, const float* b, const float* c, int64_t count, float* o1, float* o2,
+                                void* stream) {
+    GN_REQUIRE(count >= 0 && count % 4 == 0, "mul23: count must be a multiple of 4");
+    if (count == 0) return GNNOME_OK;
+    GN_REQUIRE(a && b && c && o1 && o2, "mul23: null pointer");
+    hipLaunchKernelGGL(k_mul23, dim3(ew_grid(count / 4)), dim3(kEwThreads), 0, (hipStream_t)stream, a, b, c, count / 4, o1, o2);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_segment_sum_f32(const float* X, int width, const int32_t* ptr, const int32_t* pos, int64_t num_nodes,
+                                      float* out, int ld_out, void* stream) {
+    GN_REQUIRE(num_nodes >= 0, "segment_sum: negative node count");
+    if (num_nodes == 0) return GNNOME_OK;
+    GN_REQUIRE(ptr && out && ld_out >= width && ld_out % 4 == 0, "segment_sum: bad arguments");
+    const dim3 grid((unsigned)((num_nodes + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (width) {
+        case 64: hipLaunchKernelGGL(k_segment_sum<64>, grid, block, 0, s, X, ptr, pos, num_nodes, out, ld_out); break;
+        case 128: hipLaunchKernelGGL(k_segment_sum<128>, grid, block, 0, s, X, ptr, pos, num_nodes, out, ld_out); break;
+        case 256: hipLaunchKernelGGL(k_segment_sum<256>, grid, block, 0, s, X, ptr, pos, num_nodes, out, ld_out); break;
+        case 32: hipLaunchKernelGGL(k_segment_sum<32>, grid, block, 0, s, X, ptr, pos, num_nodes, out, ld_out); break;
+        default: set_error("segment_sum: width=%d not in {16,32,64,128,256}", width); return GNNOME_EINVAL;
+    }
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_add_f32(const float* a, const float* b, int64_t count, float* out, void* stream) {
+    GN_REQUIRE(count >= 0 && count % 4 == 0, "add: count must be a multiple of 4");
+    if (count == 0) return GNNOME_OK;
+    GN_REQUIRE(a && b && out, "add: null pointer");
+    hipLaunchKernelGGL(k_add, dim3(ew_grid(count / 4)), dim3(kEwThreads), 0, (hipStream_t)stream, a, b, count / 4, out);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}

@@ -1,0 +1,281 @@
+// Training-step kernels with arithmetic in them: weight-gradient GEMM (reduction over rows), the per-edge
+// backward of the score predictor tail and of the gated aggregation, and two tiny helpers for the encoders.
+// The backward of the path is restated in gnnome_amd/train.py (autograd of models/full_graph.py:22-30 as
+// driven by train.py:138-145, 328-330); each kernel's contract is in include/gnnome_hip.h.
+#include "gemm_tile.h"
+
+namespace gnnome {
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad:  C[Ka,Kb] = A[R,Ka]^T * B[R,Kb]   (nn.Linear weight gradient dW = dY^T X; also dW of B_3, W1, W2)
+// Exact fp32 on v_mfma_f32_32x32x2_f32 with the ROW index as the MFMA k dimension.  A workgroup owns one
+// 64x64 output tile and one contiguous chunk of rows and writes its partial tile; a second kernel adds the
+// partials in chunk order, so the result does not depend on scheduling (no float atomics).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kWgTile = 64, kWgRows = 64, kWgLd = kWgTile + 4;
+
+__global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__ A, int lda, int Ka, const float* __restrict__ B,
+                                                       int ldb, int Kb, int64_t R, int64_t rows_per_chunk,
+                                                       float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float As[kWgRows * kWgLd];
+    __shared__ __attribute__((aligned(16))) float Bs[kWgRows * kWgLd];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i0 = blockIdx.x * kWgTile, j0 = blockIdx.y * kWgTile;
+    const int64_t r_begin = (int64_t)blockIdx.z * rows_per_chunk, r_end = min(R, r_begin + rows_per_chunk);
+    const int wi = wave & 1, wj = wave >> 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int c4 = tid & 15, rr = tid >> 4;  // 16 float4 per 64-wide row, 16 rows per pass
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
+#pragma unroll
+        for (int it = 0; it < kWgRows / 16; ++it) {
+            const int lr = rr + 16 * it;
+            const int64_t row = r0 + lr;
+            f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = av;
+            if (row < r_end) {  // rows and columns outside the operands contribute zeros
+                if (i0 + 4 * c4 < Ka) av = *reinterpret_cast<const f32x4*>(A + row * lda + i0 + 4 * c4);
+                if (j0 + 4 * c4 < Kb) bv = *reinterpret_cast<const f32x4*>(B + row * ldb + j0 + 4 * c4);
+            }
+            *reinterpret_cast<f32x4*>(As + lr * kWgLd + 4 * c4) = av;
+            *reinterpret_cast<f32x4*>(Bs + lr * kWgLd + 4 * c4) = bv;
+        }
+        __syncthreads();
+        // lane l supplies A^T[i = l&31][k = row 2s + (l>>5)] and B[k][j = l&31]
+        const float* ap = As + (lane >> 5) * kWgLd + 32 * wi + (lane & 31);
+        const float* bp = Bs + (lane >> 5) * kWgLd + 32 * wj + (lane & 31);
+#pragma unroll 8
+        for (int s = 0; s < kWgRows / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * kWgLd], bp[2 * s * kWgLd], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    float* out = partial + ((int64_t)blockIdx.z * Ka + i0) * Kb + j0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = 32 * wi + cd_row(r, lane), j = 32 * wj + (lane & 31);
+        if (i0 + i < Ka && j0 + j < Kb) out[(int64_t)i * Kb + j] = acc[r];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int64_t elems, int chunks,
+                                                      float* __restrict__ C, int ldc, int Kb) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * elems + i];
+        C[(i / Kb) * ldc + (i % Kb)] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// score predictor tail, backward.  Forward (score_predictor.py:15-16): z2 = relu(W2 z1 + b2), s = W3.z2 + b3.
+// Given z1 = relu(..) [E,hs] (saved by the forward) and ds [E] (gathered through srt_eid), one thread per edge:
+//   dz2 = ds * W3 * (z2 > 0);  dz1 = (W2^T dz2) * (z1 > 0);  u = ds * z2
+// dz1, dz2, u are written out; the weight gradients are column sums / wgrad products of them.
+// ---------------------------------------------------------------------------------------------------
+template <int HS>
+__global__ __launch_bounds__(256) void k_score_tail_bwd(const float* __restrict__ z1, const float* __restrict__ ds,
+                                                        const int32_t* __restrict__ srt_eid, int64_t E,
+                                                        const float* __restrict__ W2, const float* __restrict__ b2,
+                                                        const float* __restrict__ W3, float* __restrict__ dz1,
+                                                        float* __restrict__ dz2, float* __restrict__ u) {
+    __shared__ float w2s[32 * HS];
+    __shared__ float b2s[32], w3s[32];
+    for (int i = threadIdx.x; i < 32 * HS; i += blockDim.x) w2s[i] = W2[i];
+    if (threadIdx.x < 32) {
+        b2s[threadIdx.x] = b2[threadIdx.x];
+        w3s[threadIdx.x] = W3[threadIdx.x];
+    }
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E; p += (int64_t)gridDim.x * blockDim.x) {
+        const float g = ds[srt_eid != nullptr ? (int64_t)srt_eid[p] : p];
+        float z[HS];
+#pragma unroll
+        for (int j4 = 0; j4 < HS / 4; ++j4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(z1 + p * HS + 4 * j4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[4 * j4 + j] = v[j];
+        }
+        float d1[HS];
+#pragma unroll
+        for (int j = 0; j < HS; ++j) d1[j] = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            float a = b2s[k];
+#pragma unroll
+            for (int j = 0; j < HS; ++j) a += w2s[k * HS + j] * z[j];
+            const float z2 = fmaxf(a, 0.f);
+            const float d2 = a > 0.f ? g * w3s[k] : 0.f;
+            dz2[p * 32 + k] = d2;
+            u[p * 32 + k] = g * z2;
+#pragma unroll
+            for (int j = 0; j < HS; ++j) d1[j] += w2s[k * HS + j] * d2;
+        }
+#pragma unroll
+        for (int j4 = 0; j4 < HS / 4; ++j4) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = z[4 * j4 + j] > 0.f ? d1[4 * j4 + j] : 0.f;
+            *reinterpret_cast<f32x4*>(dz1 + p * HS + 4 * j4) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gated aggregation, backward, per edge (gated_gcn_full.py:111-114,124-127).  With s = sigmoid(e'),
+//   hf_i = sum s A2h[src] / (sum s + eps)  =>  d s_p (forward part)  = Tf[dst] * A2h[src] - Uf[dst]
+//   hb_i = sum s A3h[dst] / (sum s + eps)  =>  d s_p (backward part) = Tb[src] * A3h[dst] - Ub[src]
+// where T = dv * rden and U = T * h are node tables prepared by k_mul23.   de[p] += s (1 - s) (d s_p).
+// ---------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void k_agg_edge_bwd(const float* __restrict__ e, int64_t E, const float* __restrict__ Tf,
+                                                      const float* __restrict__ Uf, const float* __restrict__ Tb,
+                                                      const float* __restrict__ Ub, const float* __restrict__ A2h,
+                                                      const float* __restrict__ A3h, int ldn,
+                                                      const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst,
+                                                      float* __restrict__ de) {
+    constexpr int LPR = H / 4;
+    const int64_t total = E * LPR;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / LPR;
+        const int c = (int)(i % LPR) * 4;
+        const int64_t s_ = srt_src[p], d_ = srt_dst[p];
+        const f32x4 x = *reinterpret_cast<const f32x4*>(e + p * H + c);
+        const f32x4 tf = *reinterpret_cast<const f32x4*>(Tf + d_ * H + c), uf = *reinterpret_cast<const f32x4*>(Uf + d_ * H + c);
+        const f32x4 tb = *reinterpret_cast<const f32x4*>(Tb + s_ * H + c), ub = *reinterpret_cast<const f32x4*>(Ub + s_ * H + c);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(A2h + s_ * ldn + c), a3 = *reinterpret_cast<const f32x4*>(A3h + d_ * ldn + c);
+        f32x4 g = *reinterpret_cast<const f32x4*>(de + p * H + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sg = sigmoidf_(x[j]);
+            g[j] += sg * (1.f - sg) * (tf[j] * a2[j] - uf[j] + tb[j] * a3[j] - ub[j]);
+        }
+        *reinterpret_cast<f32x4*>(de + p * H + c) = g;
+    }
+}
+
+// t[r,:] = relu(W1 * in[row(r),:] + b1)   (hidden activations of an encoder, recomputed for its backward)
+__global__ __launch_bounds__(256) void k_encode_hidden(const float* __restrict__ in, int64_t rows, int F,
+                                                       const int32_t* __restrict__ gather, const float* __restrict__ W1,
+                                                       const float* __restrict__ b1, int M, float* __restrict__ t) {
+    const int64_t total = rows * M;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / M;
+        const int j = (int)(i % M);
+        const int64_t rin = gather != nullptr ? (int64_t)gather[r] : r;
+        float s = b1[j];
+        for (int f = 0; f < F; ++f) s += W1[j * F + f] * in[rin * F + f];
+        t[i] = fmaxf(s, 0.f);
+    }
+}
+
+// dx = dy * (y > 0)
+__global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y, int64_t n,
+                                                  float* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+static unsigned grid_for_items(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > kNumCUs * 8) b = kNumCUs * 8;
+    return (unsigned)b;
+}
+
+}  // namespace gnnome
+
+using namespace gnnome;
+
+extern "C" int gnnome_wgrad_workspace_bytes(int64_t rows, int Ka, int Kb, size_t* bytes_host) {
+    GN_REQUIRE(bytes_host && rows >= 0 && Ka > 0 && Kb > 0, "wgrad: bad arguments");
+    int64_t chunks = (rows + 4095) / 4096;  // >= 4096 rows per chunk
+    if (chunks < 1) chunks = 1;
+    if (chunks > 512) chunks = 512;
+    *bytes_host = (size_t)chunks * Ka * Kb * sizeof(float);
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C,
+                                int ldc, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(rows >= 0 && Ka > 0 && Kb > 0 && Ka % 4 == 0 && Kb % 4 == 0, "wgrad: Ka=%d Kb=%d must be positive multiples of 4", Ka, Kb);
+    GN_REQUIRE(C && ldc >= Kb, "wgrad: bad output");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows == 0) {
+        for (int i = 0; i < Ka; ++i) GN_HIP(hipMemsetAsync(C + (int64_t)i * ldc, 0, Kb * sizeof(float), s));
+        return GNNOME_OK;
+    }
+    GN_REQUIRE(A && B && workspace && lda >= Ka && ldb >= Kb && lda % 4 == 0 && ldb % 4 == 0, "wgrad: bad operands");
+    GN_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "wgrad: A and B must be 16-byte aligned");
+    int64_t chunks = (rows + 4095) / 4096;
+    if (chunks > 512) chunks = 512;
+    int64_t rpc = (rows + chunks - 1) / chunks;
+    rpc = (rpc + kWgRows - 1) / kWgRows * kWgRows;
+    chunks = (rows + rpc - 1) / rpc;
+    const size_t need = (size_t)chunks * Ka * Kb * sizeof(float);
+    if (workspace_bytes < need) {
+        set_error("wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+        return GNNOME_EWORKSPACE;
+    }
+    const dim3 grid((Ka + kWgTile - 1) / kWgTile, (Kb + kWgTile - 1) / kWgTile, (unsigned)chunks);
+    hipLaunchKernelGGL(k_wgrad_partial, grid, dim3(256), 0, s, A, lda, Ka, B, ldb, Kb, rows, rpc, (float*)workspace);
+    GN_LAUNCH_CHECK();
+    const int64_t elems = (int64_t)Ka * Kb;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for_items(elems)), dim3(256), 0, s, (const float*)workspace, elems, (int)chunks, C,
+                       ldc, Kb);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_score_tail_bwd_f32(const float* z1, const float* dscore, const int32_t* srt_eid, int64_t num_edges,
+                                         int hidden_edge_scores, const float* W2, const float* b2, const float* W3, float* dz1,
+                                         float* dz2, float* u, void* stream) {
+    GN_REQUIRE(num_edges >= 0, "score_tail_bwd: negative edge count");
+    if (num_edges == 0) return GNNOME_OK;
+    GN_REQUIRE(z1 && dscore && W2 && b2 && W3 && dz1 && dz2 && u, "score_tail_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(grid_for_items(num_edges)), block(256);
+    switch (hidden_edge_scores) {
+        case 32: hipLaunchKernelGGL(k_score_tail_bwd<32>, grid, block, 0, s, z1, dscore, srt_eid, num_edges, W2, b2, W3, dz1, dz2, u); break;
+        case 64: hipLaunchKernelGGL(k_score_tail_bwd<64>, grid, block, 0, s, z1, dscore, srt_eid, num_edges, W2, b2, W3, dz1, dz2, u); break;
+        default: set_error("score_tail_bwd: hidden_edge_scores=%d not in {32,64}", hidden_edge_scores); return GNNOME_EINVAL;
+    }
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_agg_edge_bwd_f32(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                                       const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
+                                       const int32_t* srt_src, const int32_t* srt_dst, float* de, void* stream) {
+    GN_REQUIRE(num_edges >= 0, "agg_edge_bwd: negative edge count");
+    if (num_edges == 0) return GNNOME_OK;
+    GN_REQUIRE(e && Tf && Uf && Tb && Ub && A2h && A3h && srt_src && srt_dst && de && ld_node % 4 == 0, "agg_edge_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(grid_for_items(num_edges * (hidden / 4))), block(256);
+    switch (hidden) {
+        case 64: hipLaunchKernelGGL(k_agg_edge_bwd<64>, grid, block, 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de); break;
+        case 128: hipLaunchKernelGGL(k_agg_edge_bwd<128>, grid, block, 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de); break;
+        case 256: hipLaunchKernelGGL(k_agg_edge_bwd<256>, grid, block, 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de); break;
+        default: set_error("agg_edge_bwd: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
+    }
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_encode_hidden_f32(const float* in, int64_t rows, int in_features, const int32_t* gather, const float* W1,
+                                        const float* b1, int hidden_ne, float* t, void* stream) {
+    GN_REQUIRE(rows >= 0 && in_features > 0 && hidden_ne > 0, "encode_hidden: bad shape");
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(in && W1 && b1 && t, "encode_hidden: null pointer");
+    hipLaunchKernelGGL(k_encode_hidden, dim3(grid_for_items(rows * hidden_ne)), dim3(256), 0, (hipStream_t)stream, in, rows,
+                       in_features, gather, W1, b1, hidden_ne, t);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_relu_bwd_f32(const float* dy, const float* y, int64_t count, float* dx, void* stream) {
+    GN_REQUIRE(count >= 0, "relu_bwd: negative count");
+    if (count == 0) return GNNOME_OK;
+    GN_REQUIRE(dy && y && dx, "relu_bwd: null pointer");
+    hipLaunchKernelGGL(k_relu_bwd, dim3(grid_for_items(count)), dim3(256), 0, (hipStream_t)stream, dy, y, count, dx);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}

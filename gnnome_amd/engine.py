@@ -121,11 +121,11 @@ def compute_device(*tensors):
 
 
 def _refuse_training(module):
-    if module.training and torch.is_grad_enabled():
-        raise NotImplementedError("the training step (train-mode BatchNorm + backward kernels) is not part of this build yet; "
-                                  "call model.eval() / torch.no_grad()")
-    if module.training and any(isinstance(m, torch.nn.BatchNorm1d) for m in module.modules()):
-        raise NotImplementedError("train-mode BatchNorm statistics are not part of this build yet; call model.eval()")
+    """The layer-level / predictor-level entry points are inference-only; training goes through the model
+    (gnnome_amd/train.py differentiates the whole path as one autograd.Function)."""
+    if module.training and (torch.is_grad_enabled() or any(isinstance(m, torch.nn.BatchNorm1d) for m in module.modules())):
+        raise NotImplementedError("train mode is supported through SymGatedGCNModel.forward only; call .eval() for the "
+                                  "layer-level API")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -177,7 +177,9 @@ def run_stack(ops, prep, views, x, e_raw, exchange=None, n_own=None, n_score=Non
 
 def model_forward(model, graph, x, e):
     """models/full_graph.py:22-30 on the MI355X."""
-    _refuse_training(model)
+    if model.training:
+        from .train import train_forward
+        return train_forward(model, graph, x, e).to(x.device)
     out_device = x.device
     device = compute_device(x, e)
     prep = prepared_for(model, device, Prepared)

@@ -149,7 +149,7 @@ def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_n
     return h_out
 
 
-def edge_score(e, Ps, Qd, views, W1e, W2, b2, W3, b3, logits, num_edges=None, scatter_to_edge_id=True):
+def edge_score(e, Ps, Qd, views, W1e, W2, b2, W3, b3, logits, num_edges=None, scatter_to_edge_id=True, z1_out=None):
     lib = _lib.load()
     e, _ = _rows(e, "edge_score.e")
     Ps, ldn = _rows(Ps, "edge_score.Ps")
@@ -161,8 +161,8 @@ def edge_score(e, Ps, Qd, views, W1e, W2, b2, W3, b3, logits, num_edges=None, sc
     with torch.cuda.device(e.device):
         _lib.check(lib.gnnome_edge_score_f32(_ptr(e), E, e.shape[1], W2.shape[1], _ptr(Ps), _ptr(Qd), ldn,
                                              _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(eid), _ptr(W1e), ldw1,
-                                             _ptr(W2), _ptr(b2), _ptr(W3), _ptr(b3), _ptr(logits), _stream(e.device)),
-                   "edge_score_f32")
+                                             _ptr(W2), _ptr(b2), _ptr(W3), _ptr(b3), _ptr(logits), _ptr(z1_out),
+                                             _stream(e.device)), "edge_score_f32")
     return logits
 
 
@@ -178,3 +178,158 @@ def gather_rows(table, idx, out=None):
         _lib.check(lib.gnnome_gather_rows_f32(_ptr(table), ld_in, _ptr(idx), rows, width, _ptr(out), ld_out,
                                               _stream(table.device)), "gather_rows_f32")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# training-step entries (include/gnnome_hip.h, "Training step")
+# ---------------------------------------------------------------------------------------------------
+
+def _call(name, device, *args):
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        _lib.check(getattr(lib, name)(*args, _stream(device)), name)
+
+
+def _dense(t, name):
+    _f32(t, name)
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def edge_gate_raw(e, B1h, B2h, views, W3):
+    e = _dense(e, "edge_gate_raw.e")
+    B1h, ldn = _rows(B1h, "edge_gate_raw.B1h")
+    B2h, _ = _rows(B2h, "edge_gate_raw.B2h")
+    W3, ldw = _rows(W3, "edge_gate_raw.W3")
+    out = torch.empty_like(e)
+    _call("gnnome_edge_gate_raw_f32", e.device, _ptr(e), _ptr(out), e.shape[0], e.shape[1], _ptr(B1h), _ptr(B2h), ldn,
+          _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(W3), ldw)
+    return out
+
+
+def node_aggregate_raw(e, A1h, A2h, A3h, views, mode, num_nodes):
+    """mode 1 -> (v, fwd, rden_f, bwd, rden_b); mode 2 -> (sum_in s*A2h[src], sum_out s*A3h[dst])."""
+    A2h, ldn = _rows(A2h, "node_aggregate_raw.A2h")
+    A3h, l3 = _rows(A3h, "node_aggregate_raw.A3h")
+    assert ldn == l3
+    H, dev = A2h.shape[1], A2h.device
+    mk = lambda: torch.empty((num_nodes, H), dtype=torch.float32, device=dev)  # noqa: E731
+    if mode == 1:
+        A1h, l1 = _rows(A1h, "node_aggregate_raw.A1h")
+        assert l1 == ldn
+        v, a0, a1, a2, a3 = mk(), mk(), mk(), mk(), mk()
+    else:
+        v, a0, a1, a2, a3 = None, mk(), None, mk(), None
+    _call("gnnome_node_aggregate_raw_f32", dev, _ptr(e), H, num_nodes, mode, _ptr(A1h) if mode == 1 else _ptr(None), _ptr(A2h),
+          _ptr(A3h), ldn, _ptr(views.in_ptr), _ptr(views.srt_src), _ptr(views.out_ptr), _ptr(views.out_pos), _ptr(views.out_dst),
+          _ptr(v), _ptr(a0), _ptr(a1), _ptr(a2), _ptr(a3))
+    return (v, a0, a1, a2, a3) if mode == 1 else (a0, a2)
+
+
+def colsum2(x, y=None, center=None):
+    """(sum_r x', sum_r x'*y') per column with x' = x - center; y=None gives the (centred) sum of squares."""
+    x = _dense(x, "colsum2.x")
+    H = x.shape[1]
+    s = torch.zeros((2, H), dtype=torch.float32, device=x.device)
+    _call("gnnome_colsum2_f32", x.device, _ptr(x), _ptr(y), x.shape[0], H, _ptr(center), _ptr(s[0]), _ptr(s[1]))
+    return s[0], s[1]
+
+
+def batch_stats(x):
+    """Per-column (mean, biased variance) of x[rows, H] by the two-pass formula."""
+    rows = x.shape[0]
+    mean = (colsum2(x)[0] / rows).contiguous()
+    d1, d2 = colsum2(x, center=mean)
+    return mean, (d2 / rows - (d1 / rows) ** 2).clamp_min_(0.0)
+
+
+def bn_relu_res(x, scale, shift, res):
+    x, res = _dense(x, "bn_relu_res.x"), _dense(res, "bn_relu_res.res")
+    out = torch.empty_like(x)
+    _call("gnnome_bn_relu_res_f32", x.device, _ptr(x), _ptr(scale), _ptr(shift), _ptr(res), x.shape[0], x.shape[1], _ptr(out))
+    return out
+
+
+def bn_bwd_stats(dy, x, scale, shift, mean):
+    H = x.shape[1]
+    s = torch.zeros((2, H), dtype=torch.float32, device=x.device)
+    _call("gnnome_bn_bwd_stats_f32", x.device, _ptr(_dense(dy, "dy")), _ptr(_dense(x, "x")), _ptr(scale), _ptr(shift), _ptr(mean),
+          x.shape[0], H, _ptr(s[0]), _ptr(s[1]))
+    return s[0], s[1]
+
+
+def bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd):
+    dx = torch.empty_like(x)
+    _call("gnnome_bn_bwd_apply_f32", x.device, _ptr(_dense(dy, "dy")), _ptr(_dense(x, "x")), _ptr(scale), _ptr(shift), x.shape[0],
+          x.shape[1], _ptr(a), _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(dx))
+    return dx
+
+
+def mul23(a, b, c):
+    o1, o2 = torch.empty_like(a), torch.empty_like(a)
+    _call("gnnome_mul23_f32", a.device, _ptr(_dense(a, "a")), _ptr(_dense(b, "b")), _ptr(_dense(c, "c")), a.numel(), _ptr(o1), _ptr(o2))
+    return o1, o2
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    _call("gnnome_add_f32", a.device, _ptr(_dense(a, "a")), _ptr(_dense(b, "b")), a.numel(), _ptr(out))
+    return out
+
+
+def relu_bwd(dy, y):
+    dx = torch.empty_like(dy)
+    _call("gnnome_relu_bwd_f32", dy.device, _ptr(_dense(dy, "dy")), _ptr(_dense(y, "y")), dy.numel(), _ptr(dx))
+    return dx
+
+
+def segment_sum(X, ptr, pos, num_nodes, out=None):
+    X = _dense(X, "segment_sum.X")
+    W = X.shape[1]
+    if out is None:
+        out = torch.empty((num_nodes, W), dtype=torch.float32, device=X.device)
+    out, ld = _rows(out, "segment_sum.out")
+    _call("gnnome_segment_sum_f32", X.device, _ptr(X), W, _ptr(ptr), _ptr(pos), num_nodes, _ptr(out), ld)
+    return out
+
+
+def wgrad(A, B, out=None):
+    """out[Ka,Kb] = A^T @ B over the rows (nn.Linear weight gradient dW = dY^T X)."""
+    A, lda = _rows(A, "wgrad.A")
+    B, ldb = _rows(B, "wgrad.B")
+    rows, Ka, Kb = A.shape[0], A.shape[1], B.shape[1]
+    if out is None:
+        out = torch.empty((Ka, Kb), dtype=torch.float32, device=A.device)
+    out, ldc = _rows(out, "wgrad.out")
+    need = ctypes.c_size_t(0)
+    _lib.check(_lib.load().gnnome_wgrad_workspace_bytes(rows, Ka, Kb, ctypes.byref(need)), "wgrad_workspace_bytes")
+    ws = torch.empty(max(int(need.value), 4), dtype=torch.uint8, device=A.device)
+    _call("gnnome_wgrad_f32", A.device, _ptr(A), lda, Ka, _ptr(B), ldb, Kb, rows, _ptr(out), ldc, _ptr(ws), ws.numel())
+    return out
+
+
+def score_tail_bwd(z1, dscore, views, W2, b2, W3):
+    E, hs = z1.shape
+    dz1 = torch.empty_like(z1)
+    dz2 = torch.empty((E, 32), dtype=torch.float32, device=z1.device)
+    u = torch.empty_like(dz2)
+    _call("gnnome_score_tail_bwd_f32", z1.device, _ptr(_dense(z1, "z1")), _ptr(_dense(dscore, "dscore")), _ptr(views.srt_eid), E, hs,
+          _ptr(W2), _ptr(b2), _ptr(W3), _ptr(dz1), _ptr(dz2), _ptr(u))
+    return dz1, dz2, u
+
+
+def agg_edge_bwd(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de):
+    A2h, ldn = _rows(A2h, "agg_edge_bwd.A2h")
+    A3h, _ = _rows(A3h, "agg_edge_bwd.A3h")
+    _call("gnnome_agg_edge_bwd_f32", e.device, _ptr(_dense(e, "e")), e.shape[0], e.shape[1], _ptr(Tf), _ptr(Uf), _ptr(Tb), _ptr(Ub),
+          _ptr(A2h), _ptr(A3h), ldn, _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(_dense(de, "de")))
+    return de
+
+
+def encode_hidden(x, W1, b1, gather=None, rows=None):
+    x = x.contiguous()
+    rows = int(x.shape[0] if rows is None else rows)
+    t = torch.empty((rows, W1.shape[0]), dtype=torch.float32, device=x.device)
+    _call("gnnome_encode_hidden_f32", x.device, _ptr(x), rows, x.shape[1], _ptr(gather), _ptr(W1), _ptr(b1), W1.shape[0], _ptr(t))
+    return t

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 1
+#define GNNOME_ABI_VERSION 2
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -130,7 +130,82 @@ int gnnome_edge_score_f32(const float* e, int64_t num_edges, int hidden, int hid
                           const float* Ps, const float* Qd, int ld_node, const int32_t* srt_src,
                           const int32_t* srt_dst, const int32_t* srt_eid, const float* W1e, int ldw1,
                           const float* W2, const float* b2, const float* W3, const float* b3, float* logits,
-                          void* stream);
+                          float* z1_out /* NULL, or [E,hs]: relu(z1) kept for the backward */, void* stream);
+
+/* ================================================================================================
+ * Training step (train.py:138-145 + :328-330: forward in train mode, BCE-with-logits, loss.backward()).
+ * The reference gets its backward from torch autograd over DGL's gspmm/gsddmm; here the layer backward is
+ * written out in gnnome_amd/train.py and built from the entries below.  All are stream-ordered.
+ * ================================================================================================ */
+
+/* x_out[p,:] = B1h[srt_src[p],:] + B2h[srt_dst[p],:] + e_in[p,:] * W3^T  - the input of bn_e
+ * (gated_gcn_full.py:104-106) materialised so that train-mode BatchNorm can take batch statistics. */
+int gnnome_edge_gate_raw_f32(const float* e_in, float* x_out, int64_t num_edges, int hidden, const float* B1h,
+                             const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
+                             const float* W3, int ldw, void* stream);
+
+/* Gated aggregation without the node epilogue.
+ *   mode 1: v_out = A1h + fwd + bwd (input of bn_h, gated_gcn_full.py:129); aux0 = fwd, aux1 = 1/(den_f+1e-6),
+ *           aux2 = bwd, aux3 = 1/(den_b+1e-6)   (kept for the backward)
+ *   mode 2: aux0[i] = sum_{in(i)} s_p * A2h[srt_src[p]], aux2[i] = sum_{out(i)} s_p * A3h[out_dst[q]] (raw sums:
+ *           with A2h := dv/(den_b+eps), A3h := dv/(den_f+eps) these are dA3h and dA2h) */
+int gnnome_node_aggregate_raw_f32(const float* e, int hidden, int64_t num_nodes, int mode, const float* A1h,
+                                  const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
+                                  const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
+                                  const int32_t* out_dst, float* v_out, float* aux0, float* aux1, float* aux2,
+                                  float* aux3, void* stream);
+
+/* s1[c] += sum_r x'[r,c];  s2[c] += sum_r x'[r,c]*y'[r,c]  with x' = x - center[c] (center NULL: 0) and y NULL -> x'
+ * (sum of squares).  s1/s2 must be zeroed by the caller.  hidden in {16,32,64,128,256}.  Two calls give train-mode
+ * BatchNorm its batch statistics (gated_gcn_full.py:106,119,132): the mean, then the centred second moment - the
+ * one-pass E[x^2]-E[x]^2 form cancels badly on this path (|e| ~ 500, spread of a few units).  Also bias gradients. */
+int gnnome_colsum2_f32(const float* x, const float* y, int64_t rows, int hidden, const float* center, float* s1,
+                       float* s2, void* stream);
+
+/* out = relu(x*scale[c] + shift[c]) + res : train-mode bn + relu + residual (gated_gcn_full.py:106-110, 132-137) */
+int gnnome_bn_relu_res_f32(const float* x, const float* scale, const float* shift, const float* res, int64_t rows,
+                           int hidden, float* out, void* stream);
+
+/* BatchNorm backward through the relu of out = relu(x*scale + shift) + res, m = (x*scale + shift > 0):
+ *   stats: s1[c] += sum_r dy*m,  s2[c] += sum_r dy*m*(x - mean[c])   (s1/s2 zeroed by the caller)
+ *   apply: dx = a[c] * (dy*m - c1[c] - (x - mean[c])*rstd[c]*c2[c]) */
+int gnnome_bn_bwd_stats_f32(const float* dy, const float* x, const float* scale, const float* shift,
+                            const float* mean, int64_t rows, int hidden, float* s1, float* s2, void* stream);
+int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const float* scale, const float* shift, int64_t rows,
+                            int hidden, const float* a, const float* c1, const float* c2, const float* mean,
+                            const float* rstd, float* dx, void* stream);
+
+/* o1 = a*b, o2 = a*b*c (count floats, count % 4 == 0);  out = a + b;  dx = dy*(y > 0) */
+int gnnome_mul23_f32(const float* a, const float* b, const float* c, int64_t count, float* o1, float* o2, void* stream);
+int gnnome_add_f32(const float* a, const float* b, int64_t count, float* out, void* stream);
+int gnnome_relu_bwd_f32(const float* dy, const float* y, int64_t count, float* dx, void* stream);
+
+/* out[i,:] = sum_{q in [ptr[i], ptr[i+1])} X[pos ? pos[q] : q, :]  width in {32,64,128,256}: the transposes of the
+ * per-edge gathers (dB2h, dQd with ptr = in_ptr; dB1h, dPs with ptr = out_ptr, pos = out_pos). */
+int gnnome_segment_sum_f32(const float* X, int width, const int32_t* ptr, const int32_t* pos, int64_t num_nodes,
+                           float* out, int ld_out, void* stream);
+
+/* C[Ka,Kb] = A[rows,Ka]^T * B[rows,Kb]: nn.Linear weight gradients, exact fp32 MFMA, chunked over rows with a
+ * deterministic second-stage sum.  Ka, Kb % 4 == 0; A, B 16-byte aligned. */
+int gnnome_wgrad_workspace_bytes(int64_t rows, int Ka, int Kb, size_t* bytes_host);
+int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C, int ldc,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the scorer tail (score_predictor.py:15-16) from the saved relu(z1) and d(score) (edge-id order,
+ * read through srt_eid): dz1[E,hs], dz2[E,32], u[E,32] = dscore*z2.  hs in {32,64}. */
+int gnnome_score_tail_bwd_f32(const float* z1, const float* dscore, const int32_t* srt_eid, int64_t num_edges,
+                              int hidden_edge_scores, const float* W2, const float* b2, const float* W3, float* dz1,
+                              float* dz2, float* u, void* stream);
+
+/* de[p,:] += s(1-s) * (Tf[dst]*A2h[src] - Uf[dst] + Tb[src]*A3h[dst] - Ub[src]),  s = sigmoid(e[p,:]):
+ * the gradient the two gated aggregations send back to the edge state (gated_gcn_full.py:111-114,124-127). */
+int gnnome_agg_edge_bwd_f32(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                            const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
+                            const int32_t* srt_src, const int32_t* srt_dst, float* de, void* stream);
+
+/* t[r,:] = relu(W1*in[row(r),:] + b1): an encoder's hidden layer, recomputed for its backward */
+int gnnome_encode_hidden_f32(const float* in, int64_t rows, int in_features, const int32_t* gather, const float* W1,
+                             const float* b1, int hidden_ne, float* t, void* stream);
 
 /* ---- row gather (halo packing for the destination-range partition) ------------------------------
  * out[r,:] = in[idx[r],:]   rows of `width` floats, width % 4 == 0
