@@ -84,7 +84,7 @@ class KernelTimer:
         return sum(s.elapsed_time(t) for s, t in ev) / max(len(ev), 1), len(ev)
 
 
-def cpu_baseline(hidden, kind, budget_s=30.0):
+def cpu_baseline(hidden, kind, budget_s=30.0, mode="infer"):
     """The oracle (torch-CPU restatement of the reference's CPU/DGL path) timed on this host's cores, on a
     bounded sample of the workload: same generator, same width, E = 100k.  The reference's CPU path is
     torch + DGL-OpenMP with the library default thread count; torch's intra-op pool is tried at 8, 32 and
@@ -92,31 +92,46 @@ def cpu_baseline(hidden, kind, budget_s=30.0):
     from gnnome_amd.synth import make_graph, random_state_dict
     from oracle.symgated_oracle import degree_features, model_from_state_dict
     cores = os.cpu_count() or 1
-    n, e = 10_000, 100_000
+    n, e = (10_000, 100_000) if mode == "infer" else (2_000, 20_000)
     g = make_graph(n, e, seed=1, kind=kind)
     x = degree_features(g["src"], g["dst"], n)
-    model = model_from_state_dict(random_state_dict(hidden, seed=1)).eval()
+    model = model_from_state_dict(random_state_dict(hidden, seed=1))
     graph = (g["src"], g["dst"], n)
+    if mode == "train":
+        from oracle.symgated_oracle import bce_loss
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+        def run():
+            loss = bce_loss(model(graph, x, g["e"]), g["y"], g["pos_weight"])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+    else:
+        model.eval()
+
+        def run():
+            with torch.no_grad():
+                model(graph, x, g["e"])
     best = None
     t_all = time.perf_counter()
-    for threads in sorted({min(8, cores), min(32, cores), cores}):
+    for threads in (sorted({min(8, cores), min(32, cores), cores}) if mode == "infer" else [min(8, cores)]):
         if best is not None and time.perf_counter() - t_all > budget_s:
             break
         torch.set_num_threads(threads)
-        with torch.no_grad():
-            model(graph, x, g["e"])  # warm-up
-            times = []
-            for _ in range(2):
-                t0 = time.perf_counter()
-                model(graph, x, g["e"])
-                times.append(time.perf_counter() - t0)
+        run()  # warm-up
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            run()
+            times.append(time.perf_counter() - t0)
         if best is None or min(times) < best[0]:
             best = (min(times), threads)
     return {
         "value": e / best[0], "unit": "edges/s", "cores": best[1], "kind": "port",
-        "sample": f"{kind} synthetic graph N={n} E={e} H={hidden} L=8 fp32 through oracle/symgated_oracle.py (torch-CPU "
+        "sample": f"{mode}: {kind} synthetic graph N={n} E={e} H={hidden} L=8 fp32 through oracle/symgated_oracle.py (torch-CPU "
                   f"restatement of the reference path; DGL 0.8.1 is not installable offline); 1 warm-up + best of 2 per "
-                  f"thread setting, best of 8/32/{cores} threads on a {cores}-core host",
+                  f"thread setting, best of " + ("8/32/" + str(cores) if mode == "infer" else "8") + f" threads on a {cores}-core host",
     }
 
 
@@ -127,9 +142,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default="banded", choices=["banded", "uniform"])
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer: one forward (BASELINE configs[1]); train: fwd + BCE + bwd + Adam step (configs[2], fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:  # child process of the cpu_baseline leg: no GPU work, bounded by the parent's timeout
+        print(json.dumps(cpu_baseline(WORKLOADS[args.workload][2], args.kind, mode=args.mode)))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -157,6 +178,8 @@ def main():
     model.load_state_dict(random_state_dict(hidden, seed=1))
     model.to(dev)
 
+    if args.mode == "train" and world > 1:
+        raise SystemExit("the training step is single-GPU in this build (gradient / BatchNorm all-reduce not built yet)")
     if world == 1:
         src, dst = g["src"].to(dev), g["dst"].to(dev)
         x, ef = x_cpu.to(dev), g["e"].to(dev)
@@ -167,8 +190,23 @@ def main():
         torch.cuda.synchronize()
         cold_ms = (time.perf_counter() - t0) * 1e3
 
-        def step():
-            return model(views, x, ef)
+        if args.mode == "train":
+            # train.py:138-145 (get_bce_loss_full) + :328-330, dropout 0 as in the parity fixtures
+            import torch.nn.functional as F
+            model.train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+            y, pw = g["y"].to(dev), g["pos_weight"].to(dev)
+
+            def step():
+                logits = model(views, x, ef)
+                loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), y, pos_weight=pw)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                return logits.detach()
+        else:
+            def step():
+                return model(views, x, ef)
 
         def barrier():
             torch.cuda.synchronize()
@@ -191,7 +229,7 @@ def main():
     # HIP events in the timed region go around ONE launch of the dominant kernel per step (the 8 layers launch
     # the same shape): a pair around every launch of every kernel cost ~1.6 ms per step here (56 events, ~28 us
     # of pipeline bubble each) and inflated what it measured; a pair per gate launch still cost ~0.4 ms.
-    dominant = [] if args.no_kernel_timers or world > 1 else ["edge_gate"]
+    dominant = [] if args.no_kernel_timers or world > 1 else (["edge_gate"] if args.mode == "infer" else ["edge_gate_raw"])
     with KernelTimer(ops, dominant, every=8) as kt:
         for _ in range(args.warmup):
             step()
@@ -205,7 +243,7 @@ def main():
         elapsed = time.perf_counter() - t0
         kt.on = False
     # untimed diagnostic pass: every kernel family instrumented, for the per-kernel table only
-    others = [] if args.no_kernel_timers or world > 1 else ["node_aggregate", "linear", "edge_score", "encode"]
+    others = [] if args.no_kernel_timers or world > 1 or args.mode == "train" else ["node_aggregate", "linear", "edge_score", "encode"]
     with KernelTimer(ops, others) as kd:
         kd.on = True
         for _ in range(min(args.steps, 5)):
@@ -223,27 +261,35 @@ def main():
         ms = elapsed / args.steps * 1e3
         b_fwd, f_fwd = algorithmic_bytes(n, e, hidden), algorithmic_flops(n, e, hidden)
         res = {
-            "metric": "edges/sec full-graph GatedGCN fwd", "value": e / (ms * 1e-3), "unit": "edges/s", "n_gpus": world,
+            "metric": "edges/sec full-graph GatedGCN fwd" + (" + bwd (BCE training step)" if args.mode == "train" else ""),
+            "value": e / (ms * 1e-3), "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {args.kind} synthetic assembly graph N={n} E={e}, SymGatedGCNModel hidden={hidden} "
-                                   f"L=8 hs=64 BatchNorm(eval), fwd only, random-init weights seed 1", "parallelism": parallelism},
+                                   f"L=8 hs=64, " + ("BatchNorm(eval), fwd only" if args.mode == "infer" else
+                                     "train mode: fwd (batch-stat BN) + BCEWithLogits(pos_weight) + bwd + Adam step, fp32, dropout 0")
+                                   + ", random-init weights seed 1", "parallelism": parallelism},
             "hbm_roofline_frac_whole_fwd": (b_fwd / (ms * 1e-3)) / (world * HBM_PEAK),
             "mfma_f32_frac_whole_fwd": (f_fwd / (ms * 1e-3)) / (world * MFMA_F32_PEAK),
             "algorithmic_bytes_fwd": b_fwd, "algorithmic_flops_fwd": f_fwd, "cold_ms_incl_graph_views": cold_ms,
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
         }
+        if args.mode == "train":
+            res["hbm_roofline_frac_whole_step_3xBfwd"] = (3 * b_fwd / (ms * 1e-3)) / (world * HBM_PEAK)
+            res["mfma_f32_frac_whole_step_3xFfwd"] = (3 * f_fwd / (ms * 1e-3)) / (world * MFMA_F32_PEAK)
         if timed:
-            gate_ms, gate_n = kt.mean_ms("edge_gate")
+            gate_ms, gate_n = kt.mean_ms(timed[0])
             gate_flops = 2.0 * e * hidden * hidden
             res["roofline"] = {
-                "kernel": "k_edge_gate (fused B_3 GEMM + u_add_v + bn_e + relu + residual)", "bound": "mfma",
+                "kernel": "k_edge_gate_ws (fused B_3 GEMM + u_add_v + bn_e + relu + residual)" if args.mode == "infer" else
+                          "k_edge_gate<raw> (B_3 GEMM + u_add_v, pre-BatchNorm output)", "bound": "mfma",
                 "achieved": gate_flops / (gate_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": gate_flops / (gate_ms * 1e-3) / MFMA_F32_PEAK, "traffic": None,
                 "avg_launch_ms": gate_ms, "launches": gate_n, "flops_per_launch": gate_flops,
                 "algorithmic_bytes_per_launch": 2.0 * e * hidden * 4 + 2 * e * 4,
                 "hbm_frac": (2.0 * e * hidden * 4 + 2 * e * 4) / (gate_ms * 1e-3) / HBM_PEAK,
             }
+        if timed and others:
             agg_ms, agg_n = kd.mean_ms("node_aggregate")
             agg_bytes = 2.0 * e * hidden * 4 + 3 * e * 4 + 3 * n * hidden * 4
             lin_ms, lin_n = kd.mean_ms("linear")
@@ -261,8 +307,16 @@ def main():
                 {"kernel": "k_encode (node + edge)", "bound": "hbm", "avg_launch_ms": en_ms, "launches": en_n},
             ]
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(hidden, args.kind)
-            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+            # in a child process (own thread pool, hard time limit): the baseline must never stall the bench line
+            import subprocess
+            try:
+                out_cpu = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
+                                          "--kind", args.kind, "--mode", args.mode], capture_output=True, text=True, timeout=150)
+                res["cpu_baseline"] = json.loads([ln for ln in out_cpu.stdout.splitlines() if ln.startswith("{")][-1])
+                res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+            except Exception as ex:  # noqa: BLE001
+                res["cpu_baseline"] = None
+                res["cpu_baseline_error"] = f"{type(ex).__name__}: did not finish in 150 s"
         print(json.dumps(res))
 
     if world > 1:

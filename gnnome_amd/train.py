@@ -161,7 +161,6 @@ class _TrainStep(torch.autograd.Function):
             # e' = relu(bn_e(xe)) + e_in ;  xe = B1h[src] + B2h[dst] + e_in W3^T
             dxe, g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"], E)
             g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"])
-            g[pfx + "B_3.bias"] = ops.colsum2(dxe)[0]
             de = ops.add(de, ops.linear(dxe, d(conv.B_3.weight).t().contiguous(), None))
             dB1 = ops.segment_sum(dxe, views.out_ptr, views.out_pos, N)
             dB2 = ops.segment_sum(dxe, views.in_ptr, None, N)
@@ -169,6 +168,8 @@ class _TrainStep(torch.autograd.Function):
             parts[r["A1"]], parts[r["A2"]], parts[r["A3"]], parts[r["B1"]], parts[r["B2"]] = dv, sum_out, sum_in, dB1, dB2
             for k, name in enumerate(("A_1", "A_2", "A_3", "B_1", "B_2")):
                 g[pfx + name + ".bias"] = ops.colsum2(parts[k])[0]
+            # every edge has exactly one destination: sum_p dxe[p] = sum_i dB2[i], no second pass over [E,H]
+            g[pfx + "B_3.bias"] = g[pfx + ("B_1" if views.transposed else "B_2") + ".bias"].clone()
             dP = torch.cat(parts, 1)
             gWcat = ops.wgrad(dP, s["h"])                                     # [5H, H]
             for k, name in enumerate(("A_1", "A_2", "A_3", "B_1", "B_2")):
