@@ -84,6 +84,17 @@ class KernelTimer:
         return sum(s.elapsed_time(t) for s, t in ev) / max(len(ev), 1), len(ev)
 
 
+def _pmc_traffic(args, hidden, e):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
+    read from inside this process; profiles/r01_gate_pmc.json holds the rocprofv3 passes and the gfx950 corrections).
+    Only reported for the exact kernel/shape that was profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_gate_pmc.json")
+    if args.mode != "infer" or args.workload != "c2" or hidden != 128 or e != 1_000_000 or not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["hbm_bytes_per_launch"]
+
+
 def cpu_baseline(hidden, kind, budget_s=30.0, mode="infer"):
     """The oracle (torch-CPU restatement of the reference's CPU/DGL path) timed on this host's cores, on a
     bounded sample of the workload: same generator, same width, E = 100k.  The reference's CPU path is
@@ -284,7 +295,7 @@ def main():
                 "kernel": "k_edge_gate_ws (fused B_3 GEMM + u_add_v + bn_e + relu + residual)" if args.mode == "infer" else
                           "k_edge_gate<raw> (B_3 GEMM + u_add_v, pre-BatchNorm output)", "bound": "mfma",
                 "achieved": gate_flops / (gate_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": gate_flops / (gate_ms * 1e-3) / MFMA_F32_PEAK, "traffic": None,
+                "frac": gate_flops / (gate_ms * 1e-3) / MFMA_F32_PEAK, "traffic": _pmc_traffic(args, hidden, e),
                 "avg_launch_ms": gate_ms, "launches": gate_n, "flops_per_launch": gate_flops,
                 "algorithmic_bytes_per_launch": 2.0 * e * hidden * 4 + 2 * e * 4,
                 "hbm_frac": (2.0 * e * hidden * 4 + 2 * e * 4) / (gate_ms * 1e-3) / HBM_PEAK,
