@@ -240,6 +240,16 @@ def test_goldens_shipped_weights(shipped_weights):
     assert torch.equal(g["x"], x0) and torch.equal(g["e"], e0)  # inputs untouched
 
 
+def test_against_the_fp64_c_oracle(shipped_weights):
+    """The HIP path against the double-precision C restatement: the 1e-4 bar measured from the truth, not from
+    another fp32 evaluation (the reference's own fp32 output is 4.9e-5 from it on this graph)."""
+    from oracle import c_oracle
+    g = load_golden("g2_uniform_1k.pt")
+    truth = c_oracle.forward(shipped_weights, g["src"], g["dst"], g["num_nodes"], g["x"], g["e"], precision="f64")
+    out = _model(shipped_weights, 64)((g["src"], g["dst"], g["num_nodes"]), g["x"].to(dev()), g["e"].to(dev()))
+    assert _prob_diff(out, truth) < PROB_TOL
+
+
 def test_goldens_wider_hidden_and_layernorm():
     for hidden in (128, 256):
         g = load_golden(f"g5_eval_h{hidden}.pt")
