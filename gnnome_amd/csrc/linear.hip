@@ -10,7 +10,8 @@ template <int NB>
 __global__ __launch_bounds__(kGemmThreads) void k_linear(const float* __restrict__ A, int64_t M, int K, int lda,
                                                          const float* __restrict__ W, int ldw,
                                                          const float* __restrict__ bias, int Nout,
-                                                         float* __restrict__ C, int ldc, int n_tiles, int total_tiles) {
+                                                         float* __restrict__ C, int ldc, int n_tiles, int total_tiles,
+                                                         int accumulate) {
     __shared__ __attribute__((aligned(16))) float lds[(kTileM + 32 * NB) * kLdk];
     float* As = lds;
     float* Ws = lds + kTileM * kLdk;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_linear(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = row0 + 32 * wave + cd_row(r, lane);
-                if (row < M) C[row * ldc + col] = acc[nb][r];
+                if (row < M) C[row * ldc + col] = accumulate ? C[row * ldc + col] + acc[nb][r] : acc[nb][r];
             }
         }
     }
@@ -62,7 +63,7 @@ template <int K, int CB, int RB>
 __global__ __launch_bounds__(64 * CB * RB) void k_linear_ws(const float* __restrict__ A, int64_t M, int lda,
                                                             const float* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, float* __restrict__ C, int ldc,
-                                                            int num_tiles, int tiles_per_group, int groups) {
+                                                            int num_tiles, int tiles_per_group, int groups, int accumulate) {
     using P = LinWS<K, CB, RB>;
     constexpr int TM = P::TM, NC = P::NC, NT = P::NT, LDK = P::LDK, LDY = P::LDY, NA = P::kAPieces, NY = P::kYPieces;
     __shared__ __attribute__((aligned(16))) float lds[P::kLdsFloats];
@@ -138,8 +139,12 @@ __global__ __launch_bounds__(64 * CB * RB) void k_linear_ws(const float* __restr
 #pragma unroll
             for (int it = 0; it < NY; ++it) {
                 const int f = tid + NT * it, row = f / (NC / 4), c4 = f % (NC / 4);
-                const f32x4 y = *reinterpret_cast<const f32x4*>(Ys + row * LDY + 4 * c4);
-                if (row < valid) *reinterpret_cast<f32x4*>(out + (int64_t)row * ldc + 4 * c4) = y;
+                f32x4 y = *reinterpret_cast<const f32x4*>(Ys + row * LDY + 4 * c4);
+                if (row < valid) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(out + (int64_t)row * ldc + 4 * c4);
+                    if (accumulate) y += *dst;
+                    *dst = y;
+                }
             }
         }
         if (t + 1 < t_end) {
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(64 * CB * RB) void k_linear_ws(const float* __restr
 
 template <int K, int CB, int RB>
 static int launch_linear_ws(const float* A, int64_t M, int lda, const float* W, int ldw, const float* bias, int Nout,
-                            float* C, int ldc, hipStream_t s) {
+                            float* C, int ldc, hipStream_t s, int accumulate) {
     using P = LinWS<K, CB, RB>;
     const int n_chunks = Nout / P::NC;
     const int64_t tiles = (M + P::TM - 1) / P::TM;
@@ -164,28 +169,28 @@ static int launch_linear_ws(const float* A, int64_t M, int lda, const float* W, 
     if (groups < 1) groups = 1;
     const int tpg = (int)((tiles + groups - 1) / groups);
     hipLaunchKernelGGL((k_linear_ws<K, CB, RB>), dim3(groups, n_chunks), dim3(P::NT), 0, s, A, M, lda, W, ldw, bias, C, ldc,
-                       (int)tiles, tpg, groups);
+                       (int)tiles, tpg, groups, accumulate);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
 
 template <int NB>
 static int launch_linear(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias, int Nout,
-                         float* C, int ldc, hipStream_t s) {
+                         float* C, int ldc, hipStream_t s, int accumulate) {
     const int n_tiles = (Nout + 32 * NB - 1) / (32 * NB);
     const int64_t m_tiles = (M + kTileM - 1) / kTileM;
     const int64_t total = m_tiles * n_tiles;
     GN_REQUIRE(total < (1ll << 31), "linear: too many tiles");
     hipLaunchKernelGGL(k_linear<NB>, dim3((unsigned)total), dim3(kGemmThreads), 0, s, A, M, K, lda, W, ldw, bias, Nout, C,
-                       ldc, n_tiles, (int)total);
+                       ldc, n_tiles, (int)total, accumulate);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
 
 }  // namespace gnnome
 
-extern "C" int gnnome_linear_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias,
-                                 int Nout, float* C, int ldc, void* stream) {
+static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias, int Nout,
+                       float* C, int ldc, void* stream, int accumulate) {
     using namespace gnnome;
     GN_REQUIRE(M >= 0 && Nout > 0, "linear: bad shape M=%lld Nout=%d", (long long)M, Nout);
     if (M == 0) return GNNOME_OK;
@@ -196,10 +201,21 @@ extern "C" int gnnome_linear_f32(const float* A, int64_t M, int K, int lda, cons
     hipStream_t s = (hipStream_t)stream;
     const bool aligned_out = ((uintptr_t)C % 16 == 0) && ldc % 4 == 0;
     if (tuning(kTuneLinearVariant) != 1 && aligned_out) {
-        if (K == 128 && Nout % 128 == 0) return launch_linear_ws<128, 4, 2>(A, M, lda, W, ldw, bias, Nout, C, ldc, s);
-        if (K == 64 && Nout % 64 == 0) return launch_linear_ws<64, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s);
+        if (K == 128 && Nout % 128 == 0) return launch_linear_ws<128, 4, 2>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+        if (K == 64 && Nout % 64 == 0) return launch_linear_ws<64, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
     }
-    if (Nout > 64) return launch_linear<4>(A, M, K, lda, W, ldw, bias, Nout, C, ldc, s);
-    if (Nout > 32) return launch_linear<2>(A, M, K, lda, W, ldw, bias, Nout, C, ldc, s);
-    return launch_linear<1>(A, M, K, lda, W, ldw, bias, Nout, C, ldc, s);
+    if (Nout > 64) return launch_linear<4>(A, M, K, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+    if (Nout > 32) return launch_linear<2>(A, M, K, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+    return launch_linear<1>(A, M, K, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+}
+
+extern "C" int gnnome_linear_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias,
+                                 int Nout, float* C, int ldc, void* stream) {
+    return linear_impl(A, M, K, lda, W, ldw, bias, Nout, C, ldc, stream, 0);
+}
+
+// C += A * W^T + bias  (residual form, used by the backward: d e_in = d e' + dxe * W3, dh = dh_in + dP * Wcat)
+extern "C" int gnnome_linear_acc_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias,
+                                     int Nout, float* C, int ldc, void* stream) {
+    return linear_impl(A, M, K, lda, W, ldw, bias, Nout, C, ldc, stream, 1);
 }

@@ -98,8 +98,8 @@ def encode(x, W1, b1, W2, b2, gather=None, rows=None):
     return out
 
 
-def linear(A, W, bias, out=None):
-    """out[M,Nout] = A @ W.T + bias on the fp32 matrix cores.  A, W, out may be row-strided views."""
+def linear(A, W, bias, out=None, accumulate=False):
+    """out[M,Nout] = A @ W.T + bias on the fp32 matrix cores (accumulate: out += ...).  A, W, out may be row-strided."""
     lib = _lib.load()
     A, lda = _rows(A, "linear.A")
     W, ldw = _rows(W, "linear.W")
@@ -109,8 +109,8 @@ def linear(A, W, bias, out=None):
         out = torch.empty((M, Nout), dtype=torch.float32, device=A.device)
     out, ldc = _rows(out, "linear.out")
     with torch.cuda.device(A.device):
-        _lib.check(lib.gnnome_linear_f32(_ptr(A), M, K, lda, _ptr(W), ldw, _ptr(bias), Nout, _ptr(out), ldc,
-                                         _stream(A.device)), "linear_f32")
+        fn = lib.gnnome_linear_acc_f32 if accumulate else lib.gnnome_linear_f32
+        _lib.check(fn(_ptr(A), M, K, lda, _ptr(W), ldw, _ptr(bias), Nout, _ptr(out), ldc, _stream(A.device)), "linear_f32")
     return out
 
 
@@ -237,11 +237,14 @@ def colsum2(x, y=None, center=None):
 
 
 def batch_stats(x):
-    """Per-column (mean, biased variance) of x[rows, H] by the two-pass formula."""
+    """Per-column (mean, biased variance) of x[rows, H] in ONE pass over x, shifted by its first row:
+    var = E[(x-c)^2] - E[x-c]^2 with c = x[0] is as accurate as the two-pass formula whenever c lies within a few
+    standard deviations of the mean (it is a sample), unlike the unshifted E[x^2] - E[x]^2."""
     rows = x.shape[0]
-    mean = (colsum2(x)[0] / rows).contiguous()
-    d1, d2 = colsum2(x, center=mean)
-    return mean, (d2 / rows - (d1 / rows) ** 2).clamp_min_(0.0)
+    c = x[0].contiguous()
+    d1, d2 = colsum2(x, center=c)
+    m1 = d1 / rows
+    return (c + m1).contiguous(), (d2 / rows - m1 * m1).clamp_min_(0.0)
 
 
 def bn_relu_res(x, scale, shift, res):

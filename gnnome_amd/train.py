@@ -161,7 +161,7 @@ class _TrainStep(torch.autograd.Function):
             # e' = relu(bn_e(xe)) + e_in ;  xe = B1h[src] + B2h[dst] + e_in W3^T
             dxe, g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"], E)
             g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"])
-            de = ops.add(de, ops.linear(dxe, d(conv.B_3.weight).t().contiguous(), None))
+            ops.linear(dxe, d(conv.B_3.weight).t().contiguous(), None, out=de, accumulate=True)   # d e_in = d e' + dxe W3
             dB1 = ops.segment_sum(dxe, views.out_ptr, views.out_pos, N)
             dB2 = ops.segment_sum(dxe, views.in_ptr, None, N)
             parts = [None] * 5
@@ -174,7 +174,7 @@ class _TrainStep(torch.autograd.Function):
             gWcat = ops.wgrad(dP, s["h"])                                     # [5H, H]
             for k, name in enumerate(("A_1", "A_2", "A_3", "B_1", "B_2")):
                 g[pfx + name + ".weight"] = gWcat[k * H:(k + 1) * H]
-            dh = ops.add(dh_in, ops.linear(dP, s["Wcat"].t().contiguous(), None))
+            dh = ops.linear(dP, s["Wcat"].t().contiguous(), None, out=dh_in, accumulate=True)
 
         # ---- encoders (models/full_graph.py:26-27)
         def encoder_bwd(dout, inp, gather, rows, l1, l2, pfx1, pfx2):

@@ -90,6 +90,9 @@ int gnnome_encode_f32(const float* in, int64_t rows, int in_features, const int3
  */
 int gnnome_linear_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias,
                       int Nout, float* C, int ldc, void* stream);
+/* C += A*W^T + bias: the residual form the backward uses (d e_in = d e' + dxe*W3; dh = dh_in + dP*Wcat). */
+int gnnome_linear_acc_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias,
+                          int Nout, float* C, int ldc, void* stream);
 
 /* ---- fused edge gate ----------------------------------------------------------------------------
  * For every sorted position p:

@@ -98,6 +98,9 @@ def test_linear(m, k, nout):
     A2[torch.arange(m), torch.arange(m) % k] = 1.0
     got2 = ops.linear(A2.to(dev()), W.to(dev()), None)
     assert torch.equal(got2.cpu(), W.t()[torch.arange(m) % k])
+    base = torch.randn(m, nout, generator=g)
+    acc = ops.linear(A.to(dev()), W.to(dev()), b.to(dev()), out=base.to(dev()).clone(), accumulate=True)
+    _assert_close(acc, want + base.double(), scale=float(k) ** 0.5 * 4)
     try:  # the one-tile-per-workgroup variant behind the same entry point
         ops.set_tuning(2, 1)
         _assert_close(ops.linear(A.to(dev()), W.to(dev()), b.to(dev())), want, scale=float(k) ** 0.5 * 4)
