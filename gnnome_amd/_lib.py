@@ -25,6 +25,7 @@ SIGNATURES = {
     "gnnome_linear_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "gnnome_linear_acc_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "gnnome_edge_gate_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p],
+    "gnnome_edge_gate_encode_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
     "gnnome_node_aggregate_f32": [_p, _i, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
     "gnnome_edge_score_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_edge_gate_raw_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p],

@@ -680,16 +680,31 @@ __device__ __forceinline__ void gate_ws_sweep(f32x16& acc, const float* ap, cons
     }
 }
 
-template <int CB, int RB, int ABL>
+// ENC (layer 0 only): the e tile is not loaded but COMPUTED by the load waves from the raw edge features,
+// e0[p,:] = W2e * relu(W1e * e_raw[srt_eid[p],:] + b1e) + b2e (models/full_graph.py:27, in_features = 2,
+// hidden_ne = 16): the edge encoder's [E,H] output is never written to or read from HBM.
+struct GateEnc {
+    const float* e_raw;       // [E,2] in edge-id order
+    const int32_t* srt_eid;   // sorted position -> edge id
+    const float *W1, *b1, *W2, *b2;   // [16,2] [16] [H,16] [H]
+};
+
+template <int CB, int RB, int ABL, bool ENC>
 __global__ __launch_bounds__(768) void k_edge_gate_ws(
     const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
     const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
-    const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block, int interleave) {
+    const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block, int interleave,
+    GateEnc enc) {
     using P = GateWS<CB, RB>;
     constexpr int H = P::H, TM = P::TM, LDK = P::LDK, QS = H / 8, EPQ = 16 / QS, NP = P::NP, SLOT = P::kSlotFloats;
-    __shared__ __attribute__((aligned(16))) float lds[P::kLdsFloats];
+    constexpr int kEncFloats = ENC ? 16 * H + H + 48 : 0;  // W2^T [16][H], b2 [H], W1 [32], b1 [16]
+    __shared__ __attribute__((aligned(16))) float lds[P::kLdsFloats + kEncFloats];
     float* Aring = lds;                       // [RING][TM][LDK]  e tiles
     float* Gring = lds + P::RING * SLOT;      // [RING][TM][LDK]  B1h[src] + B2h[dst]
+    float* w2t = lds + P::kLdsFloats;         // ENC only
+    float* b2s = w2t + 16 * H;
+    float* w1s = b2s + H;
+    float* b1s = w1s + 32;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -709,6 +724,13 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
     if (n <= 0) return;
     auto tile_of = [&](int r) { return first + r * stride; };
     auto tile_valid = [&](int r) { return (int)min((int64_t)TM, E - (int64_t)tile_of(r) * TM); };
+    if (ENC) {  // encoder weights -> LDS, by the whole workgroup, before the roles split
+        for (int i = tid; i < 16 * H; i += P::NT) w2t[i] = enc.W2[(i % H) * 16 + (i / H)];
+        for (int i = tid; i < H; i += P::NT) b2s[i] = enc.b2[i];
+        if (tid < 32) w1s[tid] = enc.W1[tid];
+        if (tid < 16) b1s[tid] = enc.b1[tid];
+        __syncthreads();
+    }
 
     if (wave < 4) {
         // ------------------------------------------------------------------ compute wave
@@ -772,6 +794,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
         constexpr int RSTEP = 64 * P::LWAVES / (H / 4);
         const int r0 = gl / (H / 4), c4 = gl % (H / 4);
         f32x4 a[NP], g1[NP], g2[NP];
+        float raw0[NP], raw1[NP];  // ENC: the two raw edge features of each of this lane's rows
         if (ABL & 5) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) a[p] = g1[p] = g2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -779,17 +802,21 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
         auto issue = [&](int r) {  // start fetching relative tile r
             const int64_t row0 = (int64_t)tile_of(r) * TM;
             const int valid = tile_valid(r);
-            int si[NP], di[NP];
+            int si[NP], di[NP], ei[NP];
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
                 si[p] = srt_src[row];
                 di[p] = srt_dst[row];
+                if (ENC) ei[p] = enc.srt_eid[row];
             }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
-                if (!(ABL & 4)) {
+                if (ENC) {
+                    raw0[p] = enc.e_raw[2 * (int64_t)ei[p]];
+                    raw1[p] = enc.e_raw[2 * (int64_t)ei[p] + 1];
+                } else if (!(ABL & 4)) {
                     const f32x4* src = reinterpret_cast<const f32x4*>(e_in + row * H + 4 * c4);
                     a[p] = (ABL & 16) ? __builtin_nontemporal_load(src) : *src;  // 16: streamed once, keep it out of L1
                 }
@@ -799,14 +826,32 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
                 }
             }
         };
-        if (group < n) issue(group);
+        // ENC: turn the raw features of the pending tile into its encoded e rows.  Done in an iteration in which this
+        // group has nothing else to do (two iterations before its hand-over), so that no iteration carries both a
+        // hand-over and ~900 VALU operations per lane on the barrier's critical path.
+        auto encode_pending = [&]() {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) a[p] = *reinterpret_cast<const f32x4*>(b2s + 4 * c4);
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w2t + j * H + 4 * c4);
+                const float wa = w1s[2 * j], wb = w1s[2 * j + 1], bj = b1s[j];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) a[p] += fmaxf(fmaf(wb, raw1[p], fmaf(wa, raw0[p], bj)), 0.f) * w;
+            }
+        };
+        if (group < n) {
+            issue(group);
+            if (ENC) encode_pending();
+        }
         for (int i = -1; i < n; ++i) {
+            if (ENC && i + 3 >= 4 && i + 3 < n && ((i + 3) & 3) == group) encode_pending();   // tile i+3, handed over at i+2
             const int r = i + 1;  // tile to hand over this iteration
             if (r < n && (r & 3) == group) {
                 float* As = Aring + (r & 3) * SLOT;
                 float* Gs = Gring + (r & 3) * SLOT;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
+                for (int p = 0; p < NP; ++p) {   // (ENC: a[] was encoded two iterations ago, see below)
                     *reinterpret_cast<f32x4*>(As + (r0 + p * RSTEP) * LDK + 4 * c4) = a[p];
                     *reinterpret_cast<f32x4*>(Gs + (r0 + p * RSTEP) * LDK + 4 * c4) = g1[p] + g2[p];
                 }
@@ -820,23 +865,30 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
 template <int CB, int RB>
 static int launch_gate_ws(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
                           const int32_t* ss, const int32_t* sd, const float* W3, int ldw, const float* scale,
-                          const float* shift, hipStream_t s) {
+                          const float* shift, hipStream_t s, const GateEnc* enc = nullptr) {
     using P = GateWS<CB, RB>;
     const int64_t tiles = (E + P::TM - 1) / P::TM;
     GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
     const int tpb = (int)((tiles + kNumCUs - 1) / kNumCUs);  // one resident workgroup per CU (LDS-limited)
     const int interleave = tuning(kTuneGateTileOrder) == 1 ? 0 : 1;
     const int grid = interleave ? kNumCUs : (int)((tiles + tpb - 1) / tpb);
+    if (enc != nullptr) {
+        hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, true>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd,
+                           W3, ldw, scale, shift, (int)tiles, tpb, interleave, *enc);
+        GN_LAUNCH_CHECK();
+        return GNNOME_OK;
+    }
+    const GateEnc none = {};
 #define GN_WS_ABL(M)                                                                                                        \
     case M:                                                                                                                 \
-        hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, M>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd, \
-                           W3, ldw, scale, shift, (int)tiles, tpb, interleave);                                            \
+        hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, M, false>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, \
+                           ss, sd, W3, ldw, scale, shift, (int)tiles, tpb, interleave, none);                              \
         break;
     switch (tuning(kTuneGateAblation)) {
         GN_WS_ABL(1) GN_WS_ABL(2) GN_WS_ABL(4) GN_WS_ABL(8) GN_WS_ABL(7) GN_WS_ABL(15) GN_WS_ABL(16)
         default:
-            hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss,
-                               sd, W3, ldw, scale, shift, (int)tiles, tpb, interleave);
+            hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, false>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn,
+                               ss, sd, W3, ldw, scale, shift, (int)tiles, tpb, interleave, none);
     }
 #undef GN_WS_ABL
     GN_LAUNCH_CHECK();
@@ -952,4 +1004,24 @@ extern "C" int gnnome_edge_gate_raw_f32(const float* e_in, float* x_out, int64_t
         case 256: return launch_gate<8>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, 2, nullptr, nullptr, s);
         default: set_error("edge_gate_raw: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
+}
+
+extern "C" int gnnome_edge_gate_encode_f32(const float* e_raw, const int32_t* srt_eid, const float* encW1, const float* encb1,
+                                           const float* encW2, const float* encb2, float* e_out, int64_t num_edges, int hidden,
+                                           const float* B1h, const float* B2h, int ld_node, const int32_t* srt_src,
+                                           const int32_t* srt_dst, const float* W3, int ldw, const float* norm_scale,
+                                           const float* norm_shift, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(num_edges >= 0, "edge_gate_encode: negative edge count");
+    if (num_edges == 0) return GNNOME_OK;
+    GN_REQUIRE(e_raw && srt_eid && encW1 && encb1 && encW2 && encb2 && e_out && B1h && B2h && srt_src && srt_dst && W3 &&
+                   norm_scale && norm_shift, "edge_gate_encode: null pointer");
+    GN_REQUIRE(hidden == 64 || hidden == 128, "edge_gate_encode: hidden=%d not in {64,128}", hidden);
+    GN_REQUIRE(ld_node % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0) && ((uintptr_t)W3 % 16 == 0),
+               "edge_gate_encode: alignment");
+    const GateEnc enc = {e_raw, srt_eid, encW1, encb1, encW2, encb2};
+    hipStream_t s = (hipStream_t)stream;
+    if (hidden == 128)
+        return launch_gate_ws<4, 1>(nullptr, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s, &enc);
+    return launch_gate_ws<2, 2>(nullptr, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s, &enc);
 }

@@ -157,13 +157,16 @@ def run_partitioned(ops, prep, part, x_local, e_local, group=None, reduce_result
     xchg = HaloExchange(part, ops, group)
     H = prep.hidden
     h = ops.encode(x_local, *prep.enc_node)  # halo rows of layer 0 come straight from the input features
-    e = ops.encode(e_local, *prep.enc_edge, gather=views.srt_eid, rows=views.num_edges)
+    e = engine.encode_edges(ops, prep, views, e_local)   # None: layer 0's gate encodes the edge tile itself
     for li, lw in enumerate(prep.layers):
         if li > 0:
             xchg.start(h)
         P = _project(ops, lw, h, n_own, xchg)
         A1, A2, A3, B1, B2 = (P[:, i * H:(i + 1) * H] for i in range(5))
-        ops.edge_gate(e, B1, B2, views, lw.W3, lw.norm, lw.scale_e, lw.shift_e)
+        if e is None:
+            e = ops.edge_gate_encode(e_local, prep.enc_edge, B1, B2, views, lw.W3, lw.scale_e, lw.shift_e)
+        else:
+            ops.edge_gate(e, B1, B2, views, lw.W3, lw.norm, lw.scale_e, lw.shift_e)
         h = ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_own)
     xchg.start(h)
     pw = prep.predictor

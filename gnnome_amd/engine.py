@@ -132,15 +132,27 @@ def _refuse_training(module):
 # kernel sequences (ops = gnnome_amd.ops in the product)
 # ---------------------------------------------------------------------------------------------------
 
-def layer_step(ops, lw, views, h, e, n_out=None):
-    """One SymGatedGCN layer on sorted-order e (updated in place); returns the new h."""
+def layer_step(ops, lw, views, h, e, n_out=None, raw_edges=None):
+    """One SymGatedGCN layer on sorted-order e (updated in place); returns (new h, e).  With e = None and
+    raw_edges = (e_raw, encoder weights) the edge encoder is folded into the gate (layer 0)."""
     H = h.shape[1]
     P = ops.linear(h, lw.Wcat, lw.bcat)
     A1, A2, A3, B1, B2 = (P[:, i * H:(i + 1) * H] for i in range(5))
     if views.transposed:  # dgl.reverse(g): src <-> dst, see GraphViews.reversed
         A2, A3, B1, B2 = A3, A2, B2, B1
-    ops.edge_gate(e, B1, B2, views, lw.W3, lw.norm, lw.scale_e, lw.shift_e)
-    return ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_out)
+    if e is None:
+        e = ops.edge_gate_encode(raw_edges[0], raw_edges[1], B1, B2, views, lw.W3, lw.scale_e, lw.shift_e)
+    else:
+        ops.edge_gate(e, B1, B2, views, lw.W3, lw.norm, lw.scale_e, lw.shift_e)
+    return ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_out), e
+
+
+def encode_edges(ops, prep, views, e_raw):
+    """e0 in sorted order - or None when layer 0's gate kernel will produce it on the fly."""
+    fuse = getattr(ops, "can_fuse_edge_encoder", None)
+    if prep.layers and fuse is not None and fuse(e_raw, prep.enc_edge, prep.hidden, prep.layers[0].norm, prep.layers[0].Wcat):
+        return None
+    return ops.encode(e_raw, *prep.enc_edge, gather=views.srt_eid, rows=views.num_edges)
 
 
 def score_step(ops, pw, views, h, e, logits, n_edges=None):
@@ -158,11 +170,11 @@ def run_stack(ops, prep, views, x, e_raw, exchange=None, n_own=None, n_score=Non
     consumer of h; `n_own` limits the node update to the first rows, `n_score` the scorer to the first
     sorted positions (both used by the destination-range partition, dist.py)."""
     h = ops.encode(x, *prep.enc_node)
-    e = ops.encode(e_raw, *prep.enc_edge, gather=views.srt_eid, rows=views.num_edges)
+    e = encode_edges(ops, prep, views, e_raw)
     for lw in prep.layers:
         if exchange is not None:
             h = exchange(h)
-        h = layer_step(ops, lw, views, h, e, n_out=n_own)
+        h, e = layer_step(ops, lw, views, h, e, n_out=n_own, raw_edges=(e_raw, prep.enc_edge))
     if exchange is not None:
         h = exchange(h)
     if logits is None:
@@ -204,7 +216,7 @@ def layer_forward_edge_id_order(conv, g, h, e):
         hd = h.detach().to(device=device, dtype=torch.float32).contiguous()
         ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
         es = hip_ops.gather_rows(ed, views.srt_eid)
-        h_new = layer_step(hip_ops, lw, views, hd, es)
+        h_new, _ = layer_step(hip_ops, lw, views, hd, es)
         e_new = torch.empty_like(es)
         e_new[views.srt_eid.long()] = es
         h_new = F.dropout(h_new, conv.dropout, training=conv.training)

@@ -130,6 +130,30 @@ def edge_gate(e, B1h, B2h, views, W3, norm_kind, scale, shift, out=None, num_edg
     return out
 
 
+def can_fuse_edge_encoder(e_raw, enc, hidden, norm_kind, B1h):
+    """The layer-0 gate can produce the encoded edge tile itself (gnnome_edge_gate_encode_f32)."""
+    return (e_raw.dim() == 2 and e_raw.shape[1] == 2 and enc[0].shape == (16, 2) and hidden in (64, 128)
+            and norm_kind == NORM_AFFINE and e_raw.shape[0] > 0 and B1h.stride(0) % 4 == 0 and B1h.data_ptr() % 16 == 0)
+
+
+def edge_gate_encode(e_raw, enc, B1h, B2h, views, W3, scale, shift):
+    """Layer 0: encoder + gate in one kernel; returns e'[E,H] in sorted order."""
+    lib = _lib.load()
+    e_raw = _dense(e_raw, "edge_gate_encode.e_raw")
+    B1h, ldn = _rows(B1h, "edge_gate_encode.B1h")
+    B2h, _ = _rows(B2h, "edge_gate_encode.B2h")
+    W3, ldw = _rows(W3, "edge_gate_encode.W3")
+    E, H = views.num_edges, W3.shape[0]
+    out = torch.empty((E, H), dtype=torch.float32, device=e_raw.device)
+    W1, b1, W2, b2 = enc
+    with torch.cuda.device(e_raw.device):
+        _lib.check(lib.gnnome_edge_gate_encode_f32(_ptr(e_raw), _ptr(views.srt_eid), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
+                                                   _ptr(out), E, H, _ptr(B1h), _ptr(B2h), ldn, _ptr(views.srt_src),
+                                                   _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(scale), _ptr(shift),
+                                                   _stream(e_raw.device)), "edge_gate_encode_f32")
+    return out
+
+
 def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_nodes_out=None):
     lib = _lib.load()
     A1h, ldn = _rows(A1h, "node_aggregate.A1h")

@@ -106,6 +106,16 @@ int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num_edges, int
                          const int32_t* srt_dst, const float* W3, int ldw, int norm_kind,
                          const float* norm_scale, const float* norm_shift, void* stream);
 
+/* Layer-0 form of the gate with the edge encoder folded in (models/full_graph.py:27 + gated_gcn_full.py:97-110):
+ *   e0[p,:]    = encW2 * relu(encW1 * e_raw[srt_eid[p],:] + encb1) + encb2          (in_features 2, hidden_ne 16)
+ *   e_out[p,:] = relu(norm_e(B1h[srt_src[p],:] + B2h[srt_dst[p],:] + e0[p,:]*W3^T)) + e0[p,:]
+ * e0 is produced tile by tile in LDS and never touches HBM.  hidden in {64,128}, affine norm only. */
+int gnnome_edge_gate_encode_f32(const float* e_raw, const int32_t* srt_eid, const float* encW1, const float* encb1,
+                                const float* encW2, const float* encb2, float* e_out, int64_t num_edges, int hidden,
+                                const float* B1h, const float* B2h, int ld_node, const int32_t* srt_src,
+                                const int32_t* srt_dst, const float* W3, int ldw, const float* norm_scale,
+                                const float* norm_shift, void* stream);
+
 /* ---- fused gated aggregation + node update -------------------------------------------------------
  * For every node i < num_nodes_out, with s_p = sigmoid(e[p,:]):
  *   fwd = sum_{p in in(i)}  s_p * A2h[srt_src[p],:] / (sum_{p in in(i)}  s_p + 1e-6)

@@ -209,6 +209,25 @@ def test_edge_score(hidden, hs):
         _assert_close(got, want, scale=20.0)
 
 
+@pytest.mark.parametrize("hidden", [64, 128])
+@pytest.mark.parametrize("e_count", [777, 90_001])
+def test_edge_gate_with_folded_encoder(hidden, e_count):
+    n, H = 600, hidden
+    src, dst, t = _layer_inputs(hidden, n, e_count, seed=hidden + 5)
+    gv, cv = _views_pair(src, dst, n)
+    g = torch.Generator().manual_seed(3)
+    e_raw = torch.stack([torch.randn(e_count, generator=g), 0.9 + 0.1 * torch.rand(e_count, generator=g)], 1)
+    enc = (torch.randn(16, 2, generator=g), torch.randn(16, generator=g), torch.randn(H, 16, generator=g) / 4, torch.randn(H, generator=g))
+    e0 = cpu_ops.encode(e_raw.double(), *(w.double() for w in enc), gather=cv.srt_eid)
+    want = cpu_ops.edge_gate(e0.clone(), t["P"][:, 3 * H:4 * H].double(), t["P"][:, 4 * H:].double(), cv, t["W3"].double(), 0,
+                             t["scale"].double(), t["shift"].double())
+    d = {k: v.to(dev()) for k, v in t.items()}
+    enc_d = tuple(w.to(dev()) for w in enc)
+    assert ops.can_fuse_edge_encoder(e_raw.to(dev()), enc_d, H, 0, d["P"][:, 3 * H:4 * H])
+    got = ops.edge_gate_encode(e_raw.to(dev()), enc_d, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], d["scale"], d["shift"])
+    _assert_close(got, want, scale=20.0)
+
+
 def test_gather_rows():
     g = torch.Generator().manual_seed(2)
     table = torch.randn(100, 128, generator=g).to(dev())
