@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--kind", default="banded", choices=["banded", "uniform"])
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: one forward (BASELINE configs[1]); train: fwd + BCE + bwd + Adam step (configs[2], fp32)")
+    ap.add_argument("--hipgraph", action="store_true", help="replay the forward from a captured hipGraph (single GPU, infer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -215,13 +216,20 @@ def main():
                 loss.backward()
                 opt.step()
                 return logits.detach()
+        elif args.hipgraph:
+            from gnnome_amd.capture import CapturedForward
+            captured = CapturedForward(model, views, x, ef)
+            args.no_kernel_timers = True  # events cannot be recorded inside a replayed graph
+
+            def step():
+                return captured()
         else:
             def step():
                 return model(views, x, ef)
 
         def barrier():
             torch.cuda.synchronize()
-        parallelism = "single"
+        parallelism = "single" + (" (hipGraph replay)" if args.hipgraph else "")
     else:
         from gnnome_amd import dist as gdist
         plan = gdist.PartitionedGraph.from_global(g["src"], g["dst"], n, rank, world, dev)

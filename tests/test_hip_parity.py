@@ -296,6 +296,18 @@ def test_golden_reversed_graph_both_ways():
     assert _prob_diff(rev_free, g["logits_rev"]) < PROB_TOL
 
 
+def test_hipgraph_capture_replays_bit_identically(shipped_weights):
+    from gnnome_amd.capture import CapturedForward
+    g = load_golden("g2_uniform_1k.pt")
+    m = _model(shipped_weights, 64)
+    x, e = g["x"].to(dev()), g["e"].to(dev())
+    eager = m((g["src"], g["dst"], g["num_nodes"]), x, e)
+    cap = CapturedForward(m, (g["src"], g["dst"], g["num_nodes"]), x, e)
+    assert torch.equal(cap(), eager) and torch.equal(cap(), eager)
+    e2 = e * 0.5
+    assert torch.equal(cap(e=e2).clone(), m((g["src"], g["dst"], g["num_nodes"]), x, e2))
+
+
 class _DuckGraph:
     """Anything with edges()/num_nodes()/num_edges() is accepted in place of a DGLGraph."""
 
