@@ -209,14 +209,34 @@ def main():
             opt = torch.optim.Adam(model.parameters(), lr=1e-4)
             y, pw = g["y"].to(dev), g["pos_weight"].to(dev)
 
-            def step():
+            def eager_step():
                 logits = model(views, x, ef)
                 loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), y, pos_weight=pw)
-                opt.zero_grad()
+                opt.zero_grad(set_to_none=False)
                 loss.backward()
                 opt.step()
                 return logits.detach()
-        elif args.hipgraph:
+
+            step = eager_step
+            if args.hipgraph:
+                # the whole step - forward, loss, backward kernels, Adam - recorded once into a hipGraph and replayed:
+                # ~450 library launches + ~600 small torch ops cost 30-40 ms of host time per step otherwise
+                opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        eager_step()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                train_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(train_graph):
+                    static_logits = eager_step()
+                args.no_kernel_timers = True
+
+                def step():
+                    train_graph.replay()
+                    return static_logits
+        elif args.hipgraph and args.mode == "infer":
             from gnnome_amd.capture import CapturedForward
             captured = CapturedForward(model, views, x, ef)
             args.no_kernel_timers = True  # events cannot be recorded inside a replayed graph

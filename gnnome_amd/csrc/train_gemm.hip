@@ -9,11 +9,13 @@ namespace gnnome {
 // ---------------------------------------------------------------------------------------------------
 // wgrad:  C[Ka,Kb] = A[R,Ka]^T * B[R,Kb]   (nn.Linear weight gradient dW = dY^T X; also dW of B_3, W1, W2)
 // Exact fp32 on v_mfma_f32_32x32x2_f32 with the ROW index as the MFMA k dimension.  A workgroup owns one
-// 64x64 output tile and one contiguous chunk of rows and writes its partial tile; a second kernel adds the
+// 128x128 output tile and one contiguous chunk of rows and writes its partial tile; a second kernel adds the
 // partials in chunk order, so the result does not depend on scheduling (no float atomics).
 // ---------------------------------------------------------------------------------------------------
-constexpr int kWgTile = 64, kWgRows = 64, kWgLd = kWgTile + 4;
+constexpr int kWgTile = 128, kWgRows = 64, kWgLd = kWgTile + 4;
 
+// One workgroup = one 128x128 output tile (a whole [H,H] weight at H = 128) x one chunk of rows, so every row of
+// A and B is read from HBM exactly once; wave (wi, wj) owns a 64x64 quadrant as 2x2 accumulators.
 __global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__ A, int lda, int Ka, const float* __restrict__ B,
                                                        int ldb, int Kb, int64_t R, int64_t rows_per_chunk,
                                                        float* __restrict__ partial) {
@@ -23,15 +25,19 @@ __global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__
     const int i0 = blockIdx.x * kWgTile, j0 = blockIdx.y * kWgTile;
     const int64_t r_begin = (int64_t)blockIdx.z * rows_per_chunk, r_end = min(R, r_begin + rows_per_chunk);
     const int wi = wave & 1, wj = wave >> 1;
-    f32x16 acc;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int c4 = tid & 15, rr = tid >> 4;  // 16 float4 per 64-wide row, 16 rows per pass
+    const int c4 = tid & 31, rr = tid >> 5;  // 32 float4 per 128-wide row, 8 rows per pass
     for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
 #pragma unroll
-        for (int it = 0; it < kWgRows / 16; ++it) {
-            const int lr = rr + 16 * it;
+        for (int it = 0; it < kWgRows / 8; ++it) {
+            const int lr = rr + 8 * it;
             const int64_t row = r0 + lr;
             f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = av;
             if (row < r_end) {  // rows and columns outside the operands contribute zeros
@@ -43,27 +49,44 @@ __global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__
         }
         __syncthreads();
         // lane l supplies A^T[i = l&31][k = row 2s + (l>>5)] and B[k][j = l&31]
-        const float* ap = As + (lane >> 5) * kWgLd + 32 * wi + (lane & 31);
-        const float* bp = Bs + (lane >> 5) * kWgLd + 32 * wj + (lane & 31);
-#pragma unroll 8
-        for (int s = 0; s < kWgRows / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * kWgLd], bp[2 * s * kWgLd], acc, 0, 0, 0);
+        const float* ap = As + (lane >> 5) * kWgLd + 64 * wi + (lane & 31);
+        const float* bp = Bs + (lane >> 5) * kWgLd + 64 * wj + (lane & 31);
+#pragma unroll 4
+        for (int s = 0; s < kWgRows / 2; ++s) {
+            const float a0 = ap[2 * s * kWgLd], a1 = ap[2 * s * kWgLd + 32];
+            const float b0 = bp[2 * s * kWgLd], b1 = bp[2 * s * kWgLd + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
         __syncthreads();
     }
     float* out = partial + ((int64_t)blockIdx.z * Ka + i0) * Kb + j0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = 32 * wi + cd_row(r, lane), j = 32 * wj + (lane & 31);
-        if (i0 + i < Ka && j0 + j < Kb) out[(int64_t)i * Kb + j] = acc[r];
-    }
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 64 * wi + 32 * a + cd_row(r, lane), j = 64 * wj + 32 * b + (lane & 31);
+                if (i0 + i < Ka && j0 + j < Kb) out[(int64_t)i * Kb + j] = acc[a][b][r];
+            }
 }
 
+// C = sum over chunks of the partial tiles, in a fixed order: workgroup = 64 consecutive elements, wave w adds the
+// chunks c = w, w+4, ... and the four wave sums are combined in wave order.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int64_t elems, int chunks,
                                                       float* __restrict__ C, int ldc, int Kb) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * elems + i];
-        C[(i / Kb) * ldc + (i % Kb)] = s;
-    }
+    __shared__ float part[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (i < elems)
+        for (int c = wave; c < chunks; c += 4) s += partial[(int64_t)c * elems + i];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && i < elems) C[(i / Kb) * ldc + (i % Kb)] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -187,9 +210,9 @@ using namespace gnnome;
 
 extern "C" int gnnome_wgrad_workspace_bytes(int64_t rows, int Ka, int Kb, size_t* bytes_host) {
     GN_REQUIRE(bytes_host && rows >= 0 && Ka > 0 && Kb > 0, "wgrad: bad arguments");
-    int64_t chunks = (rows + 4095) / 4096;  // >= 4096 rows per chunk
+    int64_t chunks = (rows + 2047) / 2048;  // >= 2048 rows per chunk: ~2 resident workgroups per CU at 1M rows
     if (chunks < 1) chunks = 1;
-    if (chunks > 512) chunks = 512;
+    if (chunks > 1024) chunks = 1024;
     *bytes_host = (size_t)chunks * Ka * Kb * sizeof(float);
     return GNNOME_OK;
 }
@@ -205,8 +228,8 @@ extern "C" int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B,
     }
     GN_REQUIRE(A && B && workspace && lda >= Ka && ldb >= Kb && lda % 4 == 0 && ldb % 4 == 0, "wgrad: bad operands");
     GN_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "wgrad: A and B must be 16-byte aligned");
-    int64_t chunks = (rows + 4095) / 4096;
-    if (chunks > 512) chunks = 512;
+    int64_t chunks = (rows + 2047) / 2048;
+    if (chunks > 1024) chunks = 1024;
     int64_t rpc = (rows + chunks - 1) / chunks;
     rpc = (rpc + kWgRows - 1) / kWgRows * kWgRows;
     chunks = (rows + rpc - 1) / rpc;
@@ -219,8 +242,8 @@ extern "C" int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B,
     hipLaunchKernelGGL(k_wgrad_partial, grid, dim3(256), 0, s, A, lda, Ka, B, ldb, Kb, rows, rpc, (float*)workspace);
     GN_LAUNCH_CHECK();
     const int64_t elems = (int64_t)Ka * Kb;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid_for_items(elems)), dim3(256), 0, s, (const float*)workspace, elems, (int)chunks, C,
-                       ldc, Kb);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, s, (const float*)workspace, elems,
+                       (int)chunks, C, ldc, Kb);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

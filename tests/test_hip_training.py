@@ -217,3 +217,27 @@ def test_training_step_matches_oracle_autograd(hidden, reverse):
     opt.step()
     m.eval()
     assert torch.isfinite(m(views, x.to(dev()), gr["e"].to(dev()))).all()
+
+
+def test_symmetry_loss_harness_matches_golden_and_trains():
+    """train.py:159-170 (get_symmetry_loss_full): forward on g, forward on dgl.reverse(g) with the degree columns
+    swapped, symmetry_loss over both - eval-mode value against the reference golden G4, then the same in train mode
+    with backward through BOTH passes (the reversed pass reuses the views: no rebuild)."""
+    from oracle.symgated_oracle import symmetry_loss
+    g = load_golden("g4_reverse_h64.pt")
+    sd = random_state_dict(64, seed=g["seed"])
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 8, 64, "batch", dropout=0.0)
+    m.load_state_dict(sd)
+    m.to(dev()).eval()
+    views = gnnome_amd.graph.views_for((g["src"], g["dst"], g["num_nodes"]), dev())
+    x, xr, e, y, pw = (g[k].to(dev()) for k in ("x", "x_rev", "e", "y", "pos_weight"))
+    with torch.no_grad():
+        org, rev = m(views, x, e).squeeze(-1), m(views.reversed(), xr, e).squeeze(-1)
+    assert abs(symmetry_loss(org, rev, y, pw, g["alpha"]).item() - g["symmetry_loss"].item()) < 2e-5
+    m.train()
+    org, rev = m(views, x, e).squeeze(-1), m(views.reversed(), xr, e).squeeze(-1)
+    loss = symmetry_loss(org, rev, y, pw, g["alpha"])
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    # four forward passes of bn_e statistics per layer: two model calls x two bn_e applications
+    assert dict(m.named_buffers())["gnn.convs.0.bn_e.num_batches_tracked"].item() == 4
