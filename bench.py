@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--one-gpu-gloo", action="store_true",
+                    help="plumbing check of the N>1 path on a 1-GPU box: all ranks share cuda:0, collectives go over gloo "
+                         "(host-staged); the numbers it prints are NOT a multi-GPU measurement")
     args = ap.parse_args()
     if args.cpu_baseline_only:  # child process of the cpu_baseline leg: no GPU work, bounded by the parent's timeout
         cpu_baseline(WORKLOADS[args.workload][2], args.kind, mode=args.mode)
@@ -176,6 +179,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.one_gpu_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -188,7 +193,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.one_gpu_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n, e, hidden = WORKLOADS[args.workload]
     g = make_graph(n, e, seed=1, kind=args.kind)
@@ -197,8 +205,6 @@ def main():
     model.load_state_dict(random_state_dict(hidden, seed=1))
     model.to(dev)
 
-    if args.mode == "train" and world > 1:
-        raise SystemExit("the training step is single-GPU in this build (gradient / BatchNorm all-reduce not built yet)")
     if world == 1:
         src, dst = g["src"].to(dev), g["dst"].to(dev)
         x, ef = x_cpu.to(dev), g["e"].to(dev)
@@ -260,22 +266,41 @@ def main():
     else:
         from gnnome_amd import dist as gdist
         plan = gdist.PartitionedGraph.from_global(g["src"], g["dst"], n, rank, world, dev)
+        if args.mode == "train":
+            model.train()
         runner = gdist.PartitionedRunner(model, plan, x_cpu, g["e"], dev)
         cold_ms = None
 
-        def step():
-            return runner.forward()
+        if args.mode == "train":
+            # configs[4]'s step: partitioned fwd + BCE + bwd (BatchNorm statistics, halo gradients and parameter
+            # gradients cross ranks inside runner.train_forward / backward) + Adam on every rank
+            import torch.nn.functional as F
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+            y, pw = g["y"].to(dev), g["pos_weight"].to(dev)
+
+            def step():
+                logits = runner.train_forward()
+                loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), y, pos_weight=pw)
+                opt.zero_grad(set_to_none=False)
+                loss.backward()
+                opt.step()
+                return logits.detach()
+        else:
+            def step():
+                return runner.forward()
 
         def barrier():
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-        parallelism = f"dst-range x{world}"
+        parallelism = f"dst-range x{world}" + (" (ALL RANKS ON ONE GPU over gloo: plumbing check, not a measurement)" if args.one_gpu_gloo else "")
 
     # HIP events in the timed region go around ONE launch of the dominant kernel per step (the 8 layers launch
     # the same shape): a pair around every launch of every kernel cost ~1.6 ms per step here (56 events, ~28 us
     # of pipeline bubble each) and inflated what it measured; a pair per gate launch still cost ~0.4 ms.
-    dominant = [] if args.no_kernel_timers or world > 1 else (["edge_gate"] if args.mode == "infer" else ["edge_gate_raw"])
+    # (N>1: rank 0 times its own launches; its gate kernel covers the edges incident to its node range)
+    dominant = [] if args.no_kernel_timers else (["edge_gate"] if args.mode == "infer" else ["edge_gate_raw"])
+    e_gate = e if world == 1 else plan.views.num_edges
     with KernelTimer(ops, dominant, every=8) as kt:
         for _ in range(args.warmup):
             step()
@@ -298,7 +323,7 @@ def main():
     timed = dominant
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.one_gpu_gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
@@ -325,16 +350,19 @@ def main():
             res["mfma_f32_frac_whole_step_3xFfwd"] = (3 * f_fwd / (ms * 1e-3)) / (world * MFMA_F32_PEAK)
         if timed:
             gate_ms, gate_n = kt.mean_ms(timed[0])
-            gate_flops = 2.0 * e * hidden * hidden
+            gate_flops = 2.0 * e_gate * hidden * hidden
             res["roofline"] = {
                 "kernel": "k_edge_gate_ws (fused B_3 GEMM + u_add_v + bn_e + relu + residual)" if args.mode == "infer" else
                           "k_edge_gate<raw> (B_3 GEMM + u_add_v, pre-BatchNorm output)", "bound": "mfma",
                 "achieved": gate_flops / (gate_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": gate_flops / (gate_ms * 1e-3) / MFMA_F32_PEAK, "traffic": _pmc_traffic(args, hidden, e),
+                "frac": gate_flops / (gate_ms * 1e-3) / MFMA_F32_PEAK,
+                "traffic": _pmc_traffic(args, hidden, e) if world == 1 else None,
                 "avg_launch_ms": gate_ms, "launches": gate_n, "flops_per_launch": gate_flops,
-                "algorithmic_bytes_per_launch": 2.0 * e * hidden * 4 + 2 * e * 4,
-                "hbm_frac": (2.0 * e * hidden * 4 + 2 * e * 4) / (gate_ms * 1e-3) / HBM_PEAK,
+                "algorithmic_bytes_per_launch": 2.0 * e_gate * hidden * 4 + 2 * e_gate * 4,
+                "hbm_frac": (2.0 * e_gate * hidden * 4 + 2 * e_gate * 4) / (gate_ms * 1e-3) / HBM_PEAK,
             }
+            if world > 1:
+                res["roofline"]["note"] = f"rank 0's launches: {e_gate} local edges (its node range's in- and out-edges)"
         if timed and others:
             agg_ms, agg_n = kd.mean_ms("node_aggregate")
             agg_bytes = 2.0 * e * hidden * 4 + 3 * e * 4 + 3 * n * hidden * 4

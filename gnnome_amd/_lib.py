@@ -44,6 +44,7 @@ SIGNATURES = {
     "gnnome_agg_edge_bwd_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "gnnome_encode_hidden_f32": [_p, _l, _i, _p, _p, _p, _i, _p, _p],
     "gnnome_gather_rows_f32": [_p, _i, _p, _l, _i, _p, _i, _p],
+    "gnnome_scatter_add_rows_f32": [_p, _i, _p, _l, _i, _p, _i, _p],
 }
 
 ABI_VERSION = 2

@@ -139,6 +139,22 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ i
     }
 }
 
+// out[idx[r], :] += in[r, :]; idx holds distinct rows, so every output element has exactly one writer
+__global__ __launch_bounds__(256) void k_scatter_add_rows(const float* __restrict__ in, int ld_in,
+                                                          const int32_t* __restrict__ idx, int64_t rows, int w4,
+                                                          float* __restrict__ out, int ld_out) {
+    const int64_t total = rows * w4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / w4;
+        const int c = (int)(i % w4) * 4;
+        f32x4* dst = reinterpret_cast<f32x4*>(out + (int64_t)idx[r] * ld_out + c);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(in + r * ld_in + c);
+        f32x4 b = *dst;
+        b[0] += a[0]; b[1] += a[1]; b[2] += a[2]; b[3] += a[3];
+        *dst = b;
+    }
+}
+
 }  // namespace gnnome
 
 extern "C" int gnnome_encode_f32(const float* in, int64_t rows, int in_features, const int32_t* gather, const float* W1,
@@ -174,6 +190,24 @@ extern "C" int gnnome_gather_rows_f32(const float* in, int ld_in, const int32_t*
     if (blocks > kNumCUs * 8) blocks = kNumCUs * 8;
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, ld_in, idx, rows, w4,
                        out, ld_out);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_scatter_add_rows_f32(const float* in, int ld_in, const int32_t* idx, int64_t rows, int width,
+                                           float* out, int ld_out, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(rows >= 0, "scatter_add_rows: negative row count");
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(in && idx && out, "scatter_add_rows: null pointer");
+    GN_REQUIRE(width > 0 && width % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= width && ld_out >= width,
+               "scatter_add_rows: width and strides must be multiples of 4");
+    GN_REQUIRE(((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0), "scatter_add_rows: 16-byte alignment required");
+    const int w4 = width / 4;
+    int64_t blocks = (rows * w4 + 255) / 256;
+    if (blocks > kNumCUs * 8) blocks = kNumCUs * 8;
+    hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, ld_in, idx, rows,
+                       w4, out, ld_out);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

@@ -98,14 +98,13 @@ class PartitionedGraph:
         req_counts = torch.tensor(self.recv_counts, dtype=torch.int64, device=device)
         got_counts = torch.empty(world, dtype=torch.int64, device=device)
         if world > 1:
-            dist.all_to_all_single(got_counts, req_counts, group=group)
+            all_to_all_rows(got_counts, req_counts, None, None, group)
         else:
             got_counts.copy_(req_counts)
         self.send_counts = got_counts.tolist()
         wanted = torch.empty(sum(self.send_counts), dtype=torch.int64, device=device)
         if world > 1:
-            dist.all_to_all_single(wanted, halo.to(device).contiguous(), output_split_sizes=self.send_counts,
-                                   input_split_sizes=self.recv_counts, group=group)
+            all_to_all_rows(wanted, halo.to(device).contiguous(), self.send_counts, self.recv_counts, group)
         assert wanted.numel() == 0 or (int(wanted.min()) >= lo and int(wanted.max()) < hi)
         self.send_idx = (wanted - lo).int().to(device)
         return self
@@ -115,6 +114,39 @@ class PartitionedGraph:
 
     def local_edge_rows(self, e_global):
         return e_global[self.edge_gid]
+
+
+def _staged(t, group):
+    """gloo moves host memory only: device tensors take a round trip through the host under it.  That is the
+    two-processes-on-one-GPU test configuration; RCCL ("nccl") works on device memory directly."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_to_all_rows(out, inp, out_counts, in_counts, group=None, async_op=False):
+    """out <- row blocks from every peer (out_counts rows each), inp's blocks (in_counts) go out."""
+    if _staged(out, group):
+        o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_to_all_single(o, i, output_split_sizes=out_counts, input_split_sizes=in_counts, group=group)
+        out.copy_(o)
+        return None
+    return dist.all_to_all_single(out, inp, output_split_sizes=out_counts, input_split_sizes=in_counts, group=group, async_op=async_op)
+
+
+def all_reduce_sum(t, group=None):
+    if _staged(t, group):
+        c = t.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def all_gather_rows(t, world, group=None):
+    """[world, *t.shape]: every rank's t."""
+    out = torch.empty(world * t.numel(), dtype=t.dtype, device="cpu" if _staged(t, group) else t.device)
+    dist.all_gather_into_tensor(out, (t.cpu() if _staged(t, group) else t).reshape(-1).contiguous(), group=group)
+    return out.to(t.device).view((world,) + tuple(t.shape))
 
 
 class HaloExchange:
@@ -129,13 +161,85 @@ class HaloExchange:
             return
         packed = self.ops.gather_rows(h, p.send_idx)
         self._keep = packed
-        self.work = dist.all_to_all_single(h[p.n_own:], packed, output_split_sizes=p.recv_counts,
-                                           input_split_sizes=p.send_counts, group=self.group, async_op=True)
+        self.work = all_to_all_rows(h[p.n_own:], packed, p.recv_counts, p.send_counts, self.group, async_op=True)
 
     def finish(self):
         if self.work is not None:
             self.work.wait()
-            self.work, self._keep = None, None
+        self.work, self._keep = None, None
+
+    def transpose(self, dh):
+        """Backward of start/finish: the halo rows of dh return to their owners, which add them to their own rows
+        (one peer's block at a time: within a block the rows are distinct, so the sum order is fixed), then
+        dh[n_own:] = 0."""
+        p = self.part
+        if p.world == 1:
+            return
+        got = torch.empty((int(p.send_idx.numel()), dh.shape[1]), dtype=torch.float32, device=dh.device)
+        all_to_all_rows(got, dh[p.n_own:].contiguous(), p.send_counts, p.recv_counts, self.group)
+        at = 0
+        for cnt in p.send_counts:
+            if cnt:
+                self.ops.scatter_add_rows(got[at:at + cnt], p.send_idx[at:at + cnt], dh)
+            at += cnt
+        dh[p.n_own:].zero_()
+
+
+class PartitionShard:
+    """One rank's rows of a training step over a destination-range partition (see gnnome_amd.train.WholeGraph for
+    the interface; SURVEY.md 8e "Training additions"):
+      * BatchNorm batch statistics: every rank reduces its OWNED rows (each edge / node of the graph exactly once),
+        the per-rank (count, mean, M2) are all-gathered and merged with the parallel-variance formula;
+      * backward: per-channel BatchNorm sums and, at the end, all parameter gradients are all-reduced (one flat
+        buffer); halo rows of dh are scatter-added back to their owners once per layer."""
+
+    def __init__(self, part, ops=hip_ops, group=None):
+        if part.views.transposed:
+            raise NotImplementedError("partitioned training runs on the forward orientation of the graph")
+        if part.n_own == 0 or part.n_score == 0:
+            raise NotImplementedError("a rank without owned nodes or owned in-edges (graph too small for this world size)")
+        self.part, self.ops, self.group, self.world = part, ops, group, part.world
+        self.views = part.views
+        self.n_own, self.n_local = part.n_own, part.n_local
+        self.e_own, self.e_local = part.n_score, part.views.num_edges
+        self.n_global, self.e_global = part.bounds[-1], part.num_edges_global
+        self.score_views = _ScoreViews(part.views, part.srt_geid)
+        self._xchg = HaloExchange(part, ops, group)
+
+    def halo_start(self, h):
+        self._xchg.start(h)
+
+    def halo_finish(self):
+        self._xchg.finish()
+
+    def halo_bwd(self, dh):
+        self._xchg.transpose(dh)
+
+    def combine_stats(self, mean, var, rows):
+        if self.world == 1:
+            return mean, var
+        H = mean.numel()
+        mine = torch.cat([torch.full((1,), float(rows), dtype=torch.float64, device=mean.device), mean.double(), var.double() * rows])
+        every = all_gather_rows(mine, self.world, self.group)           # [world, 1+2H], identical on every rank
+        n, mu, m2 = every[:, :1], every[:, 1:1 + H], every[:, 1 + H:]
+        total = n.sum()
+        mean_all = (n * mu).sum(0) / total
+        m2_all = (m2 + n * (mu - mean_all) ** 2).sum(0)
+        return mean_all.float().contiguous(), (m2_all / total).float().contiguous()
+
+    def sum_ranks(self, tensors):
+        if self.world == 1:
+            return tensors
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        all_reduce_sum(flat, self.group)
+        out, at = [], 0
+        for t in tensors:
+            out.append(flat[at:at + t.numel()].view(t.shape))
+            at += t.numel()
+        return out
+
+    def finish_logits(self, logits):
+        return all_reduce_sum(logits, self.group) if self.world > 1 else logits
 
 
 def _project(ops, lw, h, n_own, xchg):
@@ -180,7 +284,7 @@ def run_partitioned(ops, prep, part, x_local, e_local, group=None, reduce_result
         ops.edge_score(e, PQ[:, :hs], PQ[:, hs:], score_views, pw["W1_e"], pw["W2"], pw["b2"], pw["W3"], pw["b3"], logits,
                        num_edges=part.n_score)
     if reduce_result and part.world > 1:
-        dist.all_reduce(logits, op=dist.ReduceOp.SUM, group=group)  # disjoint supports: a concatenation
+        all_reduce_sum(logits, group)  # disjoint supports: a concatenation
     return logits
 
 
@@ -195,13 +299,20 @@ class PartitionedRunner:
     """Holds one rank's partition, weights and inputs on its GPU; forward() = one whole-graph scoring pass."""
 
     def __init__(self, model, part, x_global, e_global, device, ops=hip_ops, group=None):
-        if model.training:
-            raise NotImplementedError("partitioned execution is inference-only in this build")
-        self.ops, self.part, self.group = ops, part, group
-        self.prep = engine.prepared_for(model, device, engine.Prepared)
+        self.ops, self.part, self.group, self.model = ops, part, group, model
+        self.prep = None if model.training else engine.prepared_for(model, device, engine.Prepared)
         self.x = part.local_node_rows(x_global).to(device=device, dtype=torch.float32).contiguous()
         self.e = part.local_edge_rows(e_global).to(device=device, dtype=torch.float32).contiguous()
 
     def forward(self):
+        """eval mode: logits[E,1] of one whole-graph scoring pass."""
+        if self.prep is None:
+            raise RuntimeError("built from a model in train mode: use train_forward()")
         with torch.no_grad():
             return run_partitioned(self.ops, self.prep, self.part, self.x, self.e, self.group).unsqueeze(1)
+
+    def train_forward(self):
+        """train mode: logits[E,1] with autograd history; after loss.backward() every rank holds the whole graph's
+        parameter gradients (already summed over ranks), so identical optimizers stay in step without a DDP wrapper."""
+        from .train import train_forward_on
+        return train_forward_on(self.model, PartitionShard(self.part, self.ops, self.group), self.x, self.e)

@@ -225,6 +225,17 @@ def gather_rows(table, idx, out=None):
     return out
 
 
+def scatter_add_rows(src, idx, out):
+    """out[idx[r]] += src[r] for DISTINCT idx (transpose of gather_rows; halo gradients returning to their owner)."""
+    src, ld_in = _rows(src, "scatter_add_rows.in")
+    out, ld_out = _rows(out, "scatter_add_rows.out")
+    _i32(idx, "scatter_add_rows.idx")
+    if int(idx.numel()) != src.shape[0] or src.shape[1] != out.shape[1]:
+        raise ValueError("scatter_add_rows: shape mismatch")
+    _call("gnnome_scatter_add_rows_f32", src.device, _ptr(src), ld_in, _ptr(idx), int(idx.numel()), src.shape[1], _ptr(out), ld_out)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # training-step entries (include/gnnome_hip.h, "Training step")
 # ---------------------------------------------------------------------------------------------------
@@ -253,13 +264,17 @@ def edge_gate_raw(e, B1h, B2h, views, W3):
     return out
 
 
-def node_aggregate_raw(e, A1h, A2h, A3h, views, mode, num_nodes):
-    """mode 1 -> (v, fwd, rden_f, bwd, rden_b); mode 2 -> (sum_in s*A2h[src], sum_out s*A3h[dst])."""
+def node_aggregate_raw(e, A1h, A2h, A3h, views, mode, num_nodes, rows_alloc=None):
+    """mode 1 -> (v, fwd, rden_f, bwd, rden_b); mode 2 -> (sum_in s*A2h[src], sum_out s*A3h[dst]).
+    rows_alloc > num_nodes: outputs get that many rows, the ones past num_nodes zero (halo rows of a partition)."""
     A2h, ldn = _rows(A2h, "node_aggregate_raw.A2h")
     A3h, l3 = _rows(A3h, "node_aggregate_raw.A3h")
     assert ldn == l3
     H, dev = A2h.shape[1], A2h.device
-    mk = lambda: torch.empty((num_nodes, H), dtype=torch.float32, device=dev)  # noqa: E731
+    if rows_alloc is not None and rows_alloc > num_nodes:
+        mk = lambda: torch.zeros((rows_alloc, H), dtype=torch.float32, device=dev)  # noqa: E731
+    else:
+        mk = lambda: torch.empty((num_nodes, H), dtype=torch.float32, device=dev)  # noqa: E731
     if mode == 1:
         A1h, l1 = _rows(A1h, "node_aggregate_raw.A1h")
         assert l1 == ldn
@@ -292,9 +307,9 @@ def batch_stats(x):
     return (c + m1).contiguous(), (d2 / rows - m1 * m1).clamp_min_(0.0)
 
 
-def bn_relu_res(x, scale, shift, res):
+def bn_relu_res(x, scale, shift, res, out=None):
     x, res = _dense(x, "bn_relu_res.x"), _dense(res, "bn_relu_res.res")
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if out is None else _dense(out, "bn_relu_res.out")
     _call("gnnome_bn_relu_res_f32", x.device, _ptr(x), _ptr(scale), _ptr(shift), _ptr(res), x.shape[0], x.shape[1], _ptr(out))
     return out
 
@@ -307,8 +322,10 @@ def bn_bwd_stats(dy, x, scale, shift, mean):
     return s[0], s[1]
 
 
-def bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd):
-    dx = torch.empty_like(x)
+def bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd, out=None):
+    dx = torch.empty_like(x) if out is None else _dense(out, "bn_bwd_apply.out")
+    if x.shape[0] == 0:
+        return dx
     _call("gnnome_bn_bwd_apply_f32", x.device, _ptr(_dense(dy, "dy")), _ptr(_dense(x, "x")), _ptr(scale), _ptr(shift), x.shape[0],
           x.shape[1], _ptr(a), _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(dx))
     return dx

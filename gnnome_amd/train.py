@@ -23,10 +23,40 @@ BatchNorm statistics and concatenates/slices views.
 """
 import torch
 
-from . import ops
+from . import ops as hip_ops
 from .graph import views_for
 
-EPS_BN = 1e-5
+
+class WholeGraph:
+    """Where the rows of one training step live.  This is the single-process case: every node and edge of the graph
+    is local and owned, nothing is exchanged.  gnnome_amd.dist.PartitionShard is the destination-range partition
+    (owned nodes first, then halo; owned in-edges first, then the out-edges that end in the halo)."""
+
+    world = 1
+
+    def __init__(self, views, ops=hip_ops):
+        self.views, self.ops = views, ops
+        self.n_own = self.n_local = self.n_global = views.num_nodes
+        self.e_own = self.e_local = self.e_global = views.num_edges
+        self.score_views = views
+
+    def halo_start(self, h):            # h[n_own:] <- the owners' rows (forward)
+        pass
+
+    def halo_finish(self):
+        pass
+
+    def halo_bwd(self, dh):             # owners' dh rows += dh[n_own:], then dh[n_own:] = 0 (backward)
+        pass
+
+    def combine_stats(self, mean, var, rows):   # per-rank (mean, biased var, row count) -> statistics of the union
+        return mean, var
+
+    def sum_ranks(self, tensors):       # element-wise sum over ranks of a list of tensors (same shapes on every rank)
+        return tensors
+
+    def finish_logits(self, logits):    # assemble the per-rank disjoint pieces of logits[E_global]
+        return logits
 
 
 def _cat_layer(conv):
@@ -40,10 +70,14 @@ def _roles(transposed):
     return dict(A1=0, A2=2, A3=1, B1=4, B2=3) if transposed else dict(A1=0, A2=1, A3=2, B1=3, B2=4)
 
 
-def _bn_train(bn, x, updates):
-    """Batch statistics of x -> (mean, rstd, scale, shift); running buffers advanced `updates` times like nn.BatchNorm1d."""
-    rows = x.shape[0]
-    mean, var = ops.batch_stats(x)
+def _bn_train(sh, bn, x, rows, updates):
+    """Batch statistics over the `rows` rows of the whole graph, of which x holds this rank's -> (mean, rstd, scale,
+    shift); running buffers advanced `updates` times like nn.BatchNorm1d."""
+    if x.shape[0] > 0:
+        mean, var = sh.ops.batch_stats(x)
+    else:
+        mean = var = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    mean, var = sh.combine_stats(mean, var, x.shape[0])
     rstd = torch.rsqrt(var + bn.eps)
     scale = bn.weight.detach() * rstd
     shift = bn.bias.detach() - mean * scale
@@ -58,44 +92,63 @@ def _bn_train(bn, x, updates):
     return mean.contiguous(), rstd.contiguous(), scale.contiguous(), shift.contiguous()
 
 
-def _bn_bwd(dy, x, scale, shift, mean, rstd, rows):
-    """d(input of bn) and (d gamma, d beta) for out = relu(x*scale + shift) + res, scale = gamma*rstd."""
+def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out):
+    """out <- d(input of bn); returns this rank's share of (d gamma, d beta), for out = relu(x*scale + shift) + res with
+    scale = gamma*rstd.  `rows` = rows of the whole graph.  dy may hold PARTIAL gradients of rows that are replicated
+    on another rank (cut edges): the per-channel sums run over all local rows - summed over ranks they are the true
+    totals - while the mean-subtraction terms, which must enter once per row of the whole graph, are applied to the
+    first n_once rows only (the owned ones)."""
+    ops = sh.ops
     s1, s2 = ops.bn_bwd_stats(dy, x, scale, shift, mean)
     s2h = rstd * s2                                     # sum dy*m*xhat
-    dx = ops.bn_bwd_apply(dy, x, scale, shift, scale, (s1 / rows).contiguous(), (s2h / rows).contiguous(), mean, rstd)
-    return dx, s2h, s1
+    t1, t2 = sh.sum_ranks([s1, s2h])
+    ops.bn_bwd_apply(dy[:n_once], x[:n_once], scale, shift, scale, (t1 / rows).contiguous(), (t2 / rows).contiguous(), mean, rstd,
+                     out=out[:n_once])
+    if n_once < x.shape[0]:
+        zero = torch.zeros_like(mean)
+        ops.bn_bwd_apply(dy[n_once:], x[n_once:], scale, shift, scale, zero, zero, mean, rstd, out=out[n_once:])
+    return s2h, s1
 
 
 class _TrainStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, views, x, e_raw, names, *params):
+    def forward(ctx, model, sh, x, e_raw, names, *params):
         conv0 = model.gnn.convs[0]
         if not isinstance(conv0.bn_e, torch.nn.BatchNorm1d):
             raise NotImplementedError("training is implemented for normalization='batch' (the reference default)")
+        ops, views = sh.ops, sh.views
         H = model.linear2_node.out_features
-        N, E = views.num_nodes, views.num_edges
+        n_own, n_local, e_own, e_local = sh.n_own, sh.n_local, sh.e_own, sh.e_local
         r = _roles(views.transposed)
         blk = lambda P, k: P[:, r[k] * H:(r[k] + 1) * H]  # noqa: E731
         d = lambda t: t.detach().contiguous()  # noqa: E731
+        new = lambda rows, cols: torch.empty((rows, cols), dtype=torch.float32, device=x.device)  # noqa: E731
 
         h = ops.encode(x, d(model.linear1_node.weight), d(model.linear1_node.bias), d(model.linear2_node.weight), d(model.linear2_node.bias))
         e = ops.encode(e_raw, d(model.linear1_edge.weight), d(model.linear1_edge.bias), d(model.linear2_edge.weight),
-                       d(model.linear2_edge.bias), gather=views.srt_eid, rows=E)
+                       d(model.linear2_edge.bias), gather=views.srt_eid, rows=e_local)
         saved = []
-        for conv in model.gnn.convs:
+        for li, conv in enumerate(model.gnn.convs):
             Wcat, bcat = _cat_layer(conv)
-            P = ops.linear(h, Wcat, bcat)
+            if li > 0:
+                sh.halo_start(h)        # layer 0's halo rows come straight from the input features
+            P = new(n_local, 5 * H)
+            ops.linear(h[:n_own], Wcat, bcat, out=P[:n_own])    # owned rows while the halo rows are in flight
+            sh.halo_finish()
+            if n_local > n_own:
+                ops.linear(h[n_own:], Wcat, bcat, out=P[n_own:])
             xe = ops.edge_gate_raw(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight))
-            mean_e, rstd_e, sc_e, sh_e = _bn_train(conv.bn_e, xe, updates=2)
+            mean_e, rstd_e, sc_e, sh_e = _bn_train(sh, conv.bn_e, xe[:e_own], sh.e_global, updates=2)
             e_new = ops.bn_relu_res(xe, sc_e, sh_e, e)
-            v, hf, rdf, hb, rdb = ops.node_aggregate_raw(e_new, blk(P, "A1"), blk(P, "A2"), blk(P, "A3"), views, 1, N)
-            mean_h, rstd_h, sc_h, sh_h = _bn_train(conv.bn_h, v, updates=1)
-            h_new = ops.bn_relu_res(v, sc_h, sh_h, h)
+            v, hf, rdf, hb, rdb = ops.node_aggregate_raw(e_new, blk(P, "A1"), blk(P, "A2"), blk(P, "A3"), views, 1, n_own,
+                                                         rows_alloc=n_local)
+            mean_h, rstd_h, sc_h, sh_h = _bn_train(sh, conv.bn_h, v[:n_own], sh.n_global, updates=1)
+            h_next = new(n_local, H)
+            ops.bn_relu_res(v[:n_own], sc_h, sh_h, h[:n_own], out=h_next[:n_own])
             mask = None
-            h_next = h_new
             if conv.dropout > 0.0:
-                mask = torch.empty_like(h_new).bernoulli_(1.0 - conv.dropout).div_(1.0 - conv.dropout)
-                h_next, _ = ops.mul23(h_new, mask, mask)
+                mask = new(n_own, H).bernoulli_(1.0 - conv.dropout).div_(1.0 - conv.dropout)
+                h_next[:n_own].copy_(ops.mul23(h_next[:n_own], mask, mask)[0])
             saved.append(dict(h=h, P=P, e=e, xe=xe, e_new=e_new, mean_e=mean_e, rstd_e=rstd_e, v=v, hf=hf, rdf=rdf, hb=hb, rdb=rdb,
                               mean_h=mean_h, rstd_h=rstd_h, mask=mask, Wcat=Wcat, sc_e=sc_e, sh_e=sh_e, sc_h=sc_h, sh_h=sh_h))
             h, e = h_next, e_new
@@ -105,65 +158,81 @@ class _TrainStep(torch.autograd.Function):
         W1 = d(pred.W1.weight)
         W_nodes = torch.cat([W1[:, :H], W1[:, H:2 * H]], 0).contiguous()
         b_nodes = torch.cat([torch.zeros_like(pred.W1.bias), pred.W1.bias]).detach().contiguous()
+        sh.halo_start(h)
+        sh.halo_finish()
         PQ = ops.linear(h, W_nodes, b_nodes)
         ps, qd = (PQ[:, hs:], PQ[:, :hs]) if views.transposed else (PQ[:, :hs], PQ[:, hs:])
-        logits = torch.empty(E, dtype=torch.float32, device=h.device)
-        z1 = torch.empty((E, hs), dtype=torch.float32, device=h.device)
-        ops.edge_score(e, ps, qd, views, W1[:, 2 * H:], d(pred.W2.weight), d(pred.W2.bias), d(pred.W3.weight.reshape(-1)),
-                       d(pred.W3.bias.reshape(-1)), logits, z1_out=z1)
-        ctx.model, ctx.views, ctx.names, ctx.saved = model, views, names, saved
+        # every edge of the graph is scored once, by the rank that owns its destination, at its GLOBAL edge id
+        logits = (torch.zeros if sh.world > 1 else torch.empty)(sh.e_global, dtype=torch.float32, device=h.device)
+        z1 = new(e_own, hs)
+        ops.edge_score(e, ps, qd, sh.score_views, W1[:, 2 * H:], d(pred.W2.weight), d(pred.W2.bias), d(pred.W3.weight.reshape(-1)),
+                       d(pred.W3.bias.reshape(-1)), logits, num_edges=e_own, z1_out=z1)
+        logits = sh.finish_logits(logits)
+        ctx.model, ctx.sh, ctx.names, ctx.saved = model, sh, names, saved
         ctx.tail = dict(h=h, e=e, z1=z1, W1=W1, W_nodes=W_nodes, x=x, e_raw=e_raw)
         return logits.unsqueeze(1)
 
     @staticmethod
     def backward(ctx, dlogits):
-        model, views, saved, tail = ctx.model, ctx.views, ctx.saved, ctx.tail
+        model, sh, saved, tail = ctx.model, ctx.sh, ctx.saved, ctx.tail
+        ops, views = sh.ops, sh.views
         H = model.linear2_node.out_features
-        N, E = views.num_nodes, views.num_edges
+        n_own, n_local, e_own, e_local = sh.n_own, sh.n_local, sh.e_own, sh.e_local
         r = _roles(views.transposed)
         blk = lambda P, k: P[:, r[k] * H:(r[k] + 1) * H]  # noqa: E731
         d = lambda t: t.detach().contiguous()  # noqa: E731
+        dev = dlogits.device
         g = {}
+        # Rows that also live on another rank (cut edges, halo nodes) carry PARTIAL gradients here: everything below
+        # is linear in the incoming gradient, so the per-rank parameter gradients sum to the whole graph's (sum_ranks
+        # at the end), and halo_bwd returns the halo rows' share of dh to the owners once per layer.
 
-        # ---- scorer (score_predictor.py:12-17)
+        # ---- scorer (score_predictor.py:12-17): the owned in-edges, positions [0, e_own)
         pred = model.predictor
         hs = pred.W1.out_features
         dl = dlogits.reshape(-1).contiguous().float()
-        dz1, dz2, u = ops.score_tail_bwd(tail["z1"], dl, views, d(pred.W2.weight), d(pred.W2.bias), d(pred.W3.weight.reshape(-1)))
+        dz1, dz2, u = ops.score_tail_bwd(tail["z1"], dl, sh.score_views, d(pred.W2.weight), d(pred.W2.bias), d(pred.W3.weight.reshape(-1)))
         g["predictor.W2.weight"] = ops.wgrad(dz2, tail["z1"])
         g["predictor.W2.bias"] = ops.colsum2(dz2)[0]
         g["predictor.W3.weight"] = ops.colsum2(u)[0].reshape(1, 32)
-        g["predictor.W3.bias"] = dl.sum().reshape(1)
+        g["predictor.W3.bias"] = (dl if sh.world == 1 else dl[sh.score_views.srt_eid.long()]).sum().reshape(1)
+        if e_local > e_own:
+            dz1 = torch.cat([dz1, torch.zeros((e_local - e_own, hs), dtype=torch.float32, device=dev)], 0)
         W1 = tail["W1"]
-        de = ops.linear(dz1, W1[:, 2 * H:].t().contiguous(), None)           # d e_final  [E,H]
+        de = ops.linear(dz1, W1[:, 2 * H:].t().contiguous(), None)           # d e_final  [e_local,H]
         gW1e = ops.wgrad(dz1, tail["e"])
-        d_ps = ops.segment_sum(dz1, views.out_ptr, views.out_pos, N)         # gathered by srt_src in the forward
-        d_qd = ops.segment_sum(dz1, views.in_ptr, None, N)                   # gathered by srt_dst
+        d_ps = ops.segment_sum(dz1, views.out_ptr, views.out_pos, n_local)   # gathered by srt_src in the forward
+        d_qd = ops.segment_sum(dz1, views.in_ptr, None, n_local)             # gathered by srt_dst
         dPQ = torch.cat([d_qd, d_ps], 1) if views.transposed else torch.cat([d_ps, d_qd], 1)
         g["predictor.W1.bias"] = ops.colsum2(dPQ[:, hs:].contiguous())[0]
         gWn = ops.wgrad(dPQ, tail["h"])                                      # [2hs, H]
         g["predictor.W1.weight"] = torch.cat([gWn[:hs], gWn[hs:], gW1e], 1)
-        dh = ops.linear(dPQ, tail["W_nodes"].t().contiguous(), None)         # [N,H]
+        dh = ops.linear(dPQ, tail["W_nodes"].t().contiguous(), None)         # [n_local,H]
 
         # ---- layers, last to first (gated_gcn_full.py:82-142)
         for li in range(len(saved) - 1, -1, -1):
             s, conv, pfx = saved[li], model.gnn.convs[li], f"gnn.convs.{li}."
+            sh.halo_bwd(dh)
             if s["mask"] is not None:
-                dh, _ = ops.mul23(dh, s["mask"], s["mask"])
-            # h' = relu(bn_h(v)) + h_in
-            dv, g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = _bn_bwd(dh, s["v"], s["sc_h"], s["sh_h"], s["mean_h"], s["rstd_h"], N)
+                dh[:n_own].copy_(ops.mul23(dh[:n_own], s["mask"], s["mask"])[0])
+            # h' = relu(bn_h(v)) + h_in      (owned rows)
+            dv = (torch.zeros if n_local > n_own else torch.empty)((n_local, H), dtype=torch.float32, device=dev)
+            g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = _bn_bwd(sh, dh[:n_own], s["v"][:n_own], s["sc_h"], s["sh_h"], s["mean_h"],
+                                                                   s["rstd_h"], sh.n_global, n_own, dv[:n_own])
             dh_in = dh
             # v = A1h + fwd + bwd
             Tf, Uf = ops.mul23(dv, s["rdf"], s["hf"])
             Tb, Ub = ops.mul23(dv, s["rdb"], s["hb"])
-            sum_in, sum_out = ops.node_aggregate_raw(s["e_new"], None, Tb, Tf, views, 2, N)   # = dA3(role), dA2(role)
+            sum_in, sum_out = ops.node_aggregate_raw(s["e_new"], None, Tb, Tf, views, 2, n_local)   # = dA3(role), dA2(role)
             ops.agg_edge_bwd(s["e_new"], Tf, Uf, Tb, Ub, blk(s["P"], "A2"), blk(s["P"], "A3"), views, de)  # de += ...
             # e' = relu(bn_e(xe)) + e_in ;  xe = B1h[src] + B2h[dst] + e_in W3^T
-            dxe, g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"], E)
+            dxe = torch.empty_like(de)
+            g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
+                                                                   sh.e_global, e_own, dxe)
             g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"])
             ops.linear(dxe, d(conv.B_3.weight).t().contiguous(), None, out=de, accumulate=True)   # d e_in = d e' + dxe W3
-            dB1 = ops.segment_sum(dxe, views.out_ptr, views.out_pos, N)
-            dB2 = ops.segment_sum(dxe, views.in_ptr, None, N)
+            dB1 = ops.segment_sum(dxe, views.out_ptr, views.out_pos, n_local)
+            dB2 = ops.segment_sum(dxe, views.in_ptr, None, n_local)
             parts = [None] * 5
             parts[r["A1"]], parts[r["A2"]], parts[r["A3"]], parts[r["B1"]], parts[r["B2"]] = dv, sum_out, sum_in, dB1, dB2
             for k, name in enumerate(("A_1", "A_2", "A_3", "B_1", "B_2")):
@@ -190,11 +259,12 @@ class _TrainStep(torch.autograd.Function):
             g[pfx1 + ".weight"] = ops.wgrad(dt, x4)[:, :F_].contiguous()
             g[pfx1 + ".bias"] = ops.colsum2(dt)[0] if dt.shape[1] in (16, 32, 64) else dt.sum(0)
 
-        encoder_bwd(dh, tail["x"], None, N, model.linear1_node, model.linear2_node, "linear1_node", "linear2_node")
-        encoder_bwd(de, tail["e_raw"], views.srt_eid, E, model.linear1_edge, model.linear2_edge, "linear1_edge", "linear2_edge")
+        encoder_bwd(dh, tail["x"], None, n_local, model.linear1_node, model.linear2_node, "linear1_node", "linear2_node")
+        encoder_bwd(de, tail["e_raw"], views.srt_eid, e_local, model.linear1_edge, model.linear2_edge, "linear1_edge", "linear2_edge")
 
         ctx.saved = ctx.tail = None
-        return (None, None, None, None, None) + tuple(g[n] for n in ctx.names)
+        grads = sh.sum_ranks([g[n].contiguous() for n in ctx.names])
+        return (None, None, None, None, None) + tuple(grads)
 
 
 def train_forward(model, graph, x, e):
@@ -202,10 +272,18 @@ def train_forward(model, graph, x, e):
     from .engine import compute_device
     device = compute_device(x, e)
     views = views_for(graph, device)
-    names = [n for n, _ in model.named_parameters()]
-    params = [p for _, p in model.named_parameters()]
-    if any(p.device != device for p in params):
-        raise RuntimeError("training needs the model on the compute device: call model.to(device) first")
     xd = x.detach().to(device=device, dtype=torch.float32).contiguous()
     ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
-    return _TrainStep.apply(model, views, xd, ed, names, *params)
+    return train_forward_on(model, WholeGraph(views), xd, ed)
+
+
+def train_forward_on(model, shard, x_local, e_local):
+    """The training step over `shard`'s rows (WholeGraph, or one rank's gnnome_amd.dist.PartitionShard): x_local /
+    e_local are the input features of the shard's nodes / edges (local edge-id order).  Returns logits[E_global, 1],
+    complete on every rank, differentiable w.r.t. the model's parameters; the parameter gradients that
+    `backward()` leaves in `.grad` are already summed over ranks."""
+    names = [n for n, _ in model.named_parameters()]
+    params = [p for _, p in model.named_parameters()]
+    if any(p.device != x_local.device for p in params):
+        raise RuntimeError("training needs the model on the compute device: call model.to(device) first")
+    return _TrainStep.apply(model, shard, x_local, e_local, names, *params)

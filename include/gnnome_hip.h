@@ -226,6 +226,13 @@ int gnnome_encode_hidden_f32(const float* in, int64_t rows, int in_features, con
 int gnnome_gather_rows_f32(const float* in, int ld_in, const int32_t* idx, int64_t rows, int width, float* out,
                            int ld_out, void* stream);
 
+/* out[idx[r],:] += in[r,:]  - the transpose of the halo gather: in the partitioned training step the gradient of
+ * a halo row travels back to the row's owner and is added there (no reference counterpart).  The
+ * rows in idx must be DISTINCT within one call (one peer's block of the exchange plan), which makes the sum
+ * order, and therefore the result, deterministic. */
+int gnnome_scatter_add_rows_f32(const float* in, int ld_in, const int32_t* idx, int64_t rows, int width, float* out,
+                                int ld_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,13 +47,16 @@ def encode(x, W1, b1, W2, b2, gather=None, rows=None):
     return torch.relu(x @ W1.t() + b1) @ W2.t() + b2
 
 
-def linear(A, W, bias, out=None):
+def linear(A, W, bias, out=None, accumulate=False):
     y = A @ W.t()
     if bias is not None:
         y = y + bias
     if out is None:
         return y
-    out.copy_(y)
+    if accumulate:
+        out.add_(y)
+    else:
+        out.copy_(y)
     return out
 
 
@@ -84,10 +87,12 @@ def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_n
     return out
 
 
-def edge_score(e, Ps, Qd, views, W1e, W2, b2, W3, b3, logits, num_edges=None, scatter_to_edge_id=True):
+def edge_score(e, Ps, Qd, views, W1e, W2, b2, W3, b3, logits, num_edges=None, scatter_to_edge_id=True, z1_out=None):
     E = e.shape[0] if num_edges is None else num_edges
     s, d = views.srt_src[:E].long(), views.srt_dst[:E].long()
     z1 = torch.relu(Ps[s] + Qd[d] + e[:E] @ W1e.t())
+    if z1_out is not None:
+        z1_out[:E] = z1
     z2 = torch.relu(z1 @ W2.t() + b2)
     val = z2 @ W3 + b3
     if scatter_to_edge_id:
@@ -103,3 +108,127 @@ def gather_rows(table, idx, out=None):
         return y
     out.copy_(y)
     return out
+
+
+def scatter_add_rows(src, idx, out):
+    assert idx.unique().numel() == idx.numel(), "scatter_add_rows needs distinct rows"
+    out.index_add_(0, idx.long(), src)
+    return out
+
+
+# ---- training-step entries (include/gnnome_hip.h, "Training step") ---------------------------------
+
+def edge_gate_raw(e, B1h, B2h, views, W3):
+    return B1h[views.srt_src.long()] + B2h[views.srt_dst.long()] + e @ W3.t()
+
+
+def node_aggregate_raw(e, A1h, A2h, A3h, views, mode, num_nodes, rows_alloc=None):
+    s, d = views.srt_src.long(), views.srt_dst.long()
+    n_tab, H = A2h.shape
+    sig = torch.sigmoid(e)
+    zeros = torch.zeros((n_tab, H), dtype=torch.float32)
+    rows = num_nodes if rows_alloc is None else max(rows_alloc, num_nodes)
+
+    def cut(t):  # the kernel computes rows < num_nodes only
+        out = torch.zeros((rows, H), dtype=torch.float32)
+        out[:num_nodes] = t[:num_nodes]
+        return out
+
+    sum_in = zeros.index_add(0, d, sig * A2h[s])
+    sum_out = zeros.index_add(0, s, sig * A3h[d])
+    if mode == 2:
+        return cut(sum_in), cut(sum_out)
+    rdf = 1.0 / (zeros.index_add(0, d, sig) + 1e-6)
+    rdb = 1.0 / (zeros.index_add(0, s, sig) + 1e-6)
+    fwd, bwd = sum_in * rdf, sum_out * rdb
+    return cut(A1h + fwd + bwd), cut(fwd), cut(rdf), cut(bwd), cut(rdb)
+
+
+def colsum2(x, y=None, center=None):
+    xc = x if center is None else x - center
+    yc = xc if y is None else y
+    return xc.sum(0), (xc * yc).sum(0)
+
+
+def batch_stats(x):
+    return x.mean(0), x.var(0, unbiased=False)
+
+
+def bn_relu_res(x, scale, shift, res, out=None):
+    y = torch.relu(x * scale + shift) + res
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
+def bn_bwd_stats(dy, x, scale, shift, mean):
+    g = dy * (x * scale + shift > 0)
+    return g.sum(0), (g * (x - mean)).sum(0)
+
+
+def bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd, out=None):
+    dx = a * (dy * (x * scale + shift > 0) - c1 - (x - mean) * rstd * c2)
+    if out is None:
+        return dx
+    out.copy_(dx)
+    return out
+
+
+def mul23(a, b, c):
+    return a * b, a * b * c
+
+
+def add(a, b, out=None):
+    if out is None:
+        return a + b
+    out.copy_(a + b)
+    return out
+
+
+def relu_bwd(dy, y):
+    return dy * (y > 0)
+
+
+def segment_sum(X, ptr, pos, num_nodes, out=None):
+    ptr = ptr.long()
+    counts = ptr[1:num_nodes + 1] - ptr[:num_nodes]
+    seg = torch.repeat_interleave(torch.arange(num_nodes), counts)
+    q = torch.arange(int(ptr[0]), int(ptr[num_nodes]))
+    rows = X[q if pos is None else pos.long()[q]]
+    res = torch.zeros((num_nodes, X.shape[1]), dtype=torch.float32).index_add(0, seg, rows)
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
+def wgrad(A, B, out=None):
+    res = A.t() @ B
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
+def score_tail_bwd(z1, dscore, views, W2, b2, W3):
+    E = z1.shape[0]
+    dl = dscore[views.srt_eid[:E].long()]
+    z2 = torch.relu(z1 @ W2.t() + b2)
+    u = dl[:, None] * z2
+    dz2 = dl[:, None] * W3[None, :] * (z2 > 0)
+    dz1 = (dz2 @ W2) * (z1 > 0)
+    return dz1, dz2, u
+
+
+def agg_edge_bwd(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de):
+    s, d = views.srt_src.long(), views.srt_dst.long()
+    sig = torch.sigmoid(e)
+    de.add_(sig * (1 - sig) * (Tf[d] * A2h[s] - Uf[d] + Tb[s] * A3h[d] - Ub[s]))
+    return de
+
+
+def encode_hidden(x, W1, b1, gather=None, rows=None):
+    if gather is not None:
+        x = x[gather.long()]
+    return torch.relu(x @ W1.t() + b1)

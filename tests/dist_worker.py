@@ -22,14 +22,35 @@ def worker(rank, world, port, case, out_dir):
         from gnnome_amd import dist as gdist
         from gnnome_amd import engine
         g = torch.load(case, weights_only=False)
-        m = gnnome_amd.models.SymGatedGCNModel(2, 2, g["hidden"], 16, g["layers"], 64, "batch").eval()
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, g["hidden"], 16, g["layers"], 64, "batch", dropout=0.0).eval()
         m.load_state_dict(g["state_dict"])
-        cpu = torch.device("cpu")
-        part = gdist.PartitionedGraph.from_global(g["src"], g["dst"], g["num_nodes"], rank, world, cpu, ops=cpu_ops)
-        prep = engine.Prepared(m, cpu)
+        if g.get("device") == "cuda":
+            # both ranks on the one GPU of the test box: HIP kernels as compute, gloo (host-staged) as transport
+            from gnnome_amd import ops as backend
+            where = torch.device("cuda", 0)
+            m.to(where)
+            g = {k: (v.to(where) if k in ("x", "e", "y", "pos_weight") else v) for k, v in g.items()}
+        else:
+            backend, where = cpu_ops, torch.device("cpu")
+        part = gdist.PartitionedGraph.from_global(g["src"], g["dst"], g["num_nodes"], rank, world, where, ops=backend)
+        if g.get("train"):
+            # train.py:138-145 + :328-330 on the partition: every rank computes the loss on the assembled logits
+            import torch.nn.functional as F
+            m.train()
+            runner = gdist.PartitionedRunner(m, part, g["x"], g["e"], where, ops=backend)
+            logits = runner.train_forward()
+            loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), g["y"], pos_weight=g["pos_weight"])
+            loss.backward()
+            torch.save({"logits": logits.detach().squeeze(1).cpu(), "loss": loss.detach().cpu(),
+                        "grads": {k: p.grad.cpu() for k, p in m.named_parameters()},
+                        "buffers": {k: b.detach().cpu().clone() for k, b in m.named_buffers()}, "n_own": part.n_own, "n_local": part.n_local,
+                        "n_score": part.n_score, "e_local": int(part.edge_gid.numel())}, os.path.join(out_dir, f"rank{rank}.pt"))
+            return
+        prep = engine.Prepared(m, where)
         with torch.no_grad():
-            logits = gdist.run_partitioned(cpu_ops, prep, part, part.local_node_rows(g["x"]), part.local_edge_rows(g["e"]))
-        torch.save({"logits": logits, "n_own": part.n_own, "n_local": part.n_local, "n_score": part.n_score,
+            logits = gdist.run_partitioned(backend, prep, part, part.local_node_rows(g["x"]).contiguous(),
+                                           part.local_edge_rows(g["e"]).contiguous())
+        torch.save({"logits": logits.cpu(), "n_own": part.n_own, "n_local": part.n_local, "n_score": part.n_score,
                     "e_local": int(part.edge_gid.numel()), "bounds": part.bounds, "send": part.send_counts,
                     "recv": part.recv_counts}, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:

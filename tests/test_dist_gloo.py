@@ -68,3 +68,51 @@ def test_split_balances_incident_edges():
     loads = [int(deg[b[i]:b[i + 1]].sum()) for i in range(8)]
     assert max(loads) < 1.05 * (sum(loads) / 8)
     assert split_by_incident_edges(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 5, 2)[-1] == 5
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_training_step_matches_reference_golden_g3(world, tmp_path):
+    """SURVEY.md 8e "Training additions": BatchNorm statistics over the whole graph with every edge counted once,
+    halo gradients returned to their owners, parameter gradients summed over ranks - against the golden taken from
+    the reference's classes under autograd on the UNPARTITIONED graph."""
+    from test_train_host import check_grads
+    g = load_golden("g3_train_h64.pt")
+    case = dict(src=g["src"], dst=g["dst"], num_nodes=g["num_nodes"], x=g["x"], e=g["e"], y=g["y"], pos_weight=g["pos_weight"],
+                hidden=64, layers=8, state_dict=random_state_dict(64, seed=g["seed"]), train=True)
+    outs = _run(world, case, tmp_path)
+    assert sum(o["n_score"] for o in outs) == g["src"].numel() and sum(o["e_local"] for o in outs) > 1.05 * g["src"].numel()
+    for o in outs:
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(g["logits"].squeeze(-1))).abs().max().item() < 1e-4
+        assert abs(o["loss"].item() - g["loss"].item()) < 1e-5
+        check_grads(o["grads"], g["grads"], rtol=1e-3)
+        for k, want in g["buffers_after"].items():
+            assert torch.allclose(o["buffers"][k].float(), want.float(), atol=1e-5, rtol=1e-4), k
+    for k in outs[0]["grads"]:   # identical on every rank: optimizers stay in step without a broadcast
+        assert torch.equal(outs[0]["grads"][k], outs[-1]["grads"][k]), k
+
+
+def test_partitioned_training_on_a_mostly_cut_graph_matches_oracle_autograd(tmp_path):
+    """uniform graph at world 3: two thirds of the edges are replicated on two ranks, so nearly every gradient row is
+    assembled from partial sums on different ranks."""
+    from oracle.symgated_oracle import OracleModel, bce_loss
+    from test_train_host import check_grads
+    n, e = 400, 4000
+    gr = make_graph(n, e, seed=4, kind="uniform")
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(64, num_layers=3, seed=2)
+    om = OracleModel(2, 2, 64, 16, 3, 64, "batch", dropout=0.0)
+    om.load_state_dict(sd)
+    om.train()
+    want = om((gr["src"], gr["dst"], n), x, gr["e"])
+    want_loss = bce_loss(want, gr["y"], gr["pos_weight"])
+    want_loss.backward()
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], y=gr["y"], pos_weight=gr["pos_weight"], hidden=64, layers=3,
+                state_dict=sd, train=True)
+    outs = _run(3, case, tmp_path)
+    assert sum(o["e_local"] for o in outs) > 1.5 * e
+    for o in outs:
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(want.detach().squeeze(-1))).abs().max().item() < 1e-4
+        assert abs(o["loss"].item() - want_loss.item()) < 1e-5
+        check_grads(o["grads"], {k: p.grad for k, p in om.named_parameters()}, rtol=2e-3)
+        for k, b in om.named_buffers():
+            assert torch.allclose(o["buffers"][k].float(), b.float(), atol=1e-5, rtol=1e-4), k
