@@ -680,6 +680,39 @@ __device__ __forceinline__ void gate_ws_sweep(f32x16& acc, const float* ap, cons
     }
 }
 
+// Slot hand-over without workgroup barriers (FLAGS variant): two monotone counters per ring slot in LDS.
+//   full[s]: +1 by each of the two load waves of the slot's group once its share of a tile is written (2 per tile)
+//   done[s]: +1 by each compute wave once it has finished BOTH uses of a tile (MFMA operand, then residual/G rows
+//            in the next iteration's epilogue) (4 per tile)
+// A wave's DS instructions execute in order, so a counter bump issued after the data accesses is ordered behind
+// them without any s_waitcnt - in particular a compute wave never waits for its e' stores here, which a
+// workgroup-scope release fence (vmcnt(0)) would make it do every tile.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void flag_wait(unsigned addr, unsigned want, int nap = 3) {
+    unsigned v, spins = 0;
+    for (;;) {
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        if (__builtin_amdgcn_readfirstlane(v) >= want) break;
+        if (++spins > (1u << 22)) __builtin_trap();  // a lost hand-over must end the launch, not hang the queue
+        // consumers (nap 3) poll tightly: their wait is on the critical path.  Producers run a whole slot ahead and
+        // poll rarely (nap 0 = 64 x 64 cycles): their ds_reads compete with the compute waves' operand reads.
+        if (nap == 0) {
+            __builtin_amdgcn_s_sleep(64);
+        } else if (nap == 1) {
+            __builtin_amdgcn_s_sleep(16);
+        } else if (nap == 2) {
+            __builtin_amdgcn_s_sleep(4);
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+__device__ __forceinline__ void flag_bump(unsigned addr, int lane) {
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+}
+
 // ENC (layer 0 only): the e tile is not loaded but COMPUTED by the load waves from the raw edge features,
 // e0[p,:] = W2e * relu(W1e * e_raw[srt_eid[p],:] + b1e) + b2e (models/full_graph.py:27, in_features = 2,
 // hidden_ne = 16): the edge encoder's [E,H] output is never written to or read from HBM.
@@ -689,12 +722,12 @@ struct GateEnc {
     const float *W1, *b1, *W2, *b2;   // [16,2] [16] [H,16] [H]
 };
 
-template <int CB, int RB, int ABL, bool ENC>
+template <int CB, int RB, int ABL, bool ENC, bool FLAGS>
 __global__ __launch_bounds__(768) void k_edge_gate_ws(
     const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
     const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
     const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block, int interleave,
-    GateEnc enc) {
+    GateEnc enc, int xp) {
     using P = GateWS<CB, RB>;
     constexpr int H = P::H, TM = P::TM, LDK = P::LDK, QS = H / 8, EPQ = 16 / QS, NP = P::NP, SLOT = P::kSlotFloats;
     constexpr int kEncFloats = ENC ? 16 * H + H + 48 : 0;  // W2^T [16][H], b2 [H], W1 [32], b1 [16]
@@ -705,9 +738,11 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
     float* b2s = w2t + 16 * H;
     float* w1s = b2s + H;
     float* b1s = w1s + 32;
+    __shared__ unsigned flags[8];             // FLAGS only: full[4], done[4]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned full0 = lds_addr(&flags[0]), done0 = lds_addr(&flags[4]);
     // Tile order.  chunked: workgroup b owns the contiguous run [b*tpb, (b+1)*tpb).  interleaved: in round r the
     // whole chip works on ONE contiguous window of gridDim.x tiles (DRAM row locality for the e stream in and
     // out), and inside the window every XCD (blocks b % 8) gets a contiguous sub-window so that neighbouring
@@ -729,8 +764,9 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
         for (int i = tid; i < H; i += P::NT) b2s[i] = enc.b2[i];
         if (tid < 32) w1s[tid] = enc.W1[tid];
         if (tid < 16) b1s[tid] = enc.b1[tid];
-        __syncthreads();
     }
+    if (FLAGS && tid < 8) flags[tid] = 0;
+    if (ENC || FLAGS) __syncthreads();
 
     if (wave < 4) {
         // ------------------------------------------------------------------ compute wave
@@ -750,8 +786,10 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
         const uint32_t lane_glb = (uint32_t)(lrow * H + col);
         auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
 
-        __syncthreads();  // iteration -1: the load waves hand over tile 0
+        if (!FLAGS) __syncthreads();  // iteration -1: the load waves hand over tile 0
+        if (xp & 1) __builtin_amdgcn_s_setprio(3);
         for (int i = 0; i < n; ++i) {
+            if (FLAGS) flag_wait(full0 + 4 * (i & 3), 2u * ((unsigned)(i >> 2) + 1u));
             const float* As = Aring + (i & 3) * SLOT;
             // previous tile (i-1): its G rows and its e rows (the residual) are still in the ring
             const float* Gp = Gring + ((i - 1) & 3) * SLOT + lane_lds;
@@ -770,7 +808,11 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) accp[r] = acc[r];
-            __syncthreads();
+            if (FLAGS) {
+                if (i >= 1) flag_bump(done0 + 4 * ((i - 1) & 3), lane);   // tile i-1: operand and residual reads are over
+            } else {
+                __syncthreads();
+            }
         }
         // drain: epilogue of the last tile
         {
@@ -844,6 +886,25 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
             issue(group);
             if (ENC) encode_pending();
         }
+        if (FLAGS) {
+            // this group's tiles: group, group + 4, ...; each waits only for its own slot to be free
+            for (int r = group; r < n; r += 4) {
+                flag_wait(done0 + 4 * group, 4u * (unsigned)(r >> 2), (xp >> 1) & 3);
+                float* As = Aring + group * SLOT;
+                float* Gs = Gring + group * SLOT;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    *reinterpret_cast<f32x4*>(As + (r0 + p * RSTEP) * LDK + 4 * c4) = a[p];
+                    *reinterpret_cast<f32x4*>(Gs + (r0 + p * RSTEP) * LDK + 4 * c4) = g1[p] + g2[p];
+                }
+                flag_bump(full0 + 4 * group, lane);
+                if (r + 4 < n) {
+                    issue(r + 4);
+                    if (ENC) encode_pending();
+                }
+            }
+            return;
+        }
         for (int i = -1; i < n; ++i) {
             if (ENC && i + 3 >= 4 && i + 3 < n && ((i + 3) & 3) == group) encode_pending();   // tile i+3, handed over at i+2
             const int r = i + 1;  // tile to hand over this iteration
@@ -872,23 +933,33 @@ static int launch_gate_ws(const float* e_in, float* e_out, int64_t E, const floa
     const int tpb = (int)((tiles + kNumCUs - 1) / kNumCUs);  // one resident workgroup per CU (LDS-limited)
     const int interleave = tuning(kTuneGateTileOrder) == 1 ? 0 : 1;
     const int grid = interleave ? kNumCUs : (int)((tiles + tpb - 1) / tpb);
+    const bool flags = tuning(kTuneGateVariant) != 6;   // 6 = hand-over through workgroup barriers (the earlier form)
+    const int xp = tuning(kTuneGateExperiment);
     if (enc != nullptr) {
-        hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, true>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd,
-                           W3, ldw, scale, shift, (int)tiles, tpb, interleave, *enc);
+        if (flags) {
+            hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, true, true>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn,
+                               ss, sd, W3, ldw, scale, shift, (int)tiles, tpb, interleave, *enc, xp);
+        } else {
+            hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, true, false>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn,
+                               ss, sd, W3, ldw, scale, shift, (int)tiles, tpb, interleave, *enc, xp);
+        }
         GN_LAUNCH_CHECK();
         return GNNOME_OK;
     }
     const GateEnc none = {};
-#define GN_WS_ABL(M)                                                                                                        \
-    case M:                                                                                                                 \
-        hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, M, false>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, \
-                           ss, sd, W3, ldw, scale, shift, (int)tiles, tpb, interleave, none);                              \
+#define GN_WS_ABL(M)                                                                                                              \
+    case M:                                                                                                                       \
+        if (flags) {                                                                                                              \
+            hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, M, false, true>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, \
+                               ldn, ss, sd, W3, ldw, scale, shift, (int)tiles, tpb, interleave, none, xp);                            \
+        } else {                                                                                                                  \
+            hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, M, false, false>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h,     \
+                               B2h, ldn, ss, sd, W3, ldw, scale, shift, (int)tiles, tpb, interleave, none, xp);                       \
+        }                                                                                                                         \
         break;
     switch (tuning(kTuneGateAblation)) {
         GN_WS_ABL(1) GN_WS_ABL(2) GN_WS_ABL(4) GN_WS_ABL(8) GN_WS_ABL(7) GN_WS_ABL(15) GN_WS_ABL(16)
-        default:
-            hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, false>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn,
-                               ss, sd, W3, ldw, scale, shift, (int)tiles, tpb, interleave, none);
+        default: GN_WS_ABL(0)
     }
 #undef GN_WS_ABL
     GN_LAUNCH_CHECK();
@@ -969,7 +1040,7 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
     const bool rows16 = ld_node % 4 == 0 && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0);
     const bool persistent_ok = norm_kind == GNNOME_NORM_AFFINE && (hidden == 64 || hidden == 128);
     if (persistent_ok && variant != 1) {
-        if ((variant == 0 || variant == 5) && rows16) {
+        if ((variant == 0 || variant == 5 || variant == 6) && rows16) {
             if (hidden == 128)
                 return launch_gate_ws<4, 1>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
             return launch_gate_ws<2, 2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);

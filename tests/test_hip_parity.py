@@ -152,7 +152,7 @@ def test_edge_gate(hidden, norm, e_base):
     assert torch.equal(out, e_dev)
     # every kernel variant behind the entry point (gnnome_set_tuning key 0) must meet the same contract
     try:
-        for variant in (1, 2, 3, 4, 5):
+        for variant in (1, 2, 3, 4, 5, 6):
             ops.set_tuning(0, variant)
             e_var = d["e"].clone()
             ops.edge_gate(e_var, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], norm, d["scale"], d["shift"])
@@ -226,6 +226,12 @@ def test_edge_gate_with_folded_encoder(hidden, e_count):
     assert ops.can_fuse_edge_encoder(e_raw.to(dev()), enc_d, H, 0, d["P"][:, 3 * H:4 * H])
     got = ops.edge_gate_encode(e_raw.to(dev()), enc_d, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], d["scale"], d["shift"])
     _assert_close(got, want, scale=20.0)
+    try:  # slot hand-over through workgroup barriers instead of LDS counters: same arithmetic, same bits
+        ops.set_tuning(0, 6)
+        alt = ops.edge_gate_encode(e_raw.to(dev()), enc_d, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], d["scale"], d["shift"])
+    finally:
+        ops.set_tuning(0, 0)
+    assert torch.equal(alt, got)
 
 
 def test_gather_rows():
