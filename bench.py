@@ -200,31 +200,33 @@ def main():
 
     n, e, hidden = WORKLOADS[args.workload]
     g = make_graph(n, e, seed=1, kind=args.kind)
-    x_cpu = degree_features(g["src"], g["dst"], n)
+    x_cpu = degree_features(g["src"], g["dst"], n) if world > 1 else None   # N=1 prepares them on the device
     model = gnnome_amd.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch").eval()
     model.load_state_dict(random_state_dict(hidden, seed=1))
     model.to(dev)
 
     if world == 1:
         src, dst = g["src"].to(dev), g["dst"].to(dev)
-        x, ef = x_cpu.to(dev), g["e"].to(dev)
+        ef = g["e"].to(dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         views = ops.GraphViews(src, dst, n)
+        x = ops.degree_features(views)   # inference.py:416-420 on the device, off the views' CSR pointers
         model(views, x, ef)
         torch.cuda.synchronize()
         cold_ms = (time.perf_counter() - t0) * 1e3
 
         if args.mode == "train":
             # train.py:138-145 (get_bce_loss_full) + :328-330, dropout 0 as in the parity fixtures
-            import torch.nn.functional as F
             model.train()
             opt = torch.optim.Adam(model.parameters(), lr=1e-4)
             y, pw = g["y"].to(dev), g["pos_weight"].to(dev)
 
+            from gnnome_amd.loss import bce_loss
+
             def eager_step():
                 logits = model(views, x, ef)
-                loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), y, pos_weight=pw)
+                loss = bce_loss(logits.squeeze(-1), y, pw)   # train.py:144, one fused pass (value + d/dlogits)
                 opt.zero_grad(set_to_none=False)
                 loss.backward()
                 opt.step()
@@ -274,13 +276,14 @@ def main():
         if args.mode == "train":
             # configs[4]'s step: partitioned fwd + BCE + bwd (BatchNorm statistics, halo gradients and parameter
             # gradients cross ranks inside runner.train_forward / backward) + Adam on every rank
-            import torch.nn.functional as F
             opt = torch.optim.Adam(model.parameters(), lr=1e-4)
             y, pw = g["y"].to(dev), g["pos_weight"].to(dev)
 
+            from gnnome_amd.loss import bce_loss
+
             def step():
                 logits = runner.train_forward()
-                loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), y, pos_weight=pw)
+                loss = bce_loss(logits.squeeze(-1), y, pw)
                 opt.zero_grad(set_to_none=False)
                 loss.backward()
                 opt.step()

@@ -45,6 +45,10 @@ SIGNATURES = {
     "gnnome_encode_hidden_f32": [_p, _l, _i, _p, _p, _p, _i, _p, _p],
     "gnnome_gather_rows_f32": [_p, _i, _p, _l, _i, _p, _i, _p],
     "gnnome_scatter_add_rows_f32": [_p, _i, _p, _l, _i, _p, _i, _p],
+    "gnnome_closure_workspace_bytes": [ctypes.POINTER(_sz)],
+    "gnnome_degree_features_f32": [_p, _p, _l, _i, _p, _p, _sz, _p],
+    "gnnome_edge_features_f32": [_p, _p, _l, _p, _p, _sz, _p],
+    "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
 ABI_VERSION = 2

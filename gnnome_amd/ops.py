@@ -398,3 +398,54 @@ def encode_hidden(x, W1, b1, gather=None, rows=None):
     t = torch.empty((rows, W1.shape[0]), dtype=torch.float32, device=x.device)
     _call("gnnome_encode_hidden_f32", x.device, _ptr(x), rows, x.shape[1], _ptr(gather), _ptr(W1), _ptr(b1), W1.shape[0], _ptr(t))
     return t
+
+
+# ---------------------------------------------------------------------------------------------------
+# callers' closure (include/gnnome_hip.h, "The callers' arithmetic either side of the model call")
+# ---------------------------------------------------------------------------------------------------
+
+def _closure_workspace(device):
+    need = ctypes.c_size_t(0)
+    _lib.check(_lib.load().gnnome_closure_workspace_bytes(ctypes.byref(need)), "closure_workspace_bytes")
+    return torch.empty(int(need.value), dtype=torch.uint8, device=device)
+
+
+def degree_features(views, reverse=False):
+    """x[N,2] = z-scored in/out degree read off the views' CSR pointers (inference.py:416-420; train.py:112-122)."""
+    x = torch.empty((views.num_nodes, 2), dtype=torch.float32, device=views.device)
+    ws = _closure_workspace(views.device)
+    swap = bool(reverse) != bool(views.transposed)  # a transposed view already has in <-> out exchanged
+    _call("gnnome_degree_features_f32", views.device, _ptr(views.in_ptr), _ptr(views.out_ptr), views.num_nodes, int(swap), _ptr(x),
+          _ptr(ws), ws.numel())
+    return x
+
+
+def edge_features(overlap_length, overlap_similarity):
+    """e[E,2] = [zscore(overlap_length) | overlap_similarity] (utils/data_utils.py:31-41)."""
+    ol = _dense(overlap_length.float(), "edge_features.overlap_length")
+    sim = _dense(overlap_similarity.float(), "edge_features.overlap_similarity")
+    if ol.shape != sim.shape or ol.dim() != 1:
+        raise ValueError("edge_features: overlap_length and overlap_similarity must be 1-d and equally long")
+    e = torch.empty((ol.numel(), 2), dtype=torch.float32, device=ol.device)
+    ws = _closure_workspace(ol.device)
+    _call("gnnome_edge_features_f32", ol.device, _ptr(ol), _ptr(sim), ol.numel(), _ptr(e), _ptr(ws), ws.numel())
+    return e
+
+
+def edge_loss(logits, logits_rev, labels, pos_weight, alpha=0.0, need_grad=True, need_counts=False):
+    """-> (loss[1], d loss/d logits, d loss/d logits_rev, tfpn int64[4]); entries not asked for are None."""
+    a = _dense(logits, "edge_loss.logits")
+    b = None if logits_rev is None else _dense(logits_rev, "edge_loss.logits_rev")
+    y = _dense(labels, "edge_loss.labels")
+    E = a.numel()
+    if a.dim() != 1 or y.shape != a.shape or (b is not None and b.shape != a.shape):
+        raise ValueError("edge_loss: logits, logits_rev and labels must be 1-d and equally long")
+    pw = torch.as_tensor(pos_weight, dtype=torch.float32).reshape(1).to(a.device)
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    da = torch.empty_like(a) if need_grad else None
+    db = torch.empty_like(a) if need_grad and b is not None else None
+    tfpn = torch.empty(4, dtype=torch.int64, device=a.device) if need_counts else None
+    ws = _closure_workspace(a.device)
+    _call("gnnome_edge_loss_f32", a.device, _ptr(a), _ptr(b), _ptr(y), E, _ptr(pw), float(alpha), 1.0 / max(E, 1), _ptr(loss),
+          _ptr(da), _ptr(db), _ptr(tfpn), _ptr(ws), ws.numel())
+    return loss, da, db, tfpn

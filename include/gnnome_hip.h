@@ -233,6 +233,33 @@ int gnnome_gather_rows_f32(const float* in, int ld_in, const int32_t* idx, int64
 int gnnome_scatter_add_rows_f32(const float* in, int ld_in, const int32_t* idx, int64_t rows, int width, float* out,
                                 int ld_out, void* stream);
 
+/* ================================================================================================
+ * The callers' arithmetic either side of the model call: feature preparation
+ * before it, loss and confusion counts after it.  Deterministic reductions; `workspace` for all three is
+ * gnnome_closure_workspace_bytes() bytes, 8-byte aligned.
+ * ================================================================================================ */
+int gnnome_closure_workspace_bytes(size_t* bytes_host);
+
+/* x[N,2] = [zscore(in_degree) | zscore(out_degree)] (columns swapped when `reverse`), degrees read off the CSR
+ * pointers of the graph views, mean and UNBIASED std as torch.mean / torch.std.
+ * Replaces inference.py:416-420 and train.py:112-122 (get_full_ne_features). */
+int gnnome_degree_features_f32(const int32_t* in_ptr, const int32_t* out_ptr, int64_t num_nodes, int reverse, float* x,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* e[E,2] = [zscore(overlap_length) | overlap_similarity], unbiased std.
+ * Replaces utils/data_utils.py:31-41 (preprocess_graph with use_similarities, configs/hyperparameters.py:17). */
+int gnnome_edge_features_f32(const float* overlap_length, const float* overlap_similarity, int64_t num_edges, float* e,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* loss[0] = mean_i ( bce(logits_i) [+ bce(logits_rev_i) + alpha |logits_i - logits_rev_i|] ),
+ * bce = F.binary_cross_entropy_with_logits(., labels, pos_weight) - train.py:144 (logits_rev NULL) and
+ * train.py:103-109 symmetry_loss (logits_rev given).  pos_weight: DEVICE scalar.  dlogits / dlogits_rev (NULL: skip) =
+ * grad_scale * d(sum of per-edge terms)/d logits, so grad_scale = 1/E gives the gradient of the mean.
+ * tfpn (NULL: skip) = int64[4] TP, TN, FP, FN of round(sigmoid(logits)) against labels - utils/metrics.py:6-12. */
+int gnnome_edge_loss_f32(const float* logits, const float* logits_rev, const float* labels, int64_t num_edges,
+                         const float* pos_weight, float alpha, float grad_scale, float* loss, float* dlogits,
+                         float* dlogits_rev, int64_t* tfpn, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,3 +118,23 @@ def test_known_answers_without_any_reference(shipped_weights):
     assert (torch.sigmoid(a[perm]) - torch.sigmoid(b)).abs().max().item() < 1e-5
     assert empty.shape == (0, 1)
     assert F.relu(torch.tensor(-1.0)).item() == 0.0
+
+
+def test_g7_callers_closure_loss_metrics_and_feature_preparation():
+    """The oracle's statements of the functions either side of the model call against the reference's own
+    (tests/golden/make_golden_closure.py): train.py:103-109,112-122,144; utils/data_utils.py:31-41; utils/metrics.py:6-12."""
+    from oracle.symgated_oracle import calculate_tfpn, edge_features
+    g = load_golden("g7_closure.pt")
+    org, rev = g["org"].clone().requires_grad_(), g["rev"].clone().requires_grad_()
+    sym = symmetry_loss(org, rev, g["labels"], g["pos_weight"], g["alpha"])
+    sym.backward()
+    assert torch.equal(sym.detach(), g["symmetry_loss"])
+    assert torch.equal(org.grad, g["symmetry_grad_org"]) and torch.equal(rev.grad, g["symmetry_grad_rev"])
+    org.grad = None
+    bce = bce_loss(org.unsqueeze(-1), g["labels"], g["pos_weight"])
+    bce.backward()
+    assert torch.equal(bce.detach(), g["bce_loss"]) and torch.equal(org.grad, g["bce_grad"])
+    assert calculate_tfpn(g["org"], g["labels"]) == g["tfpn"] and calculate_tfpn(g["rev"], g["labels"]) == g["tfpn_rev"]
+    assert torch.equal(degree_features(g["src"], g["dst"], g["num_nodes"]), g["x"])
+    assert torch.equal(degree_features(g["src"], g["dst"], g["num_nodes"], reverse=True), g["x_reversed"])
+    assert torch.equal(edge_features(g["overlap_length"], g["overlap_similarity"]), g["e"])
