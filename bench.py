@@ -302,7 +302,7 @@ def main():
     # the same shape): a pair around every launch of every kernel cost ~1.6 ms per step here (56 events, ~28 us
     # of pipeline bubble each) and inflated what it measured; a pair per gate launch still cost ~0.4 ms.
     # (N>1: rank 0 times its own launches; its gate kernel covers the edges incident to its node range)
-    dominant = [] if args.no_kernel_timers else (["edge_gate"] if args.mode == "infer" else ["edge_gate_raw"])
+    dominant = [] if args.no_kernel_timers else (["edge_gate"] if args.mode == "infer" else ["edge_gate_raw_stats"])
     e_gate = e if world == 1 else plan.views.num_edges
     with KernelTimer(ops, dominant, every=8) as kt:
         for _ in range(args.warmup):
@@ -351,12 +351,12 @@ def main():
         if args.mode == "train":
             res["hbm_roofline_frac_whole_step_3xBfwd"] = (3 * b_fwd / (ms * 1e-3)) / (world * HBM_PEAK)
             res["mfma_f32_frac_whole_step_3xFfwd"] = (3 * f_fwd / (ms * 1e-3)) / (world * MFMA_F32_PEAK)
-        if timed:
+        if timed and kt.events[timed[0]]:
             gate_ms, gate_n = kt.mean_ms(timed[0])
             gate_flops = 2.0 * e_gate * hidden * hidden
             res["roofline"] = {
                 "kernel": "k_edge_gate_ws (fused B_3 GEMM + u_add_v + bn_e + relu + residual)" if args.mode == "infer" else
-                          "k_edge_gate<raw> (B_3 GEMM + u_add_v, pre-BatchNorm output)", "bound": "mfma",
+                          "k_edge_gate_ws<raw> (B_3 GEMM + u_add_v + BatchNorm batch-statistic partial sums; followed by 3 small torch ops and one column-sum launch inside the timed interval)", "bound": "mfma",
                 "achieved": gate_flops / (gate_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": gate_flops / (gate_ms * 1e-3) / MFMA_F32_PEAK,
                 "traffic": _pmc_traffic(args, hidden, e) if world == 1 else None,

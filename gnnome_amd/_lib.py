@@ -29,10 +29,13 @@ SIGNATURES = {
     "gnnome_node_aggregate_f32": [_p, _i, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
     "gnnome_edge_score_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_edge_gate_raw_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p],
+    "gnnome_edge_gate_raw_stats_rows": [_i, ctypes.POINTER(_i)],
+    "gnnome_edge_gate_raw_stats_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
     "gnnome_node_aggregate_raw_f32": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    "gnnome_colsum2_f32": [_p, _p, _l, _i, _p, _p, _p, _p],
+    "gnnome_colsum_workspace_bytes": [ctypes.POINTER(_sz)],
+    "gnnome_colsum2_f32": [_p, _p, _l, _i, _p, _p, _p, _p, _sz, _p],
     "gnnome_bn_relu_res_f32": [_p, _p, _p, _p, _l, _i, _p, _p],
-    "gnnome_bn_bwd_stats_f32": [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p],
+    "gnnome_bn_bwd_stats_f32": [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _sz, _p],
     "gnnome_bn_bwd_apply_f32": [_p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_mul23_f32": [_p, _p, _p, _l, _p, _p, _p],
     "gnnome_add_f32": [_p, _p, _l, _p, _p],
@@ -51,7 +54,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

@@ -14,6 +14,10 @@ void set_error(const char* fmt, ...);
 enum { kTuneGateVariant = 0, kTuneGateAblation = 1, kTuneLinearVariant = 2, kTuneGateTileOrder = 3, kTuneGateExperiment = 4, kTuneCount = 8 };
 int tuning(int key);
 
+// C[M,K] += A[M,K] * W[K,K]^T for K in {64,128}, contiguous 16-byte aligned A and C: the wave-specialised
+// edge-tile kernel (edge_gate.hip) in accumulate mode; linear.hip routes the backward's [E,H] dgrad here.
+int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, float* C, hipStream_t s);
+
 #define GN_REQUIRE(cond, ...)                 \
     do {                                      \
         if (!(cond)) {                        \

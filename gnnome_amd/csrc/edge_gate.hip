@@ -617,10 +617,13 @@ struct GateWS {
 // FULL = every row of the previous tile exists: unconditional stores, so a k-step is one basic block and the
 // sched_group_barrier pattern below can place the epilogue's LDS reads / VALU / store in the issue gaps that the
 // dependent MFMA chain leaves (an MFMA blocks only the next MFMA; anything else issues under it).
-template <int H, bool FULL, int ABL>
+// MODE 0: y = relu((acc + G) * sc + sh) + residual (the gate);  MODE >= 1: y = acc + G (raw: the input of a train-mode
+// BatchNorm, or C += A * W^T with G = the old rows of C), with the shifted column sums s1 += y - sc, s2 += (y - sc)^2
+// for the batch statistics when STATS (sc then carries the column's centre, sh is unused).
+template <int H, bool FULL, int ABL, int MODE = 0, bool STATS = false>
 __device__ __forceinline__ void gate_ws_sweep(f32x16& acc, const float* ap, const f32x4 (&wv)[H / 8], const float (&accp)[16],
                                               const float* Gp, const float* Ap, float* out_p, uint32_t lane_glb, int valid_p,
-                                              float sc, float sh) {
+                                              float sc, float sh, float& s1, float& s2) {
     constexpr int LDK = H + 4, QS = H / 8, EPQ = 16 / QS;
     auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
     f32x4 a_cur = *reinterpret_cast<const f32x4*>(ap);  // (ABL: measurement-only ablation mask, 0 in the shipped kernel)
@@ -628,7 +631,7 @@ __device__ __forceinline__ void gate_ws_sweep(f32x16& acc, const float* ap, cons
 #pragma unroll
     for (int j = 0; j < EPQ; ++j) {
         g_cur[j] = Gp[crow(j) * LDK];
-        r_cur[j] = Ap[crow(j) * LDK];
+        r_cur[j] = MODE == 0 ? Ap[crow(j) * LDK] : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < QS; ++q) {
@@ -639,7 +642,7 @@ __device__ __forceinline__ void gate_ws_sweep(f32x16& acc, const float* ap, cons
 #pragma unroll
         for (int j = 0; j < EPQ; ++j) {
             g_nxt[j] = Gp[crow(qn * EPQ + j) * LDK];
-            r_nxt[j] = Ap[crow(qn * EPQ + j) * LDK];
+            r_nxt[j] = MODE == 0 ? Ap[crow(qn * EPQ + j) * LDK] : 0.f;
         }
         if (!(ABL & 8)) {
 #pragma unroll
@@ -650,7 +653,12 @@ __device__ __forceinline__ void gate_ws_sweep(f32x16& acc, const float* ap, cons
 #pragma unroll
         for (int j = 0; j < EPQ; ++j) {
             const int r = q * EPQ + j;
-            const float y = fmaxf((accp[r] + g_cur[j]) * sc + sh, 0.f) + r_cur[j];
+            const float y = MODE == 0 ? fmaxf((accp[r] + g_cur[j]) * sc + sh, 0.f) + r_cur[j] : accp[r] + g_cur[j];
+            if (STATS && (FULL || crow(r) < valid_p)) {
+                const float d = y - sc;
+                s1 += d;
+                s2 = fmaf(d, d, s2);
+            }
             if (ABL & 2) {
                 asm volatile("" ::"v"(y));
             } else if (FULL || crow(r) < valid_p) {
@@ -663,7 +671,7 @@ __device__ __forceinline__ void gate_ws_sweep(f32x16& acc, const float* ap, cons
         }
         if (FULL) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1 + 2 * EPQ, 0);  // LDS reads for the next step
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + (MODE == 0 ? 2 : 1) * EPQ, 0);  // LDS reads for the next step
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 4 * EPQ, 0);      // epilogue VALU
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -722,12 +730,17 @@ struct GateEnc {
     const float *W1, *b1, *W2, *b2;   // [16,2] [16] [H,16] [H]
 };
 
-template <int CB, int RB, int ABL, bool ENC, bool FLAGS>
+// MODE 0: the gate.  MODE 1: raw gate x = B1h[src] + B2h[dst] + e W3^T (train mode), with per-workgroup shifted
+// column sums for the BatchNorm batch statistics written to `stats` ([gridDim.x * RB][2H]; `scale` = the centre).
+// MODE 2: C += A W^T on [E,H] rows (the backward's d e_in = d e' + dxe W3): G = the old rows of C, passed as B1h
+// with ldn = H; srt_src / srt_dst / B2h unused.
+template <int CB, int RB, int ABL, bool ENC, bool FLAGS, int MODE = 0>
 __global__ __launch_bounds__(768) void k_edge_gate_ws(
-    const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
+    const float* e_in, float* e_out, int64_t E, const float* B1h, const float* __restrict__ B2h, int ldn,
     const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
     const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block, int interleave,
-    GateEnc enc, int xp) {
+    GateEnc enc, int xp, float* __restrict__ stats = nullptr) {
+    static_assert(MODE == 0 || (FLAGS && !ENC && ABL == 0), "raw modes: counter hand-over only");
     using P = GateWS<CB, RB>;
     constexpr int H = P::H, TM = P::TM, LDK = P::LDK, QS = H / 8, EPQ = 16 / QS, NP = P::NP, SLOT = P::kSlotFloats;
     constexpr int kEncFloats = ENC ? 16 * H + H + 48 : 0;  // W2^T [16][H], b2 [H], W1 [32], b1 [16]
@@ -775,7 +788,8 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
         f32x4 wv[QS];  // this lane's B operands: W3[col][8q + 4*half .. +3]
 #pragma unroll
         for (int q = 0; q < QS; ++q) wv[q] = *reinterpret_cast<const f32x4*>(W3 + (int64_t)col * ldw + 8 * q + 4 * half);
-        const float sc = scale[col], sh = shift[col];
+        const float sc = MODE == 2 ? 0.f : scale[col], sh = MODE == 0 ? shift[col] : 0.f;   // MODE 1: sc = the column's centre
+        float s1 = 0.f, s2 = 0.f;
         float accp[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) accp[r] = 0.f;
@@ -802,9 +816,9 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const float* ap = As + (32 * rb + cl) * LDK + 4 * half;
             if (valid_p + lrow >= TM) {  // wave-uniform: every row of the previous tile exists
-                gate_ws_sweep<H, true, ABL>(acc, ap, wv, accp, Gp, Ap, out_p, lane_glb, valid_p, sc, sh);
+                gate_ws_sweep<H, true, ABL, MODE, MODE == 1>(acc, ap, wv, accp, Gp, Ap, out_p, lane_glb, valid_p, sc, sh, s1, s2);
             } else {                     // first iteration (nothing pending) or the ragged last tile
-                gate_ws_sweep<H, false, ABL>(acc, ap, wv, accp, Gp, Ap, out_p, lane_glb, valid_p, sc, sh);
+                gate_ws_sweep<H, false, ABL, MODE, MODE == 1>(acc, ap, wv, accp, Gp, Ap, out_p, lane_glb, valid_p, sc, sh, s1, s2);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) accp[r] = acc[r];
@@ -824,8 +838,25 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
             for (int r = 0; r < 16; ++r) {
                 if (crow(r) < valid_p) {
                     const float x = accp[r] + Gp[crow(r) * LDK];
-                    (out_p + crow(r) * H)[lane_glb] = fmaxf(x * sc + sh, 0.f) + Ap[crow(r) * LDK];
+                    if (MODE == 0) {
+                        (out_p + crow(r) * H)[lane_glb] = fmaxf(x * sc + sh, 0.f) + Ap[crow(r) * LDK];
+                    } else {
+                        (out_p + crow(r) * H)[lane_glb] = x;
+                        if (MODE == 1) {
+                            s1 += x - sc;
+                            s2 = fmaf(x - sc, x - sc, s2);
+                        }
+                    }
                 }
+            }
+        }
+        if (MODE == 1) {  // lanes l and l + 32 hold different rows of the same column
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (half == 0) {
+                float* dst = stats + ((int64_t)blockIdx.x * RB + rb) * 2 * H;
+                dst[col] = s1;
+                dst[H + col] = s2;
             }
         }
     } else {
@@ -848,8 +879,10 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
-                si[p] = srt_src[row];
-                di[p] = srt_dst[row];
+                if (MODE != 2) {
+                    si[p] = srt_src[row];
+                    di[p] = srt_dst[row];
+                }
                 if (ENC) ei[p] = enc.srt_eid[row];
             }
 #pragma unroll
@@ -862,7 +895,9 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
                     const f32x4* src = reinterpret_cast<const f32x4*>(e_in + row * H + 4 * c4);
                     a[p] = (ABL & 16) ? __builtin_nontemporal_load(src) : *src;  // 16: streamed once, keep it out of L1
                 }
-                if (!(ABL & 1)) {
+                if (MODE == 2) {
+                    g1[p] = *reinterpret_cast<const f32x4*>(B1h + row * ldn + 4 * c4);   // the old rows of C
+                } else if (!(ABL & 1)) {
                     g1[p] = *reinterpret_cast<const f32x4*>(B1h + (int64_t)si[p] * ldn + 4 * c4);
                     g2[p] = *reinterpret_cast<const f32x4*>(B2h + (int64_t)di[p] * ldn + 4 * c4);
                 }
@@ -895,7 +930,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     *reinterpret_cast<f32x4*>(As + (r0 + p * RSTEP) * LDK + 4 * c4) = a[p];
-                    *reinterpret_cast<f32x4*>(Gs + (r0 + p * RSTEP) * LDK + 4 * c4) = g1[p] + g2[p];
+                    *reinterpret_cast<f32x4*>(Gs + (r0 + p * RSTEP) * LDK + 4 * c4) = MODE == 2 ? g1[p] : g1[p] + g2[p];
                 }
                 flag_bump(full0 + 4 * group, lane);
                 if (r + 4 < n) {
@@ -964,6 +999,41 @@ static int launch_gate_ws(const float* e_in, float* e_out, int64_t E, const floa
 #undef GN_WS_ABL
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
+}
+
+// train mode: raw gate + per-workgroup shifted column sums (see k_edge_gate_ws MODE 1)
+template <int CB, int RB>
+static int launch_ws_raw_stats(const float* e_in, float* x_out, int64_t E, const float* B1h, const float* B2h, int ldn,
+                               const int32_t* ss, const int32_t* sd, const float* W3, int ldw, const float* center, float* stats,
+                               hipStream_t s) {
+    using P = GateWS<CB, RB>;
+    const int64_t tiles = (E + P::TM - 1) / P::TM;
+    GN_REQUIRE(tiles < (1ll << 31), "edge_gate_raw_stats: too many tiles");
+    const int tpb = (int)((tiles + kNumCUs - 1) / kNumCUs);
+    GN_HIP(hipMemsetAsync(stats, 0, sizeof(float) * kNumCUs * RB * 2 * P::H, s));   // idle workgroups leave zeros
+    const GateEnc none = {};
+    hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, false, true, 1>), dim3(kNumCUs), dim3(P::NT), 0, s, e_in, x_out, E, B1h, B2h, ldn, ss,
+                       sd, W3, ldw, center, nullptr, (int)tiles, tpb, 1, none, tuning(kTuneGateExperiment), stats);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+// C[M,H] += A[M,H] * W[H,H]^T through the same kernel (MODE 2): the backward's d e_in = d e' + dxe * W3
+template <int CB, int RB>
+static int launch_ws_acc(const float* A, float* C, int64_t M, const float* W, int ldw, hipStream_t s) {
+    using P = GateWS<CB, RB>;
+    const int64_t tiles = (M + P::TM - 1) / P::TM;
+    GN_REQUIRE(tiles < (1ll << 31), "linear_acc: too many tiles");
+    const int tpb = (int)((tiles + kNumCUs - 1) / kNumCUs);
+    const GateEnc none = {};
+    hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, false, true, 2>), dim3(kNumCUs), dim3(P::NT), 0, s, A, C, M, C, nullptr, P::H, nullptr,
+                       nullptr, W, ldw, nullptr, nullptr, (int)tiles, tpb, 1, none, tuning(kTuneGateExperiment), nullptr);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, float* C, hipStream_t s) {
+    return K == 128 ? launch_ws_acc<4, 1>(A, C, M, W, ldw, s) : launch_ws_acc<2, 2>(A, C, M, W, ldw, s);
 }
 
 template <int CB, int RB>
@@ -1075,6 +1145,30 @@ extern "C" int gnnome_edge_gate_raw_f32(const float* e_in, float* x_out, int64_t
         case 256: return launch_gate<8>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, 2, nullptr, nullptr, s);
         default: set_error("edge_gate_raw: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
+}
+
+extern "C" int gnnome_edge_gate_raw_stats_rows(int hidden, int* rows_host) {
+    using namespace gnnome;
+    GN_REQUIRE(rows_host && (hidden == 64 || hidden == 128), "edge_gate_raw_stats_rows: hidden=%d not in {64,128}", hidden);
+    *rows_host = kNumCUs * (hidden == 128 ? 1 : 2);
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_edge_gate_raw_stats_f32(const float* e_in, float* x_out, int64_t num_edges, int hidden, const float* B1h,
+                                              const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
+                                              const float* W3, int ldw, const float* center, float* stats_partial, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(num_edges > 0, "edge_gate_raw_stats: needs at least one edge");
+    GN_REQUIRE(e_in && x_out && x_out != e_in && B1h && B2h && srt_src && srt_dst && W3 && center && stats_partial,
+               "edge_gate_raw_stats: bad pointers");
+    GN_REQUIRE(hidden == 64 || hidden == 128, "edge_gate_raw_stats: hidden=%d not in {64,128}", hidden);
+    GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ldw >= hidden && ldw % 4 == 0, "edge_gate_raw_stats: bad strides");
+    GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0) && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0),
+               "edge_gate_raw_stats: 16-byte alignment required");
+    hipStream_t s = (hipStream_t)stream;
+    if (hidden == 128)
+        return launch_ws_raw_stats<4, 1>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, s);
+    return launch_ws_raw_stats<2, 2>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, s);
 }
 
 extern "C" int gnnome_edge_gate_encode_f32(const float* e_raw, const int32_t* srt_eid, const float* encW1, const float* encb1,

@@ -200,6 +200,9 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
     GN_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0), "linear: A and W must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const bool aligned_out = ((uintptr_t)C % 16 == 0) && ldc % 4 == 0;
+    if (tuning(kTuneLinearVariant) == 0 && accumulate && bias == nullptr && K == Nout && (K == 64 || K == 128) && lda == K &&
+        ldc == K && aligned_out && M >= 32768)   // edge-sized square residual GEMM: the wave-specialised edge-tile kernel
+        return ws_linear_acc(A, M, K, W, ldw, C, s);
     if (tuning(kTuneLinearVariant) != 1 && aligned_out) {
         if (K == 128 && Nout % 128 == 0) return launch_linear_ws<128, 4, 2>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
         if (K == 64 && Nout % 64 == 0) return launch_linear_ws<64, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);

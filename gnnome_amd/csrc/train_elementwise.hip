@@ -12,9 +12,15 @@ namespace gnnome {
 constexpr int kEwThreads = 256;
 
 // Column reduction skeleton: thread t owns float4 column group (t % (H/4)) and walks rows r = r0 + k*stride;
-// per-thread partials are combined through LDS and one atomicAdd per column per workgroup.
+// per-thread partials are combined through LDS into one value per column per workgroup, parked in the workspace
+// ([gridDim.x][NACC][H]); k_col_finish then adds the workgroups' values up IN WORKGROUP ORDER.  No floating-point
+// atomics: their order, and with it the last bits of every BatchNorm statistic and bias gradient, would change from
+// launch to launch.
+constexpr int kColMaxBlocks = 1024;
+constexpr size_t kColWorkspaceBytes = sizeof(float) * kColMaxBlocks * 2 * 256;
+
 template <int NACC, class F>
-__device__ __forceinline__ void column_reduce(int64_t rows, int H, float* const (&out)[NACC], F&& per_row) {
+__device__ __forceinline__ void column_reduce(int64_t rows, int H, float* part, F&& per_row) {
     __shared__ float red[NACC][kEwThreads * 4];
     const int lpr = H / 4, tid = threadIdx.x;
     const int c4 = tid % lpr, rsub = tid / lpr, rpb = kEwThreads / lpr;
@@ -32,8 +38,29 @@ __device__ __forceinline__ void column_reduce(int64_t rows, int H, float* const 
         for (int a = 0; a < NACC; ++a) {
             float s = 0.f;
             for (int k = 0; k < rpb; ++k) s += red[a][c * rpb + k];
-            atomicAdd(out[a] + c, s);
+            part[((int64_t)blockIdx.x * NACC + a) * H + c] = s;
         }
+    }
+}
+
+// out[a][c] += sum_b part[b][a][c], b ascending.  One workgroup per 16 of the 2*H (a, c) pairs: 16 thread groups
+// each take every 16th b, then the 16 group sums are added in group order.
+__global__ __launch_bounds__(256) void k_col_finish(const float* __restrict__ part, int nblocks, int H, float* __restrict__ s1,
+                                                    float* __restrict__ s2) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + cl;   // flattened (a, c)
+    const int a = j / H, c = j % H;
+    float s = 0.f;
+    for (int b = g; b < nblocks; b += 16) s += part[((int64_t)b * 2 + a) * H + c];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        float* out = a == 0 ? s1 : s2;
+        out[c] += t;
     }
 }
 
@@ -41,11 +68,9 @@ __device__ __forceinline__ void column_reduce(int64_t rows, int H, float* const 
 // y aliases x.  With center = the column mean this is the second pass of a two-pass variance: sum (x-mean)^2 has
 // none of the cancellation of sum x^2 / n - mean^2 (the edge state reaches |e| ~ 500 with a spread of a few units).
 __global__ __launch_bounds__(kEwThreads) void k_colsum2(const float* __restrict__ x, const float* __restrict__ y, int64_t rows,
-                                                        int H, const float* __restrict__ center, float* __restrict__ s1,
-                                                        float* __restrict__ s2) {
-    float* const out[2] = {s1, s2};
+                                                        int H, const float* __restrict__ center, float* __restrict__ part) {
     const bool same = x == y;
-    column_reduce<2>(rows, H, out, [&](int64_t r, int c, f32x4 (&acc)[2]) {
+    column_reduce<2>(rows, H, part, [&](int64_t r, int c, f32x4 (&acc)[2]) {
         f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * H + c);
         f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * H + c);
         if (center != nullptr) {
@@ -64,9 +89,8 @@ __global__ __launch_bounds__(kEwThreads) void k_colsum2(const float* __restrict_
 __global__ __launch_bounds__(kEwThreads) void k_bn_bwd_stats(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ mean, int64_t rows, int H,
-                                                             float* __restrict__ s1, float* __restrict__ s2) {
-    float* const o[2] = {s1, s2};
-    column_reduce<2>(rows, H, o, [&](int64_t r, int c, f32x4 (&acc)[2]) {
+                                                             float* __restrict__ part) {
+    column_reduce<2>(rows, H, part, [&](int64_t r, int c, f32x4 (&acc)[2]) {
         const f32x4 d = *reinterpret_cast<const f32x4*>(dy + r * H + c);
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * H + c);
 #pragma unroll
@@ -174,26 +198,49 @@ static bool ok_width(int H) { return H == 16 || H == 32 || H == 64 || H == 128 |
 
 using namespace gnnome;
 
+static unsigned col_grid(int64_t rows, int hidden) {
+    const int rpb = kEwThreads / (hidden / 4);
+    const unsigned g = ew_grid((rows + rpb - 1) / rpb * kEwThreads / 4);
+    return g > (unsigned)kColMaxBlocks ? (unsigned)kColMaxBlocks : g;
+}
+
+extern "C" int gnnome_colsum_workspace_bytes(size_t* bytes_host) {
+    GN_REQUIRE(bytes_host != nullptr, "colsum_workspace_bytes: null pointer");
+    *bytes_host = kColWorkspaceBytes;
+    return GNNOME_OK;
+}
+
 extern "C" int gnnome_colsum2_f32(const float* x, const float* y, int64_t rows, int hidden, const float* center, float* s1,
-                                  float* s2, void* stream) {
+                                  float* s2, void* workspace, size_t workspace_bytes, void* stream) {
     GN_REQUIRE(rows >= 0 && ok_width(hidden), "colsum2: hidden=%d not in {16,32,64,128,256}", hidden);
     if (rows == 0) return GNNOME_OK;
     GN_REQUIRE(x && s1 && s2, "colsum2: null pointer");
-    const int rpb = kEwThreads / (hidden / 4);
-    hipLaunchKernelGGL(k_colsum2, dim3(ew_grid((rows + rpb - 1) / rpb * kEwThreads / 4)), dim3(kEwThreads), 0, (hipStream_t)stream,
-                       x, y ? y : x, rows, hidden, center, s1, s2);
+    GN_REQUIRE(workspace && workspace_bytes >= kColWorkspaceBytes && (uintptr_t)workspace % 16 == 0,
+               "colsum2: workspace too small or misaligned (gnnome_colsum_workspace_bytes)");
+    const unsigned grid = col_grid(rows, hidden);
+    hipLaunchKernelGGL(k_colsum2, dim3(grid), dim3(kEwThreads), 0, (hipStream_t)stream, x, y ? y : x, rows, hidden, center,
+                       (float*)workspace);
+    GN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid,
+                       hidden, s1, s2);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
 
 extern "C" int gnnome_bn_bwd_stats_f32(const float* dy, const float* x, const float* scale, const float* shift,
-                                       const float* mean, int64_t rows, int hidden, float* s1, float* s2, void* stream) {
+                                       const float* mean, int64_t rows, int hidden, float* s1, float* s2, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
     GN_REQUIRE(rows >= 0 && ok_width(hidden), "bn_bwd_stats: hidden=%d not in {16,32,64,128,256}", hidden);
     if (rows == 0) return GNNOME_OK;
     GN_REQUIRE(dy && x && scale && shift && mean && s1 && s2, "bn_bwd_stats: null pointer");
-    const int rpb = kEwThreads / (hidden / 4);
-    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(ew_grid((rows + rpb - 1) / rpb * kEwThreads / 4)), dim3(kEwThreads), 0,
-                       (hipStream_t)stream, dy, x, scale, shift, mean, rows, hidden, s1, s2);
+    GN_REQUIRE(workspace && workspace_bytes >= kColWorkspaceBytes && (uintptr_t)workspace % 16 == 0,
+               "bn_bwd_stats: workspace too small or misaligned (gnnome_colsum_workspace_bytes)");
+    const unsigned grid = col_grid(rows, hidden);
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(grid), dim3(kEwThreads), 0, (hipStream_t)stream, dy, x, scale, shift, mean, rows, hidden,
+                       (float*)workspace);
+    GN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid,
+                       hidden, s1, s2);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

@@ -264,6 +264,36 @@ def edge_gate_raw(e, B1h, B2h, views, W3):
     return out
 
 
+def edge_gate_raw_stats(e, B1h, B2h, views, W3, rows_stats=None):
+    """-> (xe, mean, biased var): the raw gate and the batch statistics of its rows (of the first rows_stats rows when
+    given).  One pass where possible: the kernel leaves per-workgroup shifted column sums and colsum2 adds them up in
+    a fixed order.  Shapes the fused kernel does not take (H = 256; statistics over a prefix of the rows, as on a
+    partition) go through edge_gate_raw + batch_stats."""
+    H, E = e.shape[1], e.shape[0]
+    fused = H in (64, 128) and E > 0 and (rows_stats is None or rows_stats == E) and B1h.stride(0) % 4 == 0 and \
+        B1h.data_ptr() % 16 == 0 and B2h.data_ptr() % 16 == 0
+    if not fused:
+        xe = edge_gate_raw(e, B1h, B2h, views, W3)
+        mean, var = batch_stats(xe if rows_stats is None else xe[:rows_stats])
+        return xe, mean, var
+    e = _dense(e, "edge_gate_raw_stats.e")
+    B1h, ldn = _rows(B1h, "edge_gate_raw_stats.B1h")
+    B2h, _ = _rows(B2h, "edge_gate_raw_stats.B2h")
+    W3, ldw = _rows(W3, "edge_gate_raw_stats.W3")
+    # centre = row 0 of the output, from three [1,H] torch ops (no host sync: the indices stay on the device)
+    s0, d0 = views.srt_src[:1].long(), views.srt_dst[:1].long()
+    center = (B1h.index_select(0, s0) + B2h.index_select(0, d0) + e[:1] @ W3.t()).reshape(-1).contiguous()
+    rows = ctypes.c_int(0)
+    _lib.check(_lib.load().gnnome_edge_gate_raw_stats_rows(H, ctypes.byref(rows)), "edge_gate_raw_stats_rows")
+    partial = torch.empty((rows.value, 2 * H), dtype=torch.float32, device=e.device)
+    out = torch.empty_like(e)
+    _call("gnnome_edge_gate_raw_stats_f32", e.device, _ptr(e), _ptr(out), E, H, _ptr(B1h), _ptr(B2h), ldn, _ptr(views.srt_src),
+          _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(center), _ptr(partial))
+    sums = colsum2(partial)[0]
+    m1 = sums[:H] / E
+    return out, (center + m1).contiguous(), (sums[H:] / E - m1 * m1).clamp_min_(0.0)
+
+
 def node_aggregate_raw(e, A1h, A2h, A3h, views, mode, num_nodes, rows_alloc=None):
     """mode 1 -> (v, fwd, rden_f, bwd, rden_b); mode 2 -> (sum_in s*A2h[src], sum_out s*A3h[dst]).
     rows_alloc > num_nodes: outputs get that many rows, the ones past num_nodes zero (halo rows of a partition)."""
@@ -287,12 +317,27 @@ def node_aggregate_raw(e, A1h, A2h, A3h, views, mode, num_nodes, rows_alloc=None
     return (v, a0, a1, a2, a3) if mode == 1 else (a0, a2)
 
 
+_COL_WS = {}
+
+
+def _col_workspace(device):
+    """Scratch of the deterministic column sums, one per device.  Launches on one device are stream-ordered in this
+    package, so one buffer serves them all."""
+    ws = _COL_WS.get(device.index)
+    if ws is None:
+        need = ctypes.c_size_t(0)
+        _lib.check(_lib.load().gnnome_colsum_workspace_bytes(ctypes.byref(need)), "colsum_workspace_bytes")
+        ws = _COL_WS[device.index] = torch.empty(int(need.value), dtype=torch.uint8, device=device)
+    return ws
+
+
 def colsum2(x, y=None, center=None):
     """(sum_r x', sum_r x'*y') per column with x' = x - center; y=None gives the (centred) sum of squares."""
     x = _dense(x, "colsum2.x")
     H = x.shape[1]
     s = torch.zeros((2, H), dtype=torch.float32, device=x.device)
-    _call("gnnome_colsum2_f32", x.device, _ptr(x), _ptr(y), x.shape[0], H, _ptr(center), _ptr(s[0]), _ptr(s[1]))
+    ws = _col_workspace(x.device)
+    _call("gnnome_colsum2_f32", x.device, _ptr(x), _ptr(y), x.shape[0], H, _ptr(center), _ptr(s[0]), _ptr(s[1]), _ptr(ws), ws.numel())
     return s[0], s[1]
 
 
@@ -317,8 +362,9 @@ def bn_relu_res(x, scale, shift, res, out=None):
 def bn_bwd_stats(dy, x, scale, shift, mean):
     H = x.shape[1]
     s = torch.zeros((2, H), dtype=torch.float32, device=x.device)
+    ws = _col_workspace(x.device)
     _call("gnnome_bn_bwd_stats_f32", x.device, _ptr(_dense(dy, "dy")), _ptr(_dense(x, "x")), _ptr(scale), _ptr(shift), _ptr(mean),
-          x.shape[0], H, _ptr(s[0]), _ptr(s[1]))
+          x.shape[0], H, _ptr(s[0]), _ptr(s[1]), _ptr(ws), ws.numel())
     return s[0], s[1]
 
 

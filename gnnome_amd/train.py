@@ -70,14 +70,10 @@ def _roles(transposed):
     return dict(A1=0, A2=2, A3=1, B1=4, B2=3) if transposed else dict(A1=0, A2=1, A3=2, B1=3, B2=4)
 
 
-def _bn_train(sh, bn, x, rows, updates):
-    """Batch statistics over the `rows` rows of the whole graph, of which x holds this rank's -> (mean, rstd, scale,
-    shift); running buffers advanced `updates` times like nn.BatchNorm1d."""
-    if x.shape[0] > 0:
-        mean, var = sh.ops.batch_stats(x)
-    else:
-        mean = var = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
-    mean, var = sh.combine_stats(mean, var, x.shape[0])
+def _bn_train(sh, bn, mean, var, n_local, rows, updates):
+    """(mean, biased var) of this rank's n_local rows -> (mean, rstd, scale, shift) over the `rows` rows of the whole
+    graph; running buffers advanced `updates` times like nn.BatchNorm1d."""
+    mean, var = sh.combine_stats(mean, var, n_local)
     rstd = torch.rsqrt(var + bn.eps)
     scale = bn.weight.detach() * rstd
     shift = bn.bias.detach() - mean * scale
@@ -137,12 +133,13 @@ class _TrainStep(torch.autograd.Function):
             sh.halo_finish()
             if n_local > n_own:
                 ops.linear(h[n_own:], Wcat, bcat, out=P[n_own:])
-            xe = ops.edge_gate_raw(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight))
-            mean_e, rstd_e, sc_e, sh_e = _bn_train(sh, conv.bn_e, xe[:e_own], sh.e_global, updates=2)
+            xe, m_e, v_e = ops.edge_gate_raw_stats(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight), rows_stats=e_own)
+            mean_e, rstd_e, sc_e, sh_e = _bn_train(sh, conv.bn_e, m_e, v_e, e_own, sh.e_global, updates=2)
             e_new = ops.bn_relu_res(xe, sc_e, sh_e, e)
             v, hf, rdf, hb, rdb = ops.node_aggregate_raw(e_new, blk(P, "A1"), blk(P, "A2"), blk(P, "A3"), views, 1, n_own,
                                                          rows_alloc=n_local)
-            mean_h, rstd_h, sc_h, sh_h = _bn_train(sh, conv.bn_h, v[:n_own], sh.n_global, updates=1)
+            m_h, v_h = ops.batch_stats(v[:n_own])
+            mean_h, rstd_h, sc_h, sh_h = _bn_train(sh, conv.bn_h, m_h, v_h, n_own, sh.n_global, updates=1)
             h_next = new(n_local, H)
             ops.bn_relu_res(v[:n_own], sc_h, sh_h, h[:n_own], out=h_next[:n_own])
             mask = None

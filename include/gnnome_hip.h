@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 2
+#define GNNOME_ABI_VERSION 3
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -157,6 +157,17 @@ int gnnome_edge_gate_raw_f32(const float* e_in, float* x_out, int64_t num_edges,
                              const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
                              const float* W3, int ldw, void* stream);
 
+/* The same, with the BatchNorm batch statistics gathered on the way (hidden in {64,128}): every workgroup writes
+ * its shifted column sums  stats_partial[w][c] = sum (x - center[c]),  stats_partial[w][hidden + c] = sum (x - center[c])^2
+ * over the rows it produced; w < gnnome_edge_gate_raw_stats_rows(hidden).  Summing the rows of stats_partial (in any
+ * FIXED order, e.g. gnnome_colsum2_f32) gives the sums the statistics need without a second pass over x_out.
+ * center: any per-column value near the column mean (row 0 of x_out is one) - the shift keeps the second moment
+ * free of cancellation. */
+int gnnome_edge_gate_raw_stats_rows(int hidden, int* rows_host);
+int gnnome_edge_gate_raw_stats_f32(const float* e_in, float* x_out, int64_t num_edges, int hidden, const float* B1h,
+                                   const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
+                                   const float* W3, int ldw, const float* center, float* stats_partial, void* stream);
+
 /* Gated aggregation without the node epilogue.
  *   mode 1: v_out = A1h + fwd + bwd (input of bn_h, gated_gcn_full.py:129); aux0 = fwd, aux1 = 1/(den_f+1e-6),
  *           aux2 = bwd, aux3 = 1/(den_b+1e-6)   (kept for the backward)
@@ -171,9 +182,13 @@ int gnnome_node_aggregate_raw_f32(const float* e, int hidden, int64_t num_nodes,
 /* s1[c] += sum_r x'[r,c];  s2[c] += sum_r x'[r,c]*y'[r,c]  with x' = x - center[c] (center NULL: 0) and y NULL -> x'
  * (sum of squares).  s1/s2 must be zeroed by the caller.  hidden in {16,32,64,128,256}.  Two calls give train-mode
  * BatchNorm its batch statistics (gated_gcn_full.py:106,119,132): the mean, then the centred second moment - the
- * one-pass E[x^2]-E[x]^2 form cancels badly on this path (|e| ~ 500, spread of a few units).  Also bias gradients. */
+ * one-pass E[x^2]-E[x]^2 form cancels badly on this path (|e| ~ 500, spread of a few units).  Also bias gradients.
+ * The sum over workgroups is deterministic (partials parked in `workspace`, added up in workgroup order by a second
+ * small kernel), so BatchNorm statistics and bias gradients are bit-identical from run to run.  workspace:
+ * gnnome_colsum_workspace_bytes() bytes, 16-byte aligned, not shared by launches that may run concurrently. */
+int gnnome_colsum_workspace_bytes(size_t* bytes_host);
 int gnnome_colsum2_f32(const float* x, const float* y, int64_t rows, int hidden, const float* center, float* s1,
-                       float* s2, void* stream);
+                       float* s2, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out = relu(x*scale[c] + shift[c]) + res : train-mode bn + relu + residual (gated_gcn_full.py:106-110, 132-137) */
 int gnnome_bn_relu_res_f32(const float* x, const float* scale, const float* shift, const float* res, int64_t rows,
@@ -183,7 +198,8 @@ int gnnome_bn_relu_res_f32(const float* x, const float* scale, const float* shif
  *   stats: s1[c] += sum_r dy*m,  s2[c] += sum_r dy*m*(x - mean[c])   (s1/s2 zeroed by the caller)
  *   apply: dx = a[c] * (dy*m - c1[c] - (x - mean[c])*rstd[c]*c2[c]) */
 int gnnome_bn_bwd_stats_f32(const float* dy, const float* x, const float* scale, const float* shift,
-                            const float* mean, int64_t rows, int hidden, float* s1, float* s2, void* stream);
+                            const float* mean, int64_t rows, int hidden, float* s1, float* s2, void* workspace,
+                            size_t workspace_bytes, void* stream);
 int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const float* scale, const float* shift, int64_t rows,
                             int hidden, const float* a, const float* c1, const float* c2, const float* mean,
                             const float* rstd, float* dx, void* stream);

@@ -122,6 +122,12 @@ def edge_gate_raw(e, B1h, B2h, views, W3):
     return B1h[views.srt_src.long()] + B2h[views.srt_dst.long()] + e @ W3.t()
 
 
+def edge_gate_raw_stats(e, B1h, B2h, views, W3, rows_stats=None):
+    xe = edge_gate_raw(e, B1h, B2h, views, W3)
+    mean, var = batch_stats(xe if rows_stats is None else xe[:rows_stats])
+    return xe, mean, var
+
+
 def node_aggregate_raw(e, A1h, A2h, A3h, views, mode, num_nodes, rows_alloc=None):
     s, d = views.srt_src.long(), views.srt_dst.long()
     n_tab, H = A2h.shape

@@ -52,7 +52,7 @@ def test_colsum_and_bn_kernels(rows, H):
     big = (500.0 + 3.0 * x).to(dev())  # a large offset with a small spread, like the edge state after a few layers
     mean, var = ops.batch_stats(big)
     close(mean, (500.0 + 3.0 * x.double()).mean(0), tol=1e-5, scale=500.0)
-    close(var, (500.0 + 3.0 * x.double()).var(0, unbiased=False), tol=2e-5, scale=9.0)
+    close(var, (500.0 + 3.0 * x.double()).var(0, unbiased=False), tol=5e-5, scale=9.0)
     a, c1, c2, mu, rs = (torch.randn(H, generator=g) for _ in range(5))
     dx = ops.bn_bwd_apply(dy.to(dev()), x.to(dev()), sc.to(dev()), sh.to(dev()), *(t.to(dev()) for t in (a, c1, c2, mu, rs)))
     want_dx = a.double() * (dy.double() * m - c1.double() - (x.double() - mu.double()) * rs.double() * c2.double())
@@ -121,6 +121,51 @@ def test_gate_raw_and_aggregate_modes(H):
     de = de0.to(dev()).clone()
     ops.agg_edge_bwd(E_.to(dev()), *(t.to(dev()) for t in T), Pd[:, H:2 * H], Pd[:, 2 * H:3 * H], gv, de)
     close(de, want, scale=20.0)
+
+
+@pytest.mark.parametrize("H", [64, 128, 256])
+@pytest.mark.parametrize("e_base", [900, 70_001])
+def test_gate_raw_with_fused_batch_statistics(H, e_base):
+    """one pass: x = B1h[src] + B2h[dst] + e W3^T AND the BatchNorm batch statistics of its columns (H = 256 takes the
+    two-pass route behind the same call).  The edge state sits far from zero with a small spread, as on this path."""
+    n, e = 400, e_base + H
+    src, dst, gv, cv = _views(n, e, H)
+    g = torch.Generator().manual_seed(H + e_base)
+    E_ = 300.0 + 2 * torch.randn(e, H, generator=g)
+    P, W3 = torch.randn(n, 5 * H, generator=g), torch.randn(H, H, generator=g) / H ** 0.5
+    s, d_ = cv.srt_src.long(), cv.srt_dst.long()
+    want = P.double()[:, 3 * H:4 * H][s] + P.double()[:, 4 * H:][d_] + E_.double() @ W3.double().t()
+    Pd = P.to(dev())
+    xe, mean, var = ops.edge_gate_raw_stats(E_.to(dev()), Pd[:, 3 * H:4 * H], Pd[:, 4 * H:], gv, W3.to(dev()))
+    close(xe, want, scale=400.0)
+    close(mean, want.mean(0), scale=400.0)
+    close(var, want.var(0, unbiased=False), tol=2e-5, scale=want.var(0, unbiased=False).max().item())
+    # statistics over a prefix of the rows (a partition's owned in-edges)
+    _, mean_p, var_p = ops.edge_gate_raw_stats(E_.to(dev()), Pd[:, 3 * H:4 * H], Pd[:, 4 * H:], gv, W3.to(dev()), rows_stats=e // 2)
+    close(mean_p, want[:e // 2].mean(0), scale=400.0)
+    # bit-identical statistics on every launch (per-workgroup partials, fixed-order sum)
+    again = ops.edge_gate_raw_stats(E_.to(dev()), Pd[:, 3 * H:4 * H], Pd[:, 4 * H:], gv, W3.to(dev()))
+    assert torch.equal(again[1], mean) and torch.equal(again[2], var)
+
+
+@pytest.mark.parametrize("H", [64, 128])
+def test_edge_sized_residual_gemm(H):
+    """C += A W^T on [E,H] rows (d e_in = d e' + dxe W3): the wave-specialised kernel behind gnnome_linear_acc_f32."""
+    e = 40_000 + H + 7
+    g = torch.Generator().manual_seed(H)
+    A, C0, W = torch.randn(e, H, generator=g), torch.randn(e, H, generator=g), torch.randn(H, H, generator=g) / H ** 0.5
+    want = C0.double() + A.double() @ W.double().t()
+    C = C0.to(dev()).clone()
+    out = ops.linear(A.to(dev()), W.to(dev()), None, out=C, accumulate=True)
+    assert out.data_ptr() == C.data_ptr()
+    close(C, want, scale=10.0)
+    try:   # and the tile kernel it replaced
+        ops.set_tuning(2, 1)
+        C2 = C0.to(dev()).clone()
+        ops.linear(A.to(dev()), W.to(dev()), None, out=C2, accumulate=True)
+    finally:
+        ops.set_tuning(2, 0)
+    close(C2, want, scale=10.0)
 
 
 @pytest.mark.parametrize("hs", [32, 64])
@@ -241,3 +286,26 @@ def test_symmetry_loss_harness_matches_golden_and_trains():
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
     # four forward passes of bn_e statistics per layer: two model calls x two bn_e applications
     assert dict(m.named_buffers())["gnn.convs.0.bn_e.num_batches_tracked"].item() == 4
+
+
+def test_training_step_is_bit_reproducible():
+    """No floating-point atomics anywhere in the step: two runs from the same state give the same bits - logits, loss,
+    every gradient, every BatchNorm buffer."""
+    from gnnome_amd.loss import bce_loss as hip_bce
+    n, e = 5000, 60_000
+    gr = make_graph(n, e, seed=21)
+    views = gnnome_amd.graph.views_for((gr["src"], gr["dst"], n), dev())
+    x = ops.degree_features(views)
+    runs = []
+    for _ in range(2):
+        m = _train_model(random_state_dict(128, seed=5), 128)
+        logits = m(views, x, gr["e"].to(dev()))
+        loss = hip_bce(logits.squeeze(-1), gr["y"].to(dev()), gr["pos_weight"].to(dev()))
+        loss.backward()
+        runs.append((logits.detach(), loss.detach(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                     {k: b.clone() for k, b in m.named_buffers()}))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
+    for k in runs[0][3]:
+        assert torch.equal(runs[0][3][k], runs[1][3][k]), k
