@@ -13,7 +13,7 @@ constexpr int kEwThreads = 256;
 
 // Column reduction skeleton: thread t owns float4 column group (t % (H/4)) and walks rows r = r0 + k*stride;
 // per-thread partials are combined through LDS into one value per column per workgroup, parked in the workspace
-// ([gridDim.x][NACC][H]); k_col_finish then adds the workgroups' values up IN WORKGROUP ORDER.  No floating-point
+// ([NACC][H][kColMaxBlocks]); k_col_finish then adds the workgroups' values up in a FIXED order.  No floating-point
 // atomics: their order, and with it the last bits of every BatchNorm statistic and bias gradient, would change from
 // launch to launch.
 constexpr int kColMaxBlocks = 1024;
@@ -38,29 +38,25 @@ __device__ __forceinline__ void column_reduce(int64_t rows, int H, float* part, 
         for (int a = 0; a < NACC; ++a) {
             float s = 0.f;
             for (int k = 0; k < rpb; ++k) s += red[a][c * rpb + k];
-            part[((int64_t)blockIdx.x * NACC + a) * H + c] = s;
+            part[((int64_t)a * H + c) * kColMaxBlocks + blockIdx.x] = s;   // [a][c][workgroup]: the finish reads along b
         }
     }
 }
 
-// out[a][c] += sum_b part[b][a][c], b ascending.  One workgroup per 16 of the 2*H (a, c) pairs: 16 thread groups
-// each take every 16th b, then the 16 group sums are added in group order.
+// out[a][c] += sum_b part[a][c][b] in a FIXED order: one wave per (a, c) pair, lane l adds b = l, l + 64, ... and
+// the 64 lane sums are folded by a butterfly (the same tree on every launch).
 __global__ __launch_bounds__(256) void k_col_finish(const float* __restrict__ part, int nblocks, int H, float* __restrict__ s1,
                                                     float* __restrict__ s2) {
-    __shared__ float red[16][17];
-    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int j = blockIdx.x * 16 + cl;   // flattened (a, c)
-    const int a = j / H, c = j % H;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);   // flattened (a, c)
+    const float* p = part + (int64_t)j * kColMaxBlocks;
     float s = 0.f;
-    for (int b = g; b < nblocks; b += 16) s += part[((int64_t)b * 2 + a) * H + c];
-    red[g][cl] = s;
-    __syncthreads();
-    if (g == 0) {
-        float t = 0.f;
+    for (int b = lane; b < nblocks; b += 64) s += p[b];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][cl];
-        float* out = a == 0 ? s1 : s2;
-        out[c] += t;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        float* out = j < H ? s1 : s2;
+        out[j < H ? j : j - H] += s;
     }
 }
 
@@ -221,7 +217,7 @@ extern "C" int gnnome_colsum2_f32(const float* x, const float* y, int64_t rows, 
     hipLaunchKernelGGL(k_colsum2, dim3(grid), dim3(kEwThreads), 0, (hipStream_t)stream, x, y ? y : x, rows, hidden, center,
                        (float*)workspace);
     GN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid,
+    hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid,
                        hidden, s1, s2);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
@@ -239,7 +235,7 @@ extern "C" int gnnome_bn_bwd_stats_f32(const float* dy, const float* x, const fl
     hipLaunchKernelGGL(k_bn_bwd_stats, dim3(grid), dim3(kEwThreads), 0, (hipStream_t)stream, dy, x, scale, shift, mean, rows, hidden,
                        (float*)workspace);
     GN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 16), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid,
+    hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid,
                        hidden, s1, s2);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
