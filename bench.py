@@ -29,6 +29,7 @@ WORKLOADS = {
 }
 HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12  # flop/s, v_mfma_f32_32x32x2_f32
+MFMA_BF16_PEAK = 2.5e15   # flop/s dense bf16 (no sparsity), v_mfma_f32_32x32x16_bf16
 
 
 def algorithmic_bytes(n, e, h, layers=8):
@@ -354,16 +355,29 @@ def main():
         if timed and kt.events[timed[0]]:
             gate_ms, gate_n = kt.mean_ms(timed[0])
             gate_flops = 2.0 * e_gate * hidden * hidden
-            res["roofline"] = {
-                "kernel": "k_edge_gate_ws (fused B_3 GEMM + u_add_v + bn_e + relu + residual)" if args.mode == "infer" else
-                          "k_edge_gate_ws<raw> (B_3 GEMM + u_add_v + BatchNorm batch-statistic partial sums; followed by 3 small torch ops and one column-sum launch inside the timed interval)", "bound": "mfma",
-                "achieved": gate_flops / (gate_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": gate_flops / (gate_ms * 1e-3) / MFMA_F32_PEAK,
-                "traffic": _pmc_traffic(args, hidden, e) if world == 1 else None,
-                "avg_launch_ms": gate_ms, "launches": gate_n, "flops_per_launch": gate_flops,
-                "algorithmic_bytes_per_launch": 2.0 * e_gate * hidden * 4 + 2 * e_gate * 4,
-                "hbm_frac": (2.0 * e_gate * hidden * 4 + 2 * e_gate * 4) / (gate_ms * 1e-3) / HBM_PEAK,
-            }
+            gate_bytes = 2.0 * e_gate * hidden * 4 + 2 * e_gate * 4   # read e, write e', read src/dst (B_layer's edge part)
+            if hidden in (64, 128):
+                # bf16x6 edge-tile kernel: the exact-fp32 product costs 6 bf16 MFMAs per K=16 (197 GF per launch at
+                # configs[1] = 0.08 ms at the 2.5 PF bf16 peak) against 1.03 GB = 0.13 ms at 8 TB/s: HBM is the bound
+                res["roofline"] = {
+                    "kernel": ("k_edge_gate_bf (fused B_3 GEMM as bf16x6 + u_add_v + bn_e + relu + residual)" if args.mode == "infer" else
+                               "k_edge_gate_bf<raw> (B_3 GEMM as bf16x6 + u_add_v + BatchNorm batch-statistic partial sums; the timed "
+                               "interval also holds 3 small torch ops and the column-sum launch that follow)"),
+                    "bound": "hbm", "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK,
+                    "traffic": _pmc_traffic(args, hidden, e) if world == 1 else None,
+                    "avg_launch_ms": gate_ms, "launches": gate_n, "algorithmic_bytes_per_launch": gate_bytes,
+                    "fp32_equivalent_flops_per_launch": gate_flops, "fp32_equivalent_tflops": gate_flops / (gate_ms * 1e-3) / 1e12,
+                    "bf16_mfma_frac": 6.0 * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK,
+                }
+            else:
+                res["roofline"] = {
+                    "kernel": "k_edge_gate (tile kernel, exact-fp32 MFMA; H=256 has no register-resident W3)", "bound": "mfma",
+                    "achieved": gate_flops / (gate_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                    "frac": gate_flops / (gate_ms * 1e-3) / MFMA_F32_PEAK, "traffic": None,
+                    "avg_launch_ms": gate_ms, "launches": gate_n, "flops_per_launch": gate_flops,
+                    "algorithmic_bytes_per_launch": gate_bytes, "hbm_frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK,
+                }
             if world > 1:
                 res["roofline"]["note"] = f"rank 0's launches: {e_gate} local edges (its node range's in- and out-edges)"
         if timed and others:

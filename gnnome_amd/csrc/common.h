@@ -14,6 +14,37 @@ void set_error(const char* fmt, ...);
 enum { kTuneGateVariant = 0, kTuneGateAblation = 1, kTuneLinearVariant = 2, kTuneGateTileOrder = 3, kTuneGateExperiment = 4, kTuneCount = 8 };
 int tuning(int key);
 
+// Layer 0 only: the e tile is not loaded but COMPUTED by the load waves from the raw edge features,
+// e0[p,:] = W2e * relu(W1e * e_raw[srt_eid[p],:] + b1e) + b2e (models/full_graph.py:27, in_features = 2,
+// hidden_ne = 16): the edge encoder's [E,H] output is never written to or read from HBM.
+struct GateEnc {
+    const float* e_raw;       // [E,2] in edge-id order
+    const int32_t* srt_eid;   // sorted position -> edge id
+    const float *W1, *b1, *W2, *b2;   // [16,2] [16] [H,16] [H]
+};
+
+// Arguments of the bf16x6 edge-tile kernel (edge_gate_bf.hip); mode 0 gate, 1 raw gate + statistics, 2 C += A W^T.
+struct GateBfArgs {
+    const float* e_in;        // A operand rows [E,H] (mode 2: A); unused with enc
+    float* e_out;             // result rows [E,H] (may alias e_in; mode 2: C)
+    int64_t E;
+    const float* B1h;         // mode 0/1: gathered by srt_src; mode 2: the old rows of C
+    const float* B2h;         // mode 0/1: gathered by srt_dst
+    int ldn;
+    const int32_t* srt_src;
+    const int32_t* srt_dst;
+    const float* W3;          // [H,H] row-major ([out,in]), row stride ldw
+    int ldw;
+    const float* scale;       // mode 0: folded norm scale; mode 1: per-column centre of the statistics
+    const float* shift;       // mode 0
+    float* stats;             // mode 1: [kNumCUs * RB][2H] per-workgroup shifted column sums
+    int num_tiles;            // filled by the launcher
+    int abl;                  // measurement-only ablation mask (gnnome_set_tuning key 1), 0 in normal use
+    int xp;                   // experiment knob (key 4): producers' poll interval 0..3 = s_sleep 1/4/16/64
+    GateEnc enc;              // mode 0 with the folded edge encoder
+};
+int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& args, hipStream_t s);
+
 // C[M,K] += A[M,K] * W[K,K]^T for K in {64,128}, contiguous 16-byte aligned A and C: the wave-specialised
 // edge-tile kernel (edge_gate.hip) in accumulate mode; linear.hip routes the backward's [E,H] dgrad here.
 int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, float* C, hipStream_t s);

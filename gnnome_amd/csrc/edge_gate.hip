@@ -721,15 +721,6 @@ __device__ __forceinline__ void flag_bump(unsigned addr, int lane) {
     if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
 }
 
-// ENC (layer 0 only): the e tile is not loaded but COMPUTED by the load waves from the raw edge features,
-// e0[p,:] = W2e * relu(W1e * e_raw[srt_eid[p],:] + b1e) + b2e (models/full_graph.py:27, in_features = 2,
-// hidden_ne = 16): the edge encoder's [E,H] output is never written to or read from HBM.
-struct GateEnc {
-    const float* e_raw;       // [E,2] in edge-id order
-    const int32_t* srt_eid;   // sorted position -> edge id
-    const float *W1, *b1, *W2, *b2;   // [16,2] [16] [H,16] [H]
-};
-
 // MODE 0: the gate.  MODE 1: raw gate x = B1h[src] + B2h[dst] + e W3^T (train mode), with per-workgroup shifted
 // column sums for the BatchNorm batch statistics written to `stats` ([gridDim.x * RB][2H]; `scale` = the centre).
 // MODE 2: C += A W^T on [E,H] rows (the backward's d e_in = d e' + dxe W3): G = the old rows of C, passed as B1h
@@ -1033,6 +1024,11 @@ static int launch_ws_acc(const float* A, float* C, int64_t M, const float* W, in
 }
 
 int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, float* C, hipStream_t s) {
+    if (tuning(kTuneGateVariant) == 0) {
+        GateBfArgs a = {};
+        a.e_in = A; a.e_out = C; a.E = M; a.B1h = C; a.ldn = K; a.W3 = W; a.ldw = ldw;
+        return gate_bf_launch(K, 2, false, a, s);
+    }
     return K == 128 ? launch_ws_acc<4, 1>(A, C, M, W, ldw, s) : launch_ws_acc<2, 2>(A, C, M, W, ldw, s);
 }
 
@@ -1110,7 +1106,13 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
     const bool rows16 = ld_node % 4 == 0 && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0);
     const bool persistent_ok = norm_kind == GNNOME_NORM_AFFINE && (hidden == 64 || hidden == 128);
     if (persistent_ok && variant != 1) {
-        if ((variant == 0 || variant == 5 || variant == 6) && rows16) {
+        if (variant == 0 && rows16) {   // the shipped default: bf16x6 edge-tile kernel (edge_gate_bf.hip)
+            GateBfArgs a = {};
+            a.e_in = e_in; a.e_out = e_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
+            a.srt_dst = srt_dst; a.W3 = W3; a.ldw = ldw; a.scale = norm_scale; a.shift = norm_shift;
+            return gate_bf_launch(hidden, 0, false, a, s);
+        }
+        if ((variant == 5 || variant == 6) && rows16) {   // exact-fp32 MFMA, counter (5) / barrier (6) hand-over
             if (hidden == 128)
                 return launch_gate_ws<4, 1>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
             return launch_gate_ws<2, 2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
@@ -1150,7 +1152,8 @@ extern "C" int gnnome_edge_gate_raw_f32(const float* e_in, float* x_out, int64_t
 extern "C" int gnnome_edge_gate_raw_stats_rows(int hidden, int* rows_host) {
     using namespace gnnome;
     GN_REQUIRE(rows_host && (hidden == 64 || hidden == 128), "edge_gate_raw_stats_rows: hidden=%d not in {64,128}", hidden);
-    *rows_host = kNumCUs * (hidden == 128 ? 1 : 2);
+    // bf16x6 kernel (variant 0): one row per load/store wave (8 per workgroup); exact-fp32 kernel: one per row block
+    *rows_host = tuning(kTuneGateVariant) == 0 ? kNumCUs * 8 : kNumCUs * (hidden == 128 ? 1 : 2);
     return GNNOME_OK;
 }
 
@@ -1166,6 +1169,12 @@ extern "C" int gnnome_edge_gate_raw_stats_f32(const float* e_in, float* x_out, i
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0) && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0),
                "edge_gate_raw_stats: 16-byte alignment required");
     hipStream_t s = (hipStream_t)stream;
+    if (tuning(kTuneGateVariant) == 0) {
+        GateBfArgs a = {};
+        a.e_in = e_in; a.e_out = x_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
+        a.srt_dst = srt_dst; a.W3 = W3; a.ldw = ldw; a.scale = center; a.stats = stats_partial;
+        return gate_bf_launch(hidden, 1, false, a, s);
+    }
     if (hidden == 128)
         return launch_ws_raw_stats<4, 1>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, s);
     return launch_ws_raw_stats<2, 2>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, s);
@@ -1186,6 +1195,12 @@ extern "C" int gnnome_edge_gate_encode_f32(const float* e_raw, const int32_t* sr
                "edge_gate_encode: alignment");
     const GateEnc enc = {e_raw, srt_eid, encW1, encb1, encW2, encb2};
     hipStream_t s = (hipStream_t)stream;
+    if (tuning(kTuneGateVariant) == 0) {
+        GateBfArgs a = {};
+        a.e_out = e_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src; a.srt_dst = srt_dst;
+        a.W3 = W3; a.ldw = ldw; a.scale = norm_scale; a.shift = norm_shift; a.enc = enc;
+        return gate_bf_launch(hidden, 0, true, a, s);
+    }
     if (hidden == 128)
         return launch_gate_ws<4, 1>(nullptr, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s, &enc);
     return launch_gate_ws<2, 2>(nullptr, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s, &enc);

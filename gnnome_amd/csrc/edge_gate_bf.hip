@@ -1,0 +1,372 @@
+// Edge-tile kernel, second generation: the [32 x H] x [H x H] product of every tile runs on the bf16 matrix cores as
+// an fp32-FAITHFUL three-way split, which turns the kernel from MFMA-bound (exact-fp32 MFMA, 157 TF peak) into
+// HBM-bound.
+//
+//   x = x1 + x2 + x3 EXACTLY, each xi a bf16: x1 = the top 16 bits of x, x2 = the top 16 bits of x - x1, x3 = the rest
+//   (24 mantissa bits = 3 x 8; truncation, so the remainders are exact and x3 is exactly representable).
+//   a*b = sum of the six products a1b1, a1b2, a2b1, a2b2, a1b3, a3b1 + (a2b3 + a3b2 + a3b3 <= 3 * 2^-24 |ab|):
+//   every product of two bf16 is exact in fp32, the accumulation is the matrix core's fp32 adder, and what is dropped
+//   is of the size of ONE fp32 rounding.  Measured against an fp64 evaluation of the whole model the result is as
+//   close as the exact-fp32 path or closer ("bf16x6").
+//   Cost: 6 v_mfma_f32_32x32x16_bf16 (32 cycles each) per K = 16, against 8 v_mfma_f32_32x32x2_f32 (64 cycles each):
+//   192 vs 512 cycles, and the tile's matrix work drops from 4096 to 1536 cycles per wave.
+//
+// Structure (see edge_gate.hip for the first generation, kept as variants 5/6):
+//   * 4 compute waves (W3 split into 3 x bf16 in 96 VGPRs per lane, loaded and split once per workgroup),
+//     4 load groups x 2 waves, a 4-slot LDS ring of fp32 tiles; slots are handed over through LDS counters, no barriers;
+//   * the load waves fetch the e rows and the B1h[src] / B2h[dst] rows and store e and G = B1h[src] + B2h[dst] as fp32;
+//   * a compute wave is a pure GEMM engine: it reads its fp32 A fragment (8 consecutive k of one row), splits it in
+//     registers (~44 VALU operations per K = 16, dealt out under the previous step's MFMAs), runs the 6 MFMAs, and at
+//     the end of the tile adds its accumulators into the G tile in LDS (16 reads, 16 writes): the slot then
+//     holds x = e W3^T + G;
+//   * the load waves are also the store waves: once the compute waves are done with a slot, the group that filled it
+//     reads x and e back as whole rows (ds_read_b128), applies the epilogue (bn + relu + residual, or the raw forms) and
+//     writes e' with 16-byte stores - every global access of the kernel is a full-row, 16-byte-per-lane one - then
+//     refills the slot with the tile it fetched in the meantime.
+#include "common.h"
+
+namespace gnnome {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int CB, int RB>
+struct GateBF {
+    static_assert(CB * RB == 4, "four compute waves");
+    static constexpr int H = 32 * CB, TM = 32 * RB, LDK = H + 4, RING = 4, LWAVES = 2;
+    static constexpr int NT = 64 * (4 + RING * LWAVES);              // 768 threads
+    static constexpr int NP = TM * (H / 4) / (64 * LWAVES);          // float4 pieces per load lane per tile
+    static constexpr int kSlotFloats = TM * LDK;
+    static constexpr int kLdsFloats = RING * 2 * kSlotFloats;        // e tiles + G tiles, fp32
+};
+
+__device__ __forceinline__ unsigned lds_addr_bf(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void flag_wait_bf(unsigned addr, unsigned want, int nap) {
+    unsigned v, spins = 0;
+    for (;;) {
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        if (__builtin_amdgcn_readfirstlane(v) >= want) break;
+        if (++spins > (1u << 22)) __builtin_trap();  // a lost hand-over must end the launch, not hang the queue
+        if (nap == 0) {
+            __builtin_amdgcn_s_sleep(1);
+        } else if (nap == 1) {
+            __builtin_amdgcn_s_sleep(4);
+        } else if (nap == 2) {
+            __builtin_amdgcn_s_sleep(16);
+        } else {
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+}
+__device__ __forceinline__ void flag_bump_bf(unsigned addr, int lane) {
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+}
+
+// exact three-way bf16 split of eight floats (one lane's share of a 32x32x16 MFMA operand: 8 consecutive k)
+__device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, uint4& p1, uint4& p2, uint4& p3) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? lo4[j] : hi4[j - 4];
+        h[j] = __float_as_uint(x) & 0xFFFF0000u;
+        const float r = x - __uint_as_float(h[j]);      // exact
+        m[j] = __float_as_uint(r) & 0xFFFF0000u;
+        l[j] = __float_as_uint(r - __uint_as_float(m[j]));   // exact, <= 8 significant bits: a bf16 (low half zero)
+    }
+    // pack pairs: element 2j in the low half, 2j+1 in the high half (v_perm_b32: bytes 3,2 of each source)
+    p1 = make_uint4(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u),
+                    __builtin_amdgcn_perm(h[5], h[4], 0x07060302u), __builtin_amdgcn_perm(h[7], h[6], 0x07060302u));
+    p2 = make_uint4(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u),
+                    __builtin_amdgcn_perm(m[5], m[4], 0x07060302u), __builtin_amdgcn_perm(m[7], m[6], 0x07060302u));
+    p3 = make_uint4(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u),
+                    __builtin_amdgcn_perm(l[5], l[4], 0x07060302u), __builtin_amdgcn_perm(l[7], l[6], 0x07060302u));
+}
+
+__device__ __forceinline__ bf16x8 as_bf(const uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// MODE 0: y = relu((acc + G) * scale + shift) + e      (the gate, gated_gcn_full.py:97,104-110)
+// MODE 1: y = acc + G, G = B1h[src] + B2h[dst]          (raw gate of the training step) + shifted column sums (scale = centre)
+// MODE 2: y = acc + G, G = the old rows of C (in B1h)   (C += A W^T: the backward's d e_in = d e' + dxe W3)
+template <int CB, int RB, int MODE, bool ENC>
+__global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
+    using P = GateBF<CB, RB>;
+    constexpr int H = P::H, TM = P::TM, NP = P::NP, LDK = P::LDK, RING = P::RING, KS = H / 16, SLOT = P::kSlotFloats;
+    constexpr int kEncFloats = ENC ? 16 * H + H + 48 : (MODE == 1 ? 8 * 64 * 8 : 0);   // MODE 1: the store waves' running column sums
+    __shared__ __attribute__((aligned(16))) float lds[P::kLdsFloats + kEncFloats];
+    __shared__ unsigned flags[2 * RING];   // full[RING], done[RING]
+    float* Aring = lds;                    // [RING][TM][LDK]  e tiles (fp32)
+    float* Gring = lds + RING * SLOT;      // [RING][TM][LDK]  G tiles
+    float* w2t = lds + P::kLdsFloats;      // ENC only
+    float* b2s = w2t + 16 * H;
+    float* w1s = b2s + H;
+    float* b1s = w1s + 32;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned full0 = lds_addr_bf(&flags[0]), done0 = lds_addr_bf(&flags[RING]);
+    // interleaved tile order: in round r the whole chip works on one contiguous window of gridDim.x tiles, each XCD
+    // (blocks b % 8) on a contiguous sub-window (see edge_gate.hip)
+    const int per_xcd = gridDim.x / kXcds;
+    const int first = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
+    const int stride = (int)gridDim.x;
+    const int n = first < a.num_tiles ? (a.num_tiles - first + stride - 1) / stride : 0;
+    if (n <= 0) return;
+    auto tile_of = [&](int r) { return first + r * stride; };
+    auto tile_valid = [&](int r) { return (int)min((int64_t)TM, a.E - (int64_t)tile_of(r) * TM); };
+    if (ENC) {
+        for (int i = tid; i < 16 * H; i += P::NT) w2t[i] = a.enc.W2[(i % H) * 16 + (i / H)];
+        for (int i = tid; i < H; i += P::NT) b2s[i] = a.enc.b2[i];
+        if (tid < 32) w1s[tid] = a.enc.W1[tid];
+        if (tid < 16) b1s[tid] = a.enc.b1[tid];
+    }
+    if (tid < 2 * RING) flags[tid] = 0;
+    __syncthreads();
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ compute wave
+        const int rb = wave % RB, cb = wave / RB, cl = lane & 31, half = lane >> 5;
+        const int col = 32 * cb + cl;
+        // B operand: W[col][16q + 8 half .. + 7], split once per workgroup
+        uint4 w1[KS], w2[KS], w3[KS];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const float* wp = a.W3 + (int64_t)col * a.ldw + 16 * q + 8 * half;
+            split3(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4), w1[q], w2[q], w3[q]);
+        }
+        const int lrow = 32 * rb + 4 * half;   // accumulator element r sits in tile row lrow + crow(r)
+        const int lane_lds = lrow * LDK + col;
+        auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
+
+        for (int i = 0; i < n; ++i) {
+            const int slot = i % RING;
+            flag_wait_bf(full0 + 4 * slot, 2u * ((unsigned)(i / RING) + 1u), 0);
+            const float* As = Aring + slot * SLOT;
+            const float* ap = As + (32 * rb + cl) * LDK + 8 * half;   // + 16 q
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // Software pipeline, one basic block: while the 6 MFMAs of step q run, the fragment of step q+1 is split
+            // (44 VALU operations, dealt out 8 per MFMA by the sched_group_barriers) and the one of step q+2 is read.
+            uint4 a1, a2, a3;
+            split3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4), a1, a2, a3);
+            f32x4 x0 = *reinterpret_cast<const f32x4*>(ap + (KS > 1 ? 16 : 0)), x1 = *reinterpret_cast<const f32x4*>(ap + (KS > 1 ? 20 : 4));
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                const int q2 = q + 2 < KS ? q + 2 : KS - 1;
+                const f32x4 n0 = *reinterpret_cast<const f32x4*>(ap + 16 * q2), n1 = *reinterpret_cast<const f32x4*>(ap + 16 * q2 + 4);
+                uint4 b1 = a1, b2 = a2, b3 = a3;
+                if (q + 1 < KS) split3(x0, x1, b1, b2, b3);
+                // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a3), as_bf(w1[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a1), as_bf(w3[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a2), as_bf(w2[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a2), as_bf(w1[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a1), as_bf(w2[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a1), as_bf(w1[q]), acc, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two LDS reads of step q+2 first
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // eight VALU operations of the split under it
+                }
+                a1 = b1;
+                a2 = b2;
+                a3 = b3;
+                x0 = n0;
+                x1 = n1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // x = acc + G, in place in the G tile (rows past the end of the edge list are never stored)
+            float* Gp = Gring + slot * SLOT + lane_lds;
+            // (plain read - add - write: LDS float atomics run lane by lane and cost ~4000 cycles per tile here)
+            float gv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gv[r] = Gp[crow(r) * LDK];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Gp[crow(r) * LDK] = gv[r] + acc[r];
+            flag_bump_bf(done0 + 4 * slot, lane);
+        }
+    } else {
+        // ------------------------------------------------------------------ load wave
+        const int group = (wave - 4) / P::LWAVES;
+        const int gl = ((wave - 4) % P::LWAVES) * 64 + lane;  // lane index inside the group, 0..127
+        constexpr int RSTEP = 64 * P::LWAVES / (H / 4);
+        const int r0 = gl / (H / 4), c4 = gl % (H / 4);
+        f32x4 av[NP], g1[NP], g2[NP];
+        float raw0[NP], raw1[NP];
+        if (a.abl & 5) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) av[p] = g1[p] = g2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const unsigned off_row = (unsigned)(r0 * H + 4 * c4);   // float offset of piece 0 inside a tile of rows
+        // The fetch of a tile comes in two parts.  EARLY (issued while the compute waves still work on this group's
+        // previous tile): the sorted indices and the e rows - nothing depends on them, 48 registers.  LATE (after the
+        // previous tile's epilogue has given its registers back): the B1h[src] / B2h[dst] gathers, whose addresses the
+        // early part has meanwhile delivered - so the index -> gather dependency costs no second round trip.
+        int si[NP], di[NP], ei[NP];
+        auto issue_early = [&](int r) {
+            const int64_t row0 = (int64_t)tile_of(r) * TM;
+            const int valid = tile_valid(r);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {   // rows past the end of the list read the last valid row (never stored)
+                const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
+                if (MODE != 2) {
+                    si[p] = a.srt_src[row];
+                    di[p] = a.srt_dst[row];
+                }
+                if (ENC) ei[p] = a.enc.srt_eid[row];
+            }
+            if (!ENC && !(a.abl & 4)) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
+                    av[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + 4 * c4);
+                }
+            }
+        };
+        auto issue_late = [&](int r) {
+            const int64_t row0 = (int64_t)tile_of(r) * TM;
+            const int valid = tile_valid(r);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (ENC) {
+                    raw0[p] = a.enc.e_raw[2 * (int64_t)ei[p]];
+                    raw1[p] = a.enc.e_raw[2 * (int64_t)ei[p] + 1];
+                }
+                if (a.abl & 1) {
+                } else if (MODE == 2) {
+                    const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
+                    g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * a.ldn + 4 * c4);   // the old rows of C
+                } else {
+                    g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + (int64_t)si[p] * a.ldn + 4 * c4);
+                    g2[p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)di[p] * a.ldn + 4 * c4);
+                }
+            }
+        };
+        // ENC: e0[p,:] = W2e relu(W1e e_raw + b1e) + b2e for this lane's pieces (models/full_graph.py:27)
+        auto encode_pending = [&]() {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) av[p] = *reinterpret_cast<const f32x4*>(b2s + 4 * c4);
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w2t + j * H + 4 * c4);
+                const float wa = w1s[2 * j], wb = w1s[2 * j + 1], bj = b1s[j];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) av[p] += fmaxf(fmaf(wb, raw1[p], fmaf(wa, raw0[p], bj)), 0.f) * w;
+            }
+        };
+        if (group < n) {
+            issue_early(group);
+            issue_late(group);
+            if (ENC) encode_pending();
+        }
+        // this lane's four columns of the epilogue
+        // MODE 1: this lane's running sums of its four columns live in LDS between tiles (the fetch phase has no
+        // registers to spare for them)
+        float* my_sums = w2t + ((wave - 4) * 64 + lane) * 8;
+        if (MODE == 1) {
+            *reinterpret_cast<f32x4*>(my_sums) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(my_sums + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float* As = Aring + group * SLOT;
+        float* Gs = Gring + group * SLOT;
+        for (int r = group; r < n; r += RING) {
+            // the slot is free: this group stored its previous tile itself (below)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                *reinterpret_cast<f32x4*>(As + (r0 + p * RSTEP) * LDK + 4 * c4) = av[p];
+                *reinterpret_cast<f32x4*>(Gs + (r0 + p * RSTEP) * LDK + 4 * c4) = MODE == 2 ? g1[p] : g1[p] + g2[p];
+            }
+            flag_bump_bf(full0 + 4 * group, lane);
+            if (r + RING < n) issue_early(r + RING);
+            // epilogue + store of tile r once the four compute waves have added their products into the G tile
+            flag_wait_bf(done0 + 4 * group, 4u * ((unsigned)(r / RING) + 1u), a.xp & 3);
+            const int valid = tile_valid(r);
+            // (re-read per tile, L1-resident: eight registers fewer across the fetch phase)
+            f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+            if (MODE != 2) sc4 = *reinterpret_cast<const f32x4*>(a.scale + 4 * c4);   // MODE 1: the columns' centres
+            if (MODE == 0) sh4 = *reinterpret_cast<const f32x4*>(a.shift + 4 * c4);
+            float* out = a.e_out + (int64_t)tile_of(r) * TM * H;   // uniform; the lane's part is off_row + p * const
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1) {
+                s1 = *reinterpret_cast<const f32x4*>(my_sums);
+                s2 = *reinterpret_cast<const f32x4*>(my_sums + 4);
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int row = r0 + p * RSTEP;
+                const f32x4 x = *reinterpret_cast<const f32x4*>(Gs + row * LDK + 4 * c4);
+                f32x4 y;
+                if (MODE == 0) {
+                    const f32x4 e = *reinterpret_cast<const f32x4*>(As + row * LDK + 4 * c4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = fmaxf(x[j] * sc4[j] + sh4[j], 0.f) + e[j];
+                } else {
+                    y = x;
+                }
+                if (row < valid) {
+                    if (MODE == 1) {
+                        const f32x4 d = x - sc4;
+                        s1 += d;
+                        s2 += d * d;
+                    }
+                    if (!(a.abl & 2)) *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
+                }
+                if (a.abl & 2) asm volatile("" ::"v"(y[0] + y[1] + y[2] + y[3]));
+            }
+            if (MODE == 1) {
+                *reinterpret_cast<f32x4*>(my_sums) = s1;
+                *reinterpret_cast<f32x4*>(my_sums + 4) = s2;
+            }
+            if (r + RING < n) {
+                issue_late(r + RING);
+                if (ENC) encode_pending();
+            }
+        }
+        if (MODE == 1) {
+            f32x4 s1 = *reinterpret_cast<const f32x4*>(my_sums), s2 = *reinterpret_cast<const f32x4*>(my_sums + 4);
+            // lanes that share c4 hold different rows of the same four columns: fold them, then every load wave
+            // leaves one row of partial sums (stats[(block * 2 RING + wave - 4)][2H])
+#pragma unroll
+            for (int o = H / 4; o < 64; o <<= 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s1[j] += __shfl_xor(s1[j], o);
+                    s2[j] += __shfl_xor(s2[j], o);
+                }
+            }
+            if (lane < H / 4) {
+                float* dst = a.stats + ((int64_t)blockIdx.x * (RING * P::LWAVES) + (wave - 4)) * 2 * H;
+                *reinterpret_cast<f32x4*>(dst + 4 * c4) = s1;
+                *reinterpret_cast<f32x4*>(dst + H + 4 * c4) = s2;
+            }
+        }
+    }
+}
+
+template <int CB, int RB, int MODE, bool ENC>
+static int launch_bf(const GateBfArgs& args, hipStream_t s) {
+    using P = GateBF<CB, RB>;
+    GateBfArgs a = args;
+    const int64_t tiles = (a.E + P::TM - 1) / P::TM;
+    GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
+    a.num_tiles = (int)tiles;
+    a.abl = tuning(kTuneGateAblation);
+    a.xp = tuning(kTuneGateExperiment);
+    if (MODE == 1) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * kNumCUs * P::RING * P::LWAVES * 2 * P::H, s));   // idle waves leave zeros
+    hipLaunchKernelGGL((k_edge_gate_bf<CB, RB, MODE, ENC>), dim3(kNumCUs), dim3(P::NT), 0, s, a);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStream_t s) {
+    if (hidden == 128) {
+        if (mode == 0) return enc ? launch_bf<4, 1, 0, true>(a, s) : launch_bf<4, 1, 0, false>(a, s);
+        return mode == 1 ? launch_bf<4, 1, 1, false>(a, s) : launch_bf<4, 1, 2, false>(a, s);
+    }
+    if (mode == 0) return enc ? launch_bf<2, 2, 0, true>(a, s) : launch_bf<2, 2, 0, false>(a, s);
+    return mode == 1 ? launch_bf<2, 2, 1, false>(a, s) : launch_bf<2, 2, 2, false>(a, s);
+}
+
+}  // namespace gnnome
