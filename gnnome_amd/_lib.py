@@ -19,6 +19,7 @@ SIGNATURES = {
     "gnnome_abi_version": [],
     "gnnome_last_error": [],
     "gnnome_set_tuning": [_i, _i],
+    "gnnome_debug_gate_profile": [_p],
     "gnnome_graph_views_workspace_bytes": [_l, _l, ctypes.POINTER(_sz)],
     "gnnome_build_graph_views": [_p, _p, _l, _l, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_encode_f32": [_p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p],

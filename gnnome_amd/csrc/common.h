@@ -40,6 +40,7 @@ struct GateBfArgs {
     float* stats;             // mode 1: [kNumCUs * RB][2H] per-workgroup shifted column sums
     int num_tiles;            // filled by the launcher
     int abl;                  // measurement-only ablation mask (gnnome_set_tuning key 1), 0 in normal use
+    long long* prof;          // measurement only: per-workgroup phase cycle counters [gridDim][8] (NULL in normal use)
     int xp;                   // experiment knob (key 4): producers' poll interval 0..3 = s_sleep 1/4/16/64
     GateEnc enc;              // mode 0 with the folded edge encoder
 };

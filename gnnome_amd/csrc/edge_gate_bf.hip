@@ -17,7 +17,7 @@
 //   * the load waves fetch the e rows and the B1h[src] / B2h[dst] rows and store e and G = B1h[src] + B2h[dst] as fp32;
 //   * a compute wave is a pure GEMM engine: it reads its fp32 A fragment (8 consecutive k of one row), splits it in
 //     registers (~44 VALU operations per K = 16, dealt out under the previous step's MFMAs), runs the 6 MFMAs, and at
-//     the end of the tile adds its accumulators into the G tile in LDS (16 reads, 16 writes): the slot then
+//     the end of the tile stores its accumulators - which started from the G tile - back over it: the slot then
 //     holds x = e W3^T + G;
 //   * the load waves are also the store waves: once the compute waves are done with a slot, the group that filled it
 //     reads x and e back as whole rows (ds_read_b128), applies the epilogue (bn + relu + residual, or the raw forms) and
@@ -138,19 +138,27 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
         const int lane_lds = lrow * LDK + col;
         auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
 
+        long long t_wait = 0, t_pro = 0, t_loop = 0, t_x = 0, t0 = 0, t1 = 0;
+        const long long c_begin = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+        const long long r_begin = a.prof ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
         for (int i = 0; i < n; ++i) {
             const int slot = i % RING;
+            if (a.prof) t0 = __builtin_readcyclecounter();
             flag_wait_bf(full0 + 4 * slot, 2u * ((unsigned)(i / RING) + 1u), 0);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_wait += t1 - t0; t0 = t1; }
             const float* As = Aring + slot * SLOT;
             const float* ap = As + (32 * rb + cl) * LDK + 8 * half;   // + 16 q
+            // the accumulator starts from the G tile (so the write-back below is a plain store of x = G + e W3^T)
+            float* Gp = Gring + slot * SLOT + lane_lds;
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = Gp[crow(r) * LDK];
             // Software pipeline, one basic block: while the 6 MFMAs of step q run, the fragment of step q+1 is split
             // (44 VALU operations, dealt out 8 per MFMA by the sched_group_barriers) and the one of step q+2 is read.
             uint4 a1, a2, a3;
             split3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4), a1, a2, a3);
             f32x4 x0 = *reinterpret_cast<const f32x4*>(ap + (KS > 1 ? 16 : 0)), x1 = *reinterpret_cast<const f32x4*>(ap + (KS > 1 ? 20 : 4));
+            if (a.prof) { asm volatile("" ::"v"(a1.x), "v"(x0[0])); t1 = __builtin_readcyclecounter(); t_pro += t1 - t0; t0 = t1; }
 #pragma unroll
             for (int q = 0; q < KS; ++q) {
                 const int q2 = q + 2 < KS ? q + 2 : KS - 1;
@@ -177,15 +185,18 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
                 x1 = n1;
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (a.prof) { asm volatile("" ::"v"(acc[0])); t1 = __builtin_readcyclecounter(); t_loop += t1 - t0; t0 = t1; }
             // x = acc + G, in place in the G tile (rows past the end of the edge list are never stored)
-            float* Gp = Gring + slot * SLOT + lane_lds;
-            // (plain read - add - write: LDS float atomics run lane by lane and cost ~4000 cycles per tile here)
-            float gv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gv[r] = Gp[crow(r) * LDK];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Gp[crow(r) * LDK] = gv[r] + acc[r];
+            for (int r = 0; r < 16; ++r) Gp[crow(r) * LDK] = acc[r];
             flag_bump_bf(done0 + 4 * slot, lane);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_x += t1 - t0; }
+        }
+        if (a.prof && wave == 0 && lane == 0) {
+            long long* o = a.prof + (int64_t)blockIdx.x * 8;
+            o[0] = t_wait; o[1] = t_pro; o[2] = t_loop; o[3] = t_x; o[4] = n;
+            o[5] = (long long)__builtin_readcyclecounter() - c_begin;           // shader cycles, loop start to end
+            o[6] = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;       // the same span in 100 MHz ticks
         }
     } else {
         // ------------------------------------------------------------------ load wave
@@ -345,6 +356,8 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
     }
 }
 
+static long long* g_gate_prof = nullptr;
+
 template <int CB, int RB, int MODE, bool ENC>
 static int launch_bf(const GateBfArgs& args, hipStream_t s) {
     using P = GateBF<CB, RB>;
@@ -354,6 +367,7 @@ static int launch_bf(const GateBfArgs& args, hipStream_t s) {
     a.num_tiles = (int)tiles;
     a.abl = tuning(kTuneGateAblation);
     a.xp = tuning(kTuneGateExperiment);
+    a.prof = g_gate_prof;
     if (MODE == 1) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * kNumCUs * P::RING * P::LWAVES * 2 * P::H, s));   // idle waves leave zeros
     hipLaunchKernelGGL((k_edge_gate_bf<CB, RB, MODE, ENC>), dim3(kNumCUs), dim3(P::NT), 0, s, a);
     GN_LAUNCH_CHECK();
@@ -370,3 +384,8 @@ int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStrea
 }
 
 }  // namespace gnnome
+
+extern "C" int gnnome_debug_gate_profile(void* counters) {
+    gnnome::g_gate_prof = (long long*)counters;
+    return GNNOME_OK;
+}

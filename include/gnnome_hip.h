@@ -55,6 +55,11 @@ const char* gnnome_last_error(void);
  *   key 3 gate tile order   : 1 contiguous run per workgroup (default: interleaved, XCD-contiguous) */
 int gnnome_set_tuning(int key, int value);
 
+/* Measurement only: when set to a device buffer of 256 x 8 int64, every launch of the edge-tile kernel leaves, per
+ * workgroup, the shader-clock cycles its first compute wave spent [0] waiting for a slot, [1] in the tile prologue,
+ * [2] in the MFMA loop, [3] writing x back, and [4] its tile count.  NULL (the default) turns it off. */
+int gnnome_debug_gate_profile(void* counters);
+
 /* ---- graph views -------------------------------------------------------------------------------
  * Replaces what DGL builds lazily inside g.update_all / dgl.reverse (gated_gcn_full.py:99,112-113,
  * 125-126): the in-edge (by dst) and out-edge (by src) orderings of one edge list.

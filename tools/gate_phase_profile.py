@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Where a compute wave of the edge-tile kernel spends its cycles (gnnome_debug_gate_profile): per-tile averages of
+wait-for-slot / prologue / MFMA loop / x write-back, over all workgroups of one launch at a BASELINE size."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gnnome_amd import _lib, ops  # noqa: E402
+from gnnome_amd.synth import make_graph  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--hidden", type=int, default=128)
+ap.add_argument("--edges", type=int, default=1_000_000)
+ap.add_argument("--ablation", type=int, default=0)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+n, e, H = a.edges // 10, a.edges, a.hidden
+g = make_graph(n, e, seed=1)
+views = ops.GraphViews(g["src"].to(dev), g["dst"].to(dev), n)
+gen = torch.Generator(device=dev).manual_seed(0)
+ee = torch.randn(e, H, device=dev, generator=gen)
+out = torch.empty_like(ee)
+P = torch.randn(n, 5 * H, device=dev, generator=gen)
+W3 = torch.randn(H, H, device=dev, generator=gen) / H ** 0.5
+sc, sh = torch.rand(H, device=dev, generator=gen) * 0.1, torch.randn(H, device=dev, generator=gen)
+ops.set_tuning(1, a.ablation)
+for _ in range(3):
+    ops.edge_gate(ee, P[:, 3 * H:4 * H], P[:, 4 * H:], views, W3, 0, sc, sh, out=out)
+prof = torch.zeros(256 * 8, dtype=torch.int64, device=dev)
+lib = _lib.load()
+lib.gnnome_debug_gate_profile(prof.data_ptr())
+s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+ops.edge_gate(ee, P[:, 3 * H:4 * H], P[:, 4 * H:], views, W3, 0, sc, sh, out=out)
+t.record()
+torch.cuda.synchronize()
+lib.gnnome_debug_gate_profile(None)
+ops.set_tuning(1, 0)
+p = prof.view(256, 8).cpu().double()
+tiles = p[:, 4].sum().item()
+names = ["wait for slot", "prologue (first fragment)", "MFMA loop", "x write-back"]
+ms = s.elapsed_time(t)
+print(f"H={H} E={e} ablation={a.ablation}: launch {ms:.4f} ms (with counters), {tiles:.0f} tiles, {tiles / 256:.1f} per workgroup")
+total = 0.0
+for k, name in enumerate(names):
+    per = p[:, k].sum().item() / tiles
+    total += per
+    print(f"  {name:28s} {per:8.0f} cycles / tile")
+span_c, span_r = p[:, 5].mean().item(), p[:, 6].mean().item()
+print(f"  loop span per workgroup: {span_c:.0f} shader cycles in {span_r / 100.0:.1f} us (100 MHz counter) -> shader clock {span_c / (span_r / 100.0) / 1e3:.2f} GHz; "
+      f"accounted {total * tiles / 256 / span_c:.0%} of the span")
+print(f"  {'sum':28s} {total:8.0f} cycles / tile   -> {total * tiles / 256 / (ms * 1e-3) / 1e9:.2f} GHz if the wave were busy for the whole launch")
