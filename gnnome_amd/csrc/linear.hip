@@ -155,6 +155,177 @@ __global__ __launch_bounds__(64 * CB * RB) void k_linear_ws(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same weight-stationary walk with the product on the bf16 matrix cores as an fp32-faithful three-way split
+// (edge_gate_bf.hip explains the arithmetic: x = x1 + x2 + x3 exactly, six of the nine partial products, what is
+// dropped is of the size of one fp32 rounding).  The W chunk is split ONCE per workgroup into three bf16 planes in
+// LDS; every wave splits its A fragment in registers (~44 VALU operations per K = 16) - with two waves per SIMD one
+// wave's split runs under the other's MFMAs.  6 x 32 cycles per K = 16 instead of 8 x 64.
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 lin_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void lin_split8(const f32x4 lo4, const f32x4 hi4, uint4& p1, uint4& p2, uint4& p3) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? lo4[j] : hi4[j - 4];
+        h[j] = __float_as_uint(x) & 0xFFFF0000u;
+        const float r = x - __uint_as_float(h[j]);           // exact
+        m[j] = __float_as_uint(r) & 0xFFFF0000u;
+        l[j] = __float_as_uint(r - __uint_as_float(m[j]));   // exact, a bf16
+    }
+    p1 = make_uint4(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u),
+                    __builtin_amdgcn_perm(h[5], h[4], 0x07060302u), __builtin_amdgcn_perm(h[7], h[6], 0x07060302u));
+    p2 = make_uint4(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u),
+                    __builtin_amdgcn_perm(m[5], m[4], 0x07060302u), __builtin_amdgcn_perm(m[7], m[6], 0x07060302u));
+    p3 = make_uint4(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u),
+                    __builtin_amdgcn_perm(l[5], l[4], 0x07060302u), __builtin_amdgcn_perm(l[7], l[6], 0x07060302u));
+}
+
+template <int K, int CB, int RB>
+struct LinBF {
+    static constexpr int TM = 32 * RB, NC = 32 * CB, NW = CB * RB, NT = 64 * NW, LDK = K + 4, LDY = NC + 4, PLD = 2 * K + 16;
+    static constexpr int kAPieces = TM * (K / 4) / NT, kWPieces = NC * (K / 8) / NT, kYPieces = TM * (NC / 4) / NT;
+    static constexpr int kPlaneBytes = NC * PLD;
+    static constexpr int kLdsBytes = 3 * kPlaneBytes + 4 * (TM * LDK + TM * LDY);
+    static_assert(NC * (K / 8) % NT == 0 && TM * (K / 4) % NT == 0 && TM * (NC / 4) % NT == 0, "piece counts");
+};
+
+template <int K, int CB, int RB>
+__global__ __launch_bounds__(64 * CB * RB) void k_linear_bf(const float* __restrict__ A, int64_t M, int lda,
+                                                            const float* __restrict__ W, int ldw,
+                                                            const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                            int num_tiles, int tiles_per_group, int groups, int accumulate) {
+    using P = LinBF<K, CB, RB>;
+    constexpr int TM = P::TM, NC = P::NC, NT = P::NT, LDK = P::LDK, LDY = P::LDY, NA = P::kAPieces, NY = P::kYPieces, PLD = P::PLD,
+                  PB = P::kPlaneBytes, KS = K / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[P::kLdsBytes];
+    unsigned char* Wp = lds;                                             // three planes [NC][PLD]
+    float* As = reinterpret_cast<float*>(lds + 3 * PB);                  // [TM][LDK] fp32
+    float* Ys = As + TM * LDK;                                           // [TM][LDY]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = wave % RB, cb = wave / RB, cl = lane & 31, half = lane >> 5;
+    const int col = 32 * cb + cl;
+    const int group = blockIdx.x, ck = blockIdx.y;
+    const int t0 = group * tiles_per_group;
+    const int t_end = min(num_tiles, t0 + tiles_per_group);
+    if (t0 >= t_end) return;
+    const int col0 = ck * NC;
+
+#pragma unroll
+    for (int it = 0; it < P::kWPieces; ++it) {   // eight consecutive k of one W row per piece
+        const int f = tid + NT * it, row = f / (K / 8), c8 = f % (K / 8);
+        const float* src = W + (int64_t)(col0 + row) * ldw + 8 * c8;
+        uint4 p1, p2, p3;
+        lin_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), p1, p2, p3);
+        unsigned char* dst = Wp + row * PLD + 16 * c8;
+        *reinterpret_cast<uint4*>(dst) = p1;
+        *reinterpret_cast<uint4*>(dst + PB) = p2;
+        *reinterpret_cast<uint4*>(dst + 2 * PB) = p3;
+    }
+    const float bv = bias != nullptr ? bias[col0 + col] : 0.f;
+
+    auto tile_valid = [&](int t) { return (int)min((int64_t)TM, M - (int64_t)t * TM); };
+    auto load_a = [&](int t, f32x4 (&r)[NA]) {
+        const int64_t row0 = (int64_t)t * TM;
+        const int valid = tile_valid(t);
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            const int f = tid + NT * it, row = min(f / (K / 4), valid - 1), c4 = f % (K / 4);
+            r[it] = *reinterpret_cast<const f32x4*>(A + (row0 + row) * lda + 4 * c4);
+        }
+    };
+    auto put_a = [&](const f32x4 (&r)[NA]) {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            const int f = tid + NT * it, row = f / (K / 4), c4 = f % (K / 4);
+            *reinterpret_cast<f32x4*>(As + row * LDK + 4 * c4) = r[it];
+        }
+    };
+
+    f32x4 stage[NA];
+    load_a(t0, stage);
+    put_a(stage);
+    if (t0 + 1 < t_end) load_a(t0 + 1, stage);
+    __syncthreads();
+
+    for (int t = t0; t < t_end; ++t) {
+        f32x16 acc, acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[r] = bv;
+            acc2[r] = 0.f;
+        }
+        const float* ap = As + (32 * rb + cl) * LDK + 8 * half;         // + 16 q
+        const unsigned char* wp = Wp + col * PLD + 16 * half;           // + 32 q, + plane * PB
+        f32x4 x0 = *reinterpret_cast<const f32x4*>(ap), x1 = *reinterpret_cast<const f32x4*>(ap + 4);
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const int qn = q + 1 < KS ? q + 1 : q;
+            const f32x4 n0 = *reinterpret_cast<const f32x4*>(ap + 16 * qn), n1 = *reinterpret_cast<const f32x4*>(ap + 16 * qn + 4);
+            const uint4 w1 = *reinterpret_cast<const uint4*>(wp + 32 * q), w2 = *reinterpret_cast<const uint4*>(wp + 32 * q + PB),
+                        w3 = *reinterpret_cast<const uint4*>(wp + 32 * q + 2 * PB);
+            uint4 a1, a2, a3;
+            lin_split8(x0, x1, a1, a2, a3);
+            auto bf = [](const uint4 v) { return __builtin_bit_cast(lin_bf16x8, v); };
+            // the 2^-16 terms into one chain, the leading ones into the other
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a3), bf(w1), acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2), bf(w1), acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(w3), acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(w2), acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2), bf(w2), acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(w1), acc, 0, 0, 0);
+            x0 = n0;
+            x1 = n1;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ys[(32 * rb + cd_row(r, lane)) * LDY + col] = acc[r] + acc2[r];
+        // claim the prefetched tile before this iteration's stores are issued (see k_edge_gate_staged)
+#pragma unroll
+        for (int it = 0; it < NA; ++it) asm volatile("" : "+v"(stage[it]));
+        __syncthreads();
+
+        {
+            const int valid = tile_valid(t);
+            float* out = C + (int64_t)t * TM * ldc + col0;
+#pragma unroll
+            for (int it = 0; it < NY; ++it) {
+                const int f = tid + NT * it, row = f / (NC / 4), c4 = f % (NC / 4);
+                f32x4 y = *reinterpret_cast<const f32x4*>(Ys + row * LDY + 4 * c4);
+                if (row < valid) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(out + (int64_t)row * ldc + 4 * c4);
+                    if (accumulate) y += *dst;
+                    *dst = y;
+                }
+            }
+        }
+        if (t + 1 < t_end) {
+            put_a(stage);
+            if (t + 2 < t_end) load_a(t + 2, stage);
+        }
+        __syncthreads();
+    }
+}
+
+template <int K, int CB, int RB>
+static int launch_linear_bf(const float* A, int64_t M, int lda, const float* W, int ldw, const float* bias, int Nout,
+                            float* C, int ldc, hipStream_t s, int accumulate) {
+    using P = LinBF<K, CB, RB>;
+    const int n_chunks = Nout / P::NC;
+    const int64_t tiles = (M + P::TM - 1) / P::TM;
+    GN_REQUIRE(tiles < (1ll << 31), "linear: too many tiles");
+    int groups = kNumCUs / n_chunks;   // see launch_linear_ws
+    if (groups >= kXcds) groups -= groups % kXcds;
+    if (groups < 1) groups = 1;
+    const int tpg = (int)((tiles + groups - 1) / groups);
+    hipLaunchKernelGGL((k_linear_bf<K, CB, RB>), dim3(groups, n_chunks), dim3(P::NT), 0, s, A, M, lda, W, ldw, bias, C, ldc,
+                       (int)tiles, tpg, groups, accumulate);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
 template <int K, int CB, int RB>
 static int launch_linear_ws(const float* A, int64_t M, int lda, const float* W, int ldw, const float* bias, int Nout,
                             float* C, int ldc, hipStream_t s, int accumulate) {
@@ -203,7 +374,11 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
     if (tuning(kTuneLinearVariant) == 0 && accumulate && bias == nullptr && K == Nout && (K == 64 || K == 128) && lda == K &&
         ldc == K && aligned_out && M >= 32768)   // edge-sized square residual GEMM: the wave-specialised edge-tile kernel
         return ws_linear_acc(A, M, K, W, ldw, C, s);
-    if (tuning(kTuneLinearVariant) != 1 && aligned_out) {
+    if (tuning(kTuneLinearVariant) == 0 && aligned_out && ldw % 4 == 0) {   // the shipped default: bf16x6 weight-stationary kernel
+        if (K == 128 && Nout % 64 == 0) return launch_linear_bf<128, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+        if (K == 64 && Nout % 64 == 0) return launch_linear_bf<64, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+    }
+    if (tuning(kTuneLinearVariant) != 1 && aligned_out) {   // 2: the exact-fp32-MFMA weight-stationary kernel
         if (K == 128 && Nout % 128 == 0) return launch_linear_ws<128, 4, 2>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
         if (K == 64 && Nout % 64 == 0) return launch_linear_ws<64, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
     }
