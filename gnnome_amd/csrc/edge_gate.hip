@@ -101,489 +101,13 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_gate(const float* e_in, f
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Persistent, weight-stationary variant for H <= 128 and the affine norm (the default model).
+// Wave-specialised form with the exact-fp32 MFMA (gnnome_set_tuning(0, 5 | 6); the shipped default is its bf16x6
+// successor in edge_gate_bf.hip).
 //
-// One 8-wave workgroup per CU keeps W3 (H x H, padded) in LDS for its whole life and walks a contiguous
-// run of 32*RB-edge tiles.  Wave (rb, cb) owns the 32x32 block (row block rb, column block cb) of the
-// tile: one v_mfma_f32_32x32x2_f32 accumulator, K = H in one sweep, two waves per SIMD.  The e tile is
-// double-buffered in LDS: tile t+1 sits in registers while tile t is multiplied and is written to the
-// other buffer after tile t's epilogue, so its HBM latency is covered by a whole tile of MFMA work;
-// the B1h[src] / B2h[dst] gathers of tile t are issued before its MFMA sweep and consumed after it;
-// the residual e_in is re-read from the LDS tile, not from memory.  HBM traffic per edge is exactly
-// one read and one write of an H-float row plus two int32 indices.
-// ---------------------------------------------------------------------------------------------------
-template <int CB, int RB>
-struct GateP {
-    static constexpr int H = 32 * CB, TM = 32 * RB, NW = CB * RB, NT = 64 * NW, LDK = H + 4;
-    static constexpr int kPieces = TM * (H / 4) / NT;  // float4 per thread per tile (= 4)
-    static constexpr int kWPieces = H * (H / 4) / NT;
-    static constexpr int kLdsFloats = (H + 2 * TM) * LDK;
-};
-
-template <int CB, int RB>
-__global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_persistent(
-    const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
-    const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
-    const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block) {
-    using P = GateP<CB, RB>;
-    constexpr int H = P::H, TM = P::TM, NT = P::NT, LDK = P::LDK;
-    __shared__ __attribute__((aligned(16))) float lds[P::kLdsFloats];
-    float* Ws = lds;
-    float* As0 = lds + H * LDK;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rb = wave % RB, cb = wave / RB, cl = lane & 31, half = lane >> 5;
-    const int t_begin = blockIdx.x * tiles_per_block;
-    const int t_end = min(num_tiles, t_begin + tiles_per_block);
-    if (t_begin >= t_end) return;
-
-    // W3 -> LDS, once
-#pragma unroll
-    for (int it = 0; it < P::kWPieces; ++it) {
-        const int f = tid + NT * it, row = f / (H / 4), c4 = f % (H / 4);
-        *reinterpret_cast<f32x4*>(Ws + row * LDK + 4 * c4) = *reinterpret_cast<const f32x4*>(W3 + (int64_t)row * ldw + 4 * c4);
-    }
-    const float sc = scale[32 * cb + cl], sh = shift[32 * cb + cl];
-
-    auto load_tile = [&](int t, f32x4 (&r)[P::kPieces]) {
-        const int64_t row0 = (int64_t)t * TM;
-        const int valid = (int)min((int64_t)TM, E - row0);
-#pragma unroll
-        for (int it = 0; it < P::kPieces; ++it) {
-            const int f = tid + NT * it, row = min(f / (H / 4), valid - 1), c4 = f % (H / 4);
-            r[it] = *reinterpret_cast<const f32x4*>(e_in + (row0 + row) * H + 4 * c4);
-        }
-    };
-    auto store_tile = [&](float* buf, const f32x4 (&r)[P::kPieces]) {
-#pragma unroll
-        for (int it = 0; it < P::kPieces; ++it) {
-            const int f = tid + NT * it, row = f / (H / 4), c4 = f % (H / 4);
-            *reinterpret_cast<f32x4*>(buf + row * LDK + 4 * c4) = r[it];
-        }
-    };
-    // lane l < 32 holds srt_src, lane l >= 32 srt_dst of row (32*rb + (l & 31)) of tile t
-    auto load_idx = [&](int t) {
-        const int64_t row0 = (int64_t)t * TM;
-        const int valid = (int)min((int64_t)TM, E - row0);
-        const int64_t row = row0 + min(32 * rb + cl, valid - 1);
-        return half ? srt_dst[row] : srt_src[row];
-    };
-
-    f32x4 stage[P::kPieces];
-    load_tile(t_begin, stage);
-    int idx_cur = load_idx(t_begin);
-    store_tile(As0, stage);
-    int idx_next = 0;
-    if (t_begin + 1 < t_end) {
-        load_tile(t_begin + 1, stage);
-        idx_next = load_idx(t_begin + 1);
-    }
-    __syncthreads();
-
-    for (int t = t_begin; t < t_end; ++t) {
-        float* buf = As0 + ((t - t_begin) & 1) * TM * LDK;
-        const int64_t row0 = (int64_t)t * TM;
-        const int valid = (int)min((int64_t)TM, E - row0);
-
-        // gathers for this tile: issued now, consumed after the MFMA sweep
-        float g1[16], g2[16];
-        {
-            // all cross-lane index fetches first, then all loads: one exposed LDS round trip per tile
-            int s_i[16], d_i[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = cd_row(r, lane);  // row inside this wave's 32-row block
-                s_i[r] = __shfl(idx_cur, lr);
-                d_i[r] = __shfl(idx_cur, 32 + lr);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                g1[r] = B1h[(int64_t)s_i[r] * ldn + 32 * cb + cl];
-                g2[r] = B2h[(int64_t)d_i[r] * ldn + 32 * cb + cl];
-            }
-        }
-
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* ap = buf + (32 * rb + cl) * LDK + 4 * half;
-        const float* wp = Ws + (32 * cb + cl) * LDK + 4 * half;
-#pragma unroll 4
-        for (int q = 0; q < H / 8; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * q);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(wp + 8 * q);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
-        }
-
-        float* eout_tile = e_out + row0 * H;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = 32 * rb + cd_row(r, lane);
-            const float x = acc[r] + (g1[r] + g2[r]);
-            const float y = fmaxf(x * sc + sh, 0.f) + buf[lr * LDK + 32 * cb + cl];
-            if (lr < valid) eout_tile[(uint32_t)(lr * H + 32 * cb + cl)] = y;
-        }
-
-        // hand tile t+1 to the other buffer (its last readers finished before the previous barrier),
-        // then start fetching tile t+2
-        if (t + 1 < t_end) {
-            store_tile(As0 + ((t + 1 - t_begin) & 1) * TM * LDK, stage);
-            idx_cur = idx_next;
-            if (t + 2 < t_end) {
-                load_tile(t + 2, stage);
-                idx_next = load_idx(t + 2);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Software-pipelined form of the persistent kernel.  A single wave's accumulator chain already
-// saturates its SIMD's matrix pipe (v_mfma_f32_32x32x2_f32: issue interval = dependent latency = 64
-// cycles), so the second wave on the SIMD adds no MFMA throughput and, in the kernel above, the
-// workgroup barrier keeps both waves in the same phase: gathers, MFMA and epilogue run one after the
-// other and the matrix pipe idles a third of the time (SQ_WAIT_ANY = 34 % of SQ_WAVE_CYCLES measured).
-// Here each wave overlaps phases ITSELF: while tile t is multiplied, the epilogue of tile t-1 (its raw
-// product, gathered node terms and residual all kept in registers) is woven between the MFMAs, one
-// accumulator element per k-step, and the node gathers of tile t are issued at the top of the sweep
-// and only consumed one tile later.
-// ---------------------------------------------------------------------------------------------------
-// ABL: ablation mask for measurements only (1 = no node gathers, 2 = no e_out stores, 4 = no HBM tile loads,
-// 8 = no MFMA); the shipped instance is ABL = 0.
-template <int CB, int RB, int ABL>
-__global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_pipelined(
-    const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
-    const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
-    const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block) {
-    using P = GateP<CB, RB>;
-    constexpr int H = P::H, TM = P::TM, NT = P::NT, LDK = P::LDK, QS = H / 8, EPQ = 16 / QS;
-    __shared__ __attribute__((aligned(16))) float lds[P::kLdsFloats];
-    float* Ws = lds;
-    float* As0 = lds + H * LDK;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rb = wave % RB, cb = wave / RB, cl = lane & 31, half = lane >> 5;
-    const int t_begin = blockIdx.x * tiles_per_block;
-    const int t_end = min(num_tiles, t_begin + tiles_per_block);
-    if (t_begin >= t_end) return;
-
-#pragma unroll
-    for (int it = 0; it < P::kWPieces; ++it) {
-        const int f = tid + NT * it, row = f / (H / 4), c4 = f % (H / 4);
-        *reinterpret_cast<f32x4*>(Ws + row * LDK + 4 * c4) = *reinterpret_cast<const f32x4*>(W3 + (int64_t)row * ldw + 4 * c4);
-    }
-    const float sc = scale[32 * cb + cl], sh = shift[32 * cb + cl];
-    const int col = 32 * cb + cl;
-
-    auto load_tile = [&](int t, f32x4 (&r)[P::kPieces]) {
-        const int64_t row0 = (int64_t)t * TM;
-        const int valid = (int)min((int64_t)TM, E - row0);
-#pragma unroll
-        for (int it = 0; it < P::kPieces; ++it) {
-            const int f = tid + NT * it, row = min(f / (H / 4), valid - 1), c4 = f % (H / 4);
-            r[it] = *reinterpret_cast<const f32x4*>(e_in + (row0 + row) * H + 4 * c4);
-        }
-    };
-    auto store_tile = [&](float* buf, const f32x4 (&r)[P::kPieces]) {
-#pragma unroll
-        for (int it = 0; it < P::kPieces; ++it) {
-            const int f = tid + NT * it, row = f / (H / 4), c4 = f % (H / 4);
-            *reinterpret_cast<f32x4*>(buf + row * LDK + 4 * c4) = r[it];
-        }
-    };
-    auto load_idx = [&](int t) {
-        const int64_t row0 = (int64_t)t * TM;
-        const int valid = (int)min((int64_t)TM, E - row0);
-        const int64_t row = row0 + min(32 * rb + cl, valid - 1);
-        return half ? srt_dst[row] : srt_src[row];
-    };
-
-    f32x4 stage[P::kPieces];
-    load_tile(t_begin, stage);
-    int idx_cur = load_idx(t_begin);
-    store_tile(As0, stage);
-    int idx_next = 0;
-    if (t_begin + 1 < t_end) {
-        load_tile(t_begin + 1, stage);
-        idx_next = load_idx(t_begin + 1);
-    }
-    __syncthreads();
-
-    // tile t-1, waiting for its epilogue
-    float accp[16], gp[16], resp[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accp[r] = gp[r] = resp[r] = 0.f;
-    float* eout_p = e_out;
-    int valid_p = 0;
-
-    for (int t = t_begin; t < t_end; ++t) {
-        float* buf = As0 + ((t - t_begin) & 1) * TM * LDK;
-        const int64_t row0 = (int64_t)t * TM;
-        const int valid = (int)min((int64_t)TM, E - row0);
-
-        // this tile's node gathers: issued now, needed one tile from now
-        float g1[16], g2[16];
-        if (ABL & 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g1[r] = g2[r] = 0.f;
-        } else {
-            // all cross-lane index fetches first, then all loads: one exposed LDS round trip per tile
-            int s_i[16], d_i[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = cd_row(r, lane);
-                s_i[r] = __shfl(idx_cur, lr);
-                d_i[r] = __shfl(idx_cur, 32 + lr);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                g1[r] = B1h[(int64_t)s_i[r] * ldn + col];
-                g2[r] = B2h[(int64_t)d_i[r] * ldn + col];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* ap = buf + (32 * rb + cl) * LDK + 4 * half;
-        const float* wp = Ws + col * LDK + 4 * half;
-#pragma unroll
-        for (int q = 0; q < QS; ++q) {
-            if (!(ABL & 8)) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * q);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(wp + 8 * q);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
-            }
-            // epilogue of the previous tile, EPQ accumulator elements per k-step
-#pragma unroll
-            for (int j = 0; j < EPQ; ++j) {
-                const int r = q * EPQ + j;
-                const int lr = 32 * rb + cd_row(r, lane);
-                const float y = fmaxf((accp[r] + gp[r]) * sc + sh, 0.f) + resp[r];
-                if (ABL & 2) {
-                    asm volatile("" ::"v"(y));
-                } else if (lr < valid_p) {
-                    eout_p[(uint32_t)(lr * H + col)] = y;
-                }
-            }
-        }
-
-        // rotate: tile t becomes the pending one (its residual is still intact in the LDS tile)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            accp[r] = acc[r];
-            gp[r] = g1[r] + g2[r];
-            resp[r] = buf[(32 * rb + cd_row(r, lane)) * LDK + col];
-        }
-        eout_p = e_out + row0 * H;
-        valid_p = valid;
-
-        if (t + 1 < t_end) {
-            store_tile(As0 + ((t + 1 - t_begin) & 1) * TM * LDK, stage);
-            idx_cur = idx_next;
-            if (t + 2 < t_end) {
-                if (!(ABL & 4)) load_tile(t + 2, stage);
-                idx_next = load_idx(t + 2);
-            }
-        }
-        __syncthreads();
-    }
-
-    // drain the last tile
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int lr = 32 * rb + cd_row(r, lane);
-        const float y = fmaxf((accp[r] + gp[r]) * sc + sh, 0.f) + resp[r];
-        if (lr < valid_p) eout_p[(uint32_t)(lr * H + col)] = y;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// "Staged" form: every global access is a 16-byte-per-lane row access.
-//
-// Ablating the pipelined kernel (tools/kernel_ab.py; E = 1M, H = 128) gave MFMA+LDS alone 0.27 ms, the
-// memory side alone 0.25 ms, both together 0.42 ms.  In the MFMA C/D layout a lane owns one column of
-// 16 scattered rows, so node gathers and e' stores are dword accesses: 52 vector-memory instructions
-// per wave per tile, each costing ~20 cycles of address processing whatever its size.  Here the
-// workgroup moves whole rows instead: the B1h[src] + B2h[dst] rows of a tile are fetched as float4
-// pieces (32 lanes per 512-byte row), summed and parked in an LDS tile GY; the epilogue reads its
-// C/D-layout elements from GY and writes e' back INTO GY; the tile then leaves row-wise as dwordx4
-// stores.  17 vector-memory instructions per wave per tile for the same bytes.
-//
-// LDS: W3 [H][H+4] + A tile [TM][H+4] + GY [TM][H+4] (135 KiB at H = 128).  Iteration i, three phases
-// separated by workgroup barriers:
-//   P1  MFMA sweep of tile i (A tile) with the epilogue of tile i-1 woven in (G(i-1) -> e'(i-1) in GY)
-//   P2  read-out: GY rows -> HBM (e' of tile i-1); residual of tile i: A tile -> registers
-//   P3  write-in: A(i+1) registers -> A tile, G(i) registers -> GY; issue loads of A(i+2), G(i+1), idx(i+2)
-// so every HBM / L2 load has a full tile of MFMA work to land in.
-// ---------------------------------------------------------------------------------------------------
-template <int CB, int RB>
-__global__ __launch_bounds__(64 * CB * RB) void k_edge_gate_staged(
-    const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
-    const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
-    const float* __restrict__ scale, const float* __restrict__ shift, int num_tiles, int tiles_per_block) {
-    using P = GateP<CB, RB>;
-    constexpr int H = P::H, TM = P::TM, NT = P::NT, LDK = P::LDK, QS = H / 8, EPQ = 16 / QS, NP = P::kPieces;
-    __shared__ __attribute__((aligned(16))) float lds[(H + 2 * TM) * LDK];
-    float* Ws = lds;
-    float* As = lds + H * LDK;
-    float* GY = As + TM * LDK;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rb = wave % RB, cb = wave / RB, cl = lane & 31, half = lane >> 5;
-    const int col = 32 * cb + cl;
-    const int t0 = blockIdx.x * tiles_per_block;
-    const int t_end = min(num_tiles, t0 + tiles_per_block);
-    if (t0 >= t_end) return;
-
-#pragma unroll
-    for (int it = 0; it < P::kWPieces; ++it) {
-        const int f = tid + NT * it, row = f / (H / 4), c4 = f % (H / 4);
-        *reinterpret_cast<f32x4*>(Ws + row * LDK + 4 * c4) = *reinterpret_cast<const f32x4*>(W3 + (int64_t)row * ldw + 4 * c4);
-    }
-    const float sc = scale[col], sh = shift[col];
-
-    // piece `it` of this thread is row prow, float4 column pc4 of a tile (32 lanes = one 512-byte row at H = 128)
-    int prow[NP], pc4[NP];
-#pragma unroll
-    for (int it = 0; it < NP; ++it) {
-        prow[it] = (tid + NT * it) / (H / 4);
-        pc4[it] = (tid + NT * it) % (H / 4);
-    }
-    auto tile_valid = [&](int t) { return (int)min((int64_t)TM, E - (int64_t)t * TM); };
-    auto load_a = [&](int t, f32x4 (&r)[NP]) {
-        const int64_t row0 = (int64_t)t * TM;
-        const int valid = tile_valid(t);
-#pragma unroll
-        for (int it = 0; it < NP; ++it)
-            r[it] = *reinterpret_cast<const f32x4*>(e_in + (row0 + min(prow[it], valid - 1)) * H + 4 * pc4[it]);
-    };
-    auto load_idx = [&](int t, int (&si)[NP], int (&di)[NP]) {
-        const int64_t row0 = (int64_t)t * TM;
-        const int valid = tile_valid(t);
-#pragma unroll
-        for (int it = 0; it < NP; ++it) {
-            const int64_t row = row0 + min(prow[it], valid - 1);
-            si[it] = srt_src[row];
-            di[it] = srt_dst[row];
-        }
-    };
-    auto load_g = [&](const int (&si)[NP], const int (&di)[NP], f32x4 (&a)[NP], f32x4 (&b)[NP]) {
-#pragma unroll
-        for (int it = 0; it < NP; ++it) {
-            a[it] = *reinterpret_cast<const f32x4*>(B1h + (int64_t)si[it] * ldn + 4 * pc4[it]);
-            b[it] = *reinterpret_cast<const f32x4*>(B2h + (int64_t)di[it] * ldn + 4 * pc4[it]);
-        }
-    };
-    auto put_rows = [&](float* buf, const f32x4 (&r)[NP]) {
-#pragma unroll
-        for (int it = 0; it < NP; ++it) *reinterpret_cast<f32x4*>(buf + prow[it] * LDK + 4 * pc4[it]) = r[it];
-    };
-    auto epilogue_elem = [&](int r, float prod, float res) {
-        float* gy = GY + (32 * rb + cd_row(r, lane)) * LDK + col;
-        *gy = fmaxf((prod + *gy) * sc + sh, 0.f) + res;
-    };
-    auto flush = [&](int t) {
-        const int valid = tile_valid(t);
-        float* out = e_out + (int64_t)t * TM * H;
-#pragma unroll
-        for (int it = 0; it < NP; ++it) {
-            const f32x4 y = *reinterpret_cast<const f32x4*>(GY + prow[it] * LDK + 4 * pc4[it]);
-            if (prow[it] < valid) *reinterpret_cast<f32x4*>(out + (uint32_t)(prow[it] * H + 4 * pc4[it])) = y;
-        }
-    };
-
-    // ---- prologue: A(t0) -> LDS; registers: g = G(t0), stage = A(t0+1), idx = idx(t0+1)
-    f32x4 stage[NP], g1[NP], g2[NP];
-    int si[NP], di[NP];
-    load_a(t0, stage);
-    load_idx(t0, si, di);
-    put_rows(As, stage);
-    load_g(si, di, g1, g2);
-    if (t0 + 1 < t_end) {
-        load_a(t0 + 1, stage);
-        load_idx(t0 + 1, si, di);
-    }
-    __syncthreads();
-
-    float accp[16], resp[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accp[r] = resp[r] = 0.f;
-
-    for (int t = t0; t < t_end; ++t) {
-        const bool pending = t > t0;  // workgroup-uniform
-        // ---- P1
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* ap = As + (32 * rb + cl) * LDK + 4 * half;
-        const float* wp = Ws + col * LDK + 4 * half;
-#pragma unroll
-        for (int q = 0; q < QS; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * q);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(wp + 8 * q);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
-            if (pending) {
-#pragma unroll
-                for (int j = 0; j < EPQ; ++j) epilogue_elem(q * EPQ + j, accp[q * EPQ + j], resp[q * EPQ + j]);
-            }
-        }
-        __syncthreads();
-        // ---- P2
-        // The loads issued in P3 of the previous iteration (a whole MFMA sweep ago) are claimed HERE, before
-        // this iteration's stores are issued: hipcc cannot count outstanding operations across the loop
-        // back-edge and waits vmcnt(0) at the first use, which would otherwise also wait for the
-        // acknowledgement of the stores below (vmcnt counts stores on gfx950).
-#pragma unroll
-        for (int it = 0; it < NP; ++it) {
-            asm volatile("" : "+v"(g1[it]), "+v"(g2[it]), "+v"(stage[it]));
-            asm volatile("" : "+v"(si[it]), "+v"(di[it]));
-        }
-        if (pending) flush(t - 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            accp[r] = acc[r];
-            resp[r] = As[(32 * rb + cd_row(r, lane)) * LDK + col];
-        }
-        __syncthreads();
-        // ---- P3
-#pragma unroll
-        for (int it = 0; it < NP; ++it) g1[it] += g2[it];
-        put_rows(GY, g1);  // G(t)
-        if (t + 1 < t_end) {
-            put_rows(As, stage);        // A(t+1)
-            load_g(si, di, g1, g2);     // G(t+1)
-            if (t + 2 < t_end) {
-                load_a(t + 2, stage);
-                load_idx(t + 2, si, di);
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- drain: epilogue and read-out of the last tile
-#pragma unroll
-    for (int r = 0; r < 16; ++r) epilogue_elem(r, accp[r], resp[r]);
-    __syncthreads();
-    flush(t_end - 1);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Wave-specialised form (the default for H <= 128 with the affine norm).
-//
-// What the variants above taught (tools/kernel_ab.py, profiles/): the MFMA side alone needs 0.27 ms and
-// the memory side alone 0.25 ms per launch (E = 1M, H = 128), but in one instruction stream they add up
-// (0.42 ms) instead of overlapping.  Two reasons.  (1) A wave's vector loads return IN ORDER, so any
+// What three earlier single-stream variants taught - persistent weight-stationary, software-pipelined, LDS-staged;
+// their measurements are in profiles/r01_c2_persistent_gate.* and r01_c2_pipelined_gate.*, their code in the
+// repository history: the MFMA side alone needs 0.27 ms and the memory side alone 0.25 ms per launch
+// (E = 1M, H = 128), but in one instruction stream they add up (0.42 ms) instead of overlapping.  Two reasons.  (1) A wave's vector loads return IN ORDER, so any
 // wait on a young L2 gather also waits for the older HBM tile prefetch: one tile (~4 us) is all the
 // latency a single stream tolerates, and that is about what HBM needs under this load.  (2) hipcc cannot
 // count outstanding loads across a loop back-edge and waits vmcnt(0) at the first cross-iteration use.
@@ -1032,40 +556,6 @@ int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, flo
     return K == 128 ? launch_ws_acc<4, 1>(A, C, M, W, ldw, s) : launch_ws_acc<2, 2>(A, C, M, W, ldw, s);
 }
 
-template <int CB, int RB>
-static int launch_gate_persistent(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
-                                  const int32_t* ss, const int32_t* sd, const float* W3, int ldw, const float* scale,
-                                  const float* shift, hipStream_t s) {
-    using P = GateP<CB, RB>;
-    const int64_t tiles = (E + P::TM - 1) / P::TM;
-    GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
-    const int grid_max = kNumCUs;  // one resident workgroup per CU (LDS-limited)
-    const int tpb = (int)((tiles + grid_max - 1) / grid_max);
-    const int grid = (int)((tiles + tpb - 1) / tpb);
-    if (tuning(kTuneGateVariant) == 4) {
-        hipLaunchKernelGGL((k_edge_gate_staged<CB, RB>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd,
-                           W3, ldw, scale, shift, (int)tiles, tpb);
-    } else if (tuning(kTuneGateVariant) == 2) {
-        hipLaunchKernelGGL((k_edge_gate_persistent<CB, RB>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss,
-                           sd, W3, ldw, scale, shift, (int)tiles, tpb);
-    } else {
-#define GN_GATE_ABL(M)                                                                                                      \
-    case M:                                                                                                                 \
-        hipLaunchKernelGGL((k_edge_gate_pipelined<CB, RB, M>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, \
-                           ss, sd, W3, ldw, scale, shift, (int)tiles, tpb);                                                \
-        break;
-        switch (tuning(kTuneGateAblation)) {
-            GN_GATE_ABL(1) GN_GATE_ABL(2) GN_GATE_ABL(4) GN_GATE_ABL(8) GN_GATE_ABL(7) GN_GATE_ABL(15)
-            default:
-                hipLaunchKernelGGL((k_edge_gate_pipelined<CB, RB, 0>), dim3(grid), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h,
-                                   ldn, ss, sd, W3, ldw, scale, shift, (int)tiles, tpb);
-        }
-#undef GN_GATE_ABL
-    }
-    GN_LAUNCH_CHECK();
-    return GNNOME_OK;
-}
-
 template <int NB>
 static int launch_gate(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
                        const int32_t* ss, const int32_t* sd, const float* W3, int ldw, int norm, const float* scale,
@@ -1101,7 +591,8 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
     GN_REQUIRE(ld_node >= hidden && ldw >= hidden && ldw % 4 == 0, "edge_gate: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0), "edge_gate: e_in and W3 must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    // variant 0 = shipped default: wave-specialised kernel where it applies, else the tile kernel
+    // variant 0 = shipped default (bf16x6 edge-tile kernel where it applies, else the tile kernel); 1 = tile kernel;
+    // 5 / 6 = exact-fp32 wave-specialised kernel
     const int variant = tuning(kTuneGateVariant);
     const bool rows16 = ld_node % 4 == 0 && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0);
     const bool persistent_ok = norm_kind == GNNOME_NORM_AFFINE && (hidden == 64 || hidden == 128);
@@ -1116,11 +607,6 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
             if (hidden == 128)
                 return launch_gate_ws<4, 1>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
             return launch_gate_ws<2, 2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
-        }
-        if (variant != 4 || rows16) {  // 2 = persistent, 3 = pipelined, 4 = staged (selected inside)
-            if (hidden == 128)
-                return launch_gate_persistent<4, 2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
-            return launch_gate_persistent<2, 4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
         }
     }
     switch (hidden) {

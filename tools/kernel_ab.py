@@ -72,7 +72,8 @@ def main():
         ts = sorted(s.elapsed_time(t) for s, t in evs)
         print(f"  in-layer  {name:16s} {ts[len(ts) // 2]:.3f} / {ts[0]:.3f}")
     # edge-gate variants, interleaved rounds (cdna_hip_programming.md 5.4 rule 24)
-    names = {1: "tile-per-workgroup", 2: "persistent", 3: "persistent+pipelined", 4: "staged (row-wise gathers/stores via LDS)", 5: "wave-specialised (compute + load waves)", 0: "default"}
+    names = {1: "tile-per-workgroup, exact-fp32 MFMA", 6: "wave-specialised, exact-fp32 MFMA, barrier hand-over",
+             5: "wave-specialised, exact-fp32 MFMA, counter hand-over", 0: "bf16x6 edge-tile kernel (default)"}
     res = {k: [] for k in names}
     for _ in range(5):
         for k in names:
@@ -91,7 +92,7 @@ def main():
         print(f"  wave-specialised gate, {nm:36s} median {timed(gate, 10)[0]:.3f} ms")
     ops.set_tuning(1, 0)
     ops.set_tuning(0, 0)
-    lv = {1: "tile kernel", 0: "weight-stationary (default)"}
+    lv = {1: "tile kernel, exact-fp32 MFMA", 2: "weight-stationary, exact-fp32 MFMA", 0: "weight-stationary, bf16x6 (default)"}
     res = {k: [] for k in lv}
     for _ in range(5):
         for k in lv:
@@ -100,9 +101,8 @@ def main():
     ops.set_tuning(2, 0)
     for k, v in res.items():
         print(f"  linear [N,{H}]x[{H},{5 * H}] variant {lv[k]:28s} median {sorted(v)[len(v) // 2]:.3f}  min {min(v):.3f} ms")
-    # ablations of the pipelined gate (results are wrong by construction; timing only)
-    abl = {0: "full", 1: "no node gathers", 2: "no e_out stores", 4: "no HBM tile loads", 8: "no MFMA", 7: "MFMA + LDS only",
-           15: "loop skeleton only"}
+    # ablations (results are wrong by construction; timing only)
+    abl = {0: "full", 1: "no node gathers", 2: "no e_out stores", 4: "no HBM tile loads", 7: "MFMA + LDS only"}
     res = {k: [] for k in abl}
     for _ in range(3):
         for k in abl:
@@ -110,7 +110,9 @@ def main():
             res[k].append(timed(gate, 5)[0])
     ops.set_tuning(1, 0)
     for k, v in res.items():
-        print(f"  pipelined gate ablation {abl[k]:24s} median {sorted(v)[len(v) // 2]:.3f} ms")
+        print(f"  bf16x6 gate ablation {abl[k]:24s} median {sorted(v)[len(v) // 2]:.3f} ms")
+    abl = {0: "full", 1: "no node gathers", 2: "no e_out stores", 4: "no HBM tile loads", 8: "no MFMA", 7: "MFMA + LDS only",
+           15: "loop skeleton only"}
     ops.set_tuning(0, 5)
     res = {k: [] for k in abl}
     for _ in range(3):
@@ -120,7 +122,7 @@ def main():
     ops.set_tuning(1, 0)
     ops.set_tuning(0, 0)
     for k, v in res.items():
-        print(f"  wave-specialised gate ablation {abl[k]:24s} median {sorted(v)[len(v) // 2]:.3f} ms")
+        print(f"  exact-fp32 wave-specialised gate ablation {abl[k]:24s} median {sorted(v)[len(v) // 2]:.3f} ms")
     # raw copy bandwidth reference on the same tensors
     dst = torch.empty_like(ee)
     med, mn = timed(lambda: dst.copy_(ee), a.reps)

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""rocprofv3 --pmc passes of tools/pmc_traffic.sh -> profiles/<name>.json: HBM bytes per launch of the edge-tile kernel.
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies 128-byte reads at 64 B, so it is doubled
+(MI355X_MICROARCH.md, "HBM"); WRITE_SIZE is taken as is - it equals the kernel's exact output size, which calibrates it.
+usage: tools/pmc_to_json.py <dir with FETCH_SIZE/ and WRITE_SIZE/> <out.json> [kernel-name substring]"""
+import csv
+import json
+import os
+import sys
+
+
+def mean_counter(path, needle):
+    vals = []
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if needle in row["Kernel_Name"]:
+                vals.append(float(row["Counter_Value"]))
+    if not vals:
+        raise SystemExit(f"no launch of a kernel matching {needle!r} in {path}")
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    needle = sys.argv[3] if len(sys.argv) > 3 else "k_edge_gate_bf"
+    fetch, n_f = mean_counter(os.path.join(src, "FETCH_SIZE", "p_counter_collection.csv"), needle)
+    write, n_w = mean_counter(os.path.join(src, "WRITE_SIZE", "p_counter_collection.csv"), needle)
+    e, hidden = 1_000_000, 128
+    rd, wr = int(2 * fetch * 1024), int(write * 1024)
+    res = {
+        "kernel": needle, "workload": f"c2: N={e // 10} E={e} H={hidden} (tools/gate_only.py, {n_f} launches averaged)",
+        "collected_with": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, one counter per pass",
+        "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
+        "corrections": "FETCH_SIZE doubled (gfx950 tallies 128-byte reads at 64 B - MI355X_MICROARCH.md, HBM); WRITE_SIZE taken as is: "
+                       "it equals the kernel's exact output size E*H*4 B, which calibrates it",
+        "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+        "algorithmic_bytes_per_launch": 2 * e * hidden * 4 + 2 * e * 4,
+    }
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
