@@ -167,20 +167,22 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
                       float* aux2 = nullptr, float* aux3 = nullptr) {
     const int64_t blocks = (n_out + (kAggThreads / 64) - 1) / (kAggThreads / 64);
     GN_REQUIRE(blocks < (1ll << 31), "node_aggregate: too many nodes");
+    // (measurement knob: unused dynamic LDS caps the workgroups resident per CU, i.e. the window of nodes in flight)
+    const size_t dyn = (size_t)tuning(kTuneAggLdsKiB) * 1024;
     if (mode == 1) {
-        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 1>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
+        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 1>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
                            n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
                            (int)blocks, aux0, aux1, aux2, aux3);
     } else if (mode == 2) {
-        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 2>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
+        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 2>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
                            n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
                            (int)blocks, aux0, aux1, aux2, aux3);
     } else if (norm == GNNOME_NORM_AFFINE) {
-        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 0>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
+        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 0>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
                            n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
                            (int)blocks, aux0, aux1, aux2, aux3);
     } else {
-        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_LAYER, 0>), dim3((unsigned)blocks), dim3(kAggThreads), 0, s, e,
+        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_LAYER, 0>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
                            n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
                            (int)blocks, aux0, aux1, aux2, aux3);
     }
