@@ -28,10 +28,10 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_gate(const float* e_in, f
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int total_tiles) {
     constexpr int H = 32 * NB;
-    __shared__ __attribute__((aligned(16))) float lds[(kTileM + H) * kLdk + 2 * kTileM];
+    __shared__ __attribute__((aligned(16))) float lds[tile_lds_floats<NB>() + 2 * kTileM];
     float* As = lds;
     float* Ws = lds + kTileM * kLdk;
-    int* s_src = reinterpret_cast<int*>(lds + (kTileM + H) * kLdk);
+    int* s_src = reinterpret_cast<int*>(lds + tile_lds_floats<NB>());
     int* s_dst = s_src + kTileM;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

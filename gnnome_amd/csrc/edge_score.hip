@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_score(
     const float* __restrict__ W3, const float* __restrict__ b3, float* __restrict__ logits, int total_tiles,
     float* __restrict__ z1_out) {
     constexpr int H = 32 * NBH, HS = 32 * NBS, LDZ = HS + 4;
-    constexpr int kGemmFloats = (kTileM + HS) * kLdk;
+    constexpr int kGemmFloats = tile_lds_floats<NBS>();
     constexpr int kStage2Floats = (kTileM + 32) * LDZ;
     constexpr int kLdsFloats = kGemmFloats > kStage2Floats ? kGemmFloats : kStage2Floats;
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats + 2 * kTileM];

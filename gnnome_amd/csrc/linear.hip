@@ -12,7 +12,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_linear(const float* __restrict
                                                          const float* __restrict__ bias, int Nout,
                                                          float* __restrict__ C, int ldc, int n_tiles, int total_tiles,
                                                          int accumulate) {
-    __shared__ __attribute__((aligned(16))) float lds[(kTileM + 32 * NB) * kLdk];
+    __shared__ __attribute__((aligned(16))) float lds[tile_lds_floats<NB>()];
     float* As = lds;
     float* Ws = lds + kTileM * kLdk;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
