@@ -188,7 +188,6 @@ def main():
     import gnnome_amd
     from gnnome_amd import _lib, ops
     from gnnome_amd.synth import make_graph, random_state_dict
-    from gnnome_amd.features import degree_features
     _lib.load()
 
     if world > 1:
@@ -201,7 +200,6 @@ def main():
 
     n, e, hidden = WORKLOADS[args.workload]
     g = make_graph(n, e, seed=1, kind=args.kind)
-    x_cpu = degree_features(g["src"], g["dst"], n) if world > 1 else None   # N=1 prepares them on the device
     model = gnnome_amd.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch").eval()
     model.load_state_dict(random_state_dict(hidden, seed=1))
     model.to(dev)
@@ -271,7 +269,10 @@ def main():
         plan = gdist.PartitionedGraph.from_global(g["src"], g["dst"], n, rank, world, dev)
         if args.mode == "train":
             model.train()
-        runner = gdist.PartitionedRunner(model, plan, x_cpu, g["e"], dev)
+        # every rank holds the edge list (as inference.py holds the whole graph): degree features of the WHOLE graph
+        # on its own GPU, then each rank keeps the rows of its partition
+        x_global = ops.degree_features(ops.GraphViews(g["src"].to(dev), g["dst"].to(dev), n))
+        runner = gdist.PartitionedRunner(model, plan, x_global, g["e"], dev)
         cold_ms = None
 
         if args.mode == "train":

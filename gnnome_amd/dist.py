@@ -110,10 +110,10 @@ class PartitionedGraph:
         return self
 
     def local_node_rows(self, x_global):
-        return x_global[self.node_gid]
+        return x_global[self.node_gid.to(x_global.device)]
 
     def local_edge_rows(self, e_global):
-        return e_global[self.edge_gid]
+        return e_global[self.edge_gid.to(e_global.device)]
 
 
 def _staged(t, group):

@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 from conftest import load_golden
 from dist_worker import worker
 from gnnome_amd.dist import split_by_incident_edges
-from gnnome_amd.features import degree_features
+from oracle.symgated_oracle import degree_features
 from gnnome_amd.synth import make_graph, random_state_dict
 from oracle.symgated_oracle import model_from_state_dict
 

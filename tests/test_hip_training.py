@@ -9,7 +9,7 @@ import cpu_ops
 import gnnome_amd
 from conftest import load_golden
 from gnnome_amd import ops
-from gnnome_amd.features import degree_features
+from oracle.symgated_oracle import degree_features
 from gnnome_amd.synth import make_graph, random_state_dict
 from oracle.symgated_oracle import OracleModel, bce_loss
 
