@@ -8,7 +8,7 @@ namespace gnnome {
 
 // ---------------------------------------------------------------------------------------------------
 // wgrad:  C[Ka,Kb] = A[R,Ka]^T * B[R,Kb]   (nn.Linear weight gradient dW = dY^T X; also dW of B_3, W1, W2)
-// Exact fp32 on v_mfma_f32_32x32x2_f32 with the ROW index as the MFMA k dimension.  A workgroup owns one
+// fp32-faithful bf16x6 product (gemm_tile.h) with the ROW index as the MFMA k dimension.  A workgroup owns one
 // 128x128 output tile and one contiguous chunk of rows and writes its partial tile; a second kernel adds the
 // partials in chunk order, so the result does not depend on scheduling (no float atomics).
 // ---------------------------------------------------------------------------------------------------
@@ -48,17 +48,42 @@ __global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__
             *reinterpret_cast<f32x4*>(Bs + lr * kWgLd + 4 * c4) = bv;
         }
         __syncthreads();
-        // lane l supplies A^T[i = l&31][k = row 2s + (l>>5)] and B[k][j = l&31]
-        const float* ap = As + (lane >> 5) * kWgLd + 64 * wi + (lane & 31);
-        const float* bp = Bs + (lane >> 5) * kWgLd + 64 * wj + (lane & 31);
-#pragma unroll 4
-        for (int s = 0; s < kWgRows / 2; ++s) {
-            const float a0 = ap[2 * s * kWgLd], a1 = ap[2 * s * kWgLd + 32];
-            const float b0 = bp[2 * s * kWgLd], b1 = bp[2 * s * kWgLd + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        // bf16x6 (gemm_tile.h): for v_mfma_f32_32x32x16_bf16 lane l supplies A^T[i = l&31][k = rows 16s + 8(l>>5) .. +7] and
+        // B[k][j = l&31] - eight ROWS of one column, read as eight conflict-free dwords and split in registers
+        const float* ap = As + 8 * (lane >> 5) * kWgLd + 64 * wi + (lane & 31);
+        const float* bp = Bs + 8 * (lane >> 5) * kWgLd + 64 * wj + (lane & 31);
+        auto bf = [](const uint4 v) { return __builtin_bit_cast(tile_bf16x8, v); };
+        auto frag = [&](const float* p, uint4& x1, uint4& x2, uint4& x3) {
+            const f32x4 lo = {p[0], p[kWgLd], p[2 * kWgLd], p[3 * kWgLd]};
+            const f32x4 hi = {p[4 * kWgLd], p[5 * kWgLd], p[6 * kWgLd], p[7 * kWgLd]};
+            uint2 l1, l2, l3, h1, h2, h3;
+            tile_split4(lo, l1, l2, l3);
+            tile_split4(hi, h1, h2, h3);
+            x1 = make_uint4(l1.x, l1.y, h1.x, h1.y);
+            x2 = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            x3 = make_uint4(l3.x, l3.y, h3.x, h3.y);
+        };
+#pragma unroll 2
+        for (int s = 0; s < kWgRows / 16; ++s) {
+            uint4 a1[2], a2[2], a3[2], b1[2], b2[2], b3[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                frag(ap + 16 * s * kWgLd + 32 * h, a1[h], a2[h], a3[h]);
+                frag(bp + 16 * s * kWgLd + 32 * h, b1[h], b2[h], b3[h]);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x16 c = acc[a][b];   // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a3[a]), bf(b1[b]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[a]), bf(b3[b]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2[a]), bf(b2[b]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2[a]), bf(b1[b]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[a]), bf(b2[b]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[a]), bf(b1[b]), c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
         }
         __syncthreads();
     }
