@@ -11,10 +11,10 @@ import torch
 import cpu_ops
 import gnnome_amd
 from conftest import load_golden
-from gnnome_amd import engine, ops
+from gnnome_amd import ops
 from gnnome_amd.graph import reverse, views_for
 from gnnome_amd.synth import make_graph, random_state_dict
-from oracle.symgated_oracle import OracleModel, degree_features, model_from_state_dict
+from oracle.symgated_oracle import degree_features, model_from_state_dict
 
 pytestmark = pytest.mark.gpu
 PROB_TOL = 1e-4
