@@ -138,6 +138,101 @@ __global__ __launch_bounds__(kEwThreads) void k_bn_relu_res(const float* __restr
     }
 }
 
+// ---- LayerNorm (normalization='layer', gated_gcn_full.py:40-42): per-ROW statistics, so training needs no global
+// reduction in the forward; the backward's d gamma / d beta are column sums like BatchNorm's.
+// A row is held by H/4 consecutive lanes (one float4 each); lpr_sum adds over them.
+__device__ __forceinline__ float lpr_sum(float v, int lpr) {
+    for (int m = 1; m < lpr; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// out = relu(LayerNorm(x) * gamma + beta) + res ; LayerNorm over the H entries of each row, biased variance, eps 1e-5
+__global__ __launch_bounds__(kEwThreads) void k_ln_relu_res(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ res,
+                                                            int64_t rows, int H, float* __restrict__ out) {
+    const int lpr = H / 4, c = (threadIdx.x % lpr) * 4, rpb = kEwThreads / lpr;
+    // whole rows only: a row never straddles two passes, idle lanes past the end still take part in the shuffles
+    const int64_t passes = (rows + rpb - 1) / rpb;
+    for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+        const int64_t r = pass * rpb + threadIdx.x / lpr;
+        const bool live = r < rows;
+        const int64_t off = (live ? r : 0) * H + c;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+        const float mean = lpr_sum(xv[0] + xv[1] + xv[2] + xv[3], lpr) * (1.0f / H);
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s2 += (xv[j] - mean) * (xv[j] - mean);
+        const float rstd = rsqrtf(lpr_sum(s2, lpr) * (1.0f / H) + kNormEps);
+        if (live) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaxf((xv[j] - mean) * rstd * gamma[c + j] + beta[c + j], 0.f) + rv[j];
+            *reinterpret_cast<f32x4*>(out + off) = o;
+        }
+    }
+}
+
+// Backward of out = relu(LayerNorm(x) * gamma + beta) + res with respect to x, gamma, beta:
+//   xhat = (x - mean_row) rstd_row,  m = (xhat gamma + beta > 0),  g = dy m gamma
+//   dx = rstd_row (g - mean_row(g) - xhat mean_row(g xhat));   d beta[c] += sum_r dy m,  d gamma[c] += sum_r dy m xhat
+// (column sums deterministic: per-workgroup partials + k_col_finish, as for BatchNorm)
+__global__ __launch_bounds__(kEwThreads) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int64_t rows,
+                                                       int H, float* __restrict__ dx, float* __restrict__ part) {
+    __shared__ float red[2][kEwThreads * 4];
+    const int lpr = H / 4, tid = threadIdx.x, c4 = tid % lpr, rsub = tid / lpr, rpb = kEwThreads / lpr, c = 4 * c4;
+    f32x4 acc_b = {0.f, 0.f, 0.f, 0.f}, acc_g = acc_b;
+    const int64_t passes = (rows + rpb - 1) / rpb;
+    for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
+        const int64_t r = pass * rpb + rsub;
+        const bool live = r < rows;
+        const int64_t off = (live ? r : 0) * H + c;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + off);
+        const float mean = lpr_sum(xv[0] + xv[1] + xv[2] + xv[3], lpr) * (1.0f / H);
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s2 += (xv[j] - mean) * (xv[j] - mean);
+        const float rstd = rsqrtf(lpr_sum(s2, lpr) * (1.0f / H) + kNormEps);
+        f32x4 xh, g;
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xh[j] = (xv[j] - mean) * rstd;
+            const float dm = (xh[j] * gamma[c + j] + beta[c + j] > 0.f) ? dv[j] : 0.f;
+            g[j] = dm * gamma[c + j];
+            sg += g[j];
+            sgx += g[j] * xh[j];
+            if (live) {
+                acc_b[j] += dm;
+                acc_g[j] += dm * xh[j];
+            }
+        }
+        const float mg = lpr_sum(sg, lpr) * (1.0f / H), mgx = lpr_sum(sgx, lpr) * (1.0f / H);
+        if (live) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rstd * (g[j] - mg - xh[j] * mgx);
+            *reinterpret_cast<f32x4*>(dx + off) = o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][(c + j) * rpb + rsub] = acc_b[j];
+        red[1][(c + j) * rpb + rsub] = acc_g[j];
+    }
+    __syncthreads();
+    for (int cc = tid; cc < H; cc += kEwThreads) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float sum = 0.f;
+            for (int k = 0; k < rpb; ++k) sum += red[a][cc * rpb + k];
+            part[((int64_t)a * H + cc) * kColMaxBlocks + blockIdx.x] = sum;
+        }
+    }
+}
+
 // out = a + b
 __global__ __launch_bounds__(kEwThreads) void k_add(const float* __restrict__ a, const float* __restrict__ b, int64_t n4,
                                                     float* __restrict__ out) {
@@ -260,6 +355,34 @@ extern "C" int gnnome_bn_relu_res_f32(const float* x, const float* scale, const 
     GN_REQUIRE(x && scale && shift && res && out, "bn_relu_res: null pointer");
     hipLaunchKernelGGL(k_bn_relu_res, dim3(ew_grid(rows * (hidden / 4))), dim3(kEwThreads), 0, (hipStream_t)stream, x, scale, shift,
                        res, rows, hidden, out);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_ln_relu_res_f32(const float* x, const float* gamma, const float* beta, const float* res, int64_t rows,
+                                      int hidden, float* out, void* stream) {
+    GN_REQUIRE(rows >= 0 && ok_width(hidden), "ln_relu_res: hidden=%d not in {16,32,64,128,256}", hidden);
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(x && gamma && beta && res && out, "ln_relu_res: null pointer");
+    hipLaunchKernelGGL(k_ln_relu_res, dim3(ew_grid(rows * (hidden / 4))), dim3(kEwThreads), 0, (hipStream_t)stream, x, gamma, beta, res,
+                       rows, hidden, out);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_ln_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, int64_t rows, int hidden,
+                                 float* dx, float* dbeta, float* dgamma, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(rows >= 0 && ok_width(hidden), "ln_bwd: hidden=%d not in {16,32,64,128,256}", hidden);
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(dy && x && gamma && beta && dx && dbeta && dgamma, "ln_bwd: null pointer");
+    GN_REQUIRE(workspace && workspace_bytes >= kColWorkspaceBytes && (uintptr_t)workspace % 16 == 0,
+               "ln_bwd: workspace too small or misaligned (gnnome_colsum_workspace_bytes)");
+    const unsigned grid = col_grid(rows, hidden);
+    hipLaunchKernelGGL(k_ln_bwd, dim3(grid), dim3(kEwThreads), 0, (hipStream_t)stream, dy, x, gamma, beta, rows, hidden, dx,
+                       (float*)workspace);
+    GN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid,
+                       hidden, dbeta, dgamma);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

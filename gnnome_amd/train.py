@@ -109,9 +109,7 @@ def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out):
 class _TrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, sh, x, e_raw, names, *params):
-        conv0 = model.gnn.convs[0]
-        if not isinstance(conv0.bn_e, torch.nn.BatchNorm1d):
-            raise NotImplementedError("training is implemented for normalization='batch' (the reference default)")
+        layer_norm = isinstance(model.gnn.convs[0].bn_e, torch.nn.LayerNorm)   # normalization='layer' (gated_gcn_full.py:40-42)
         ops, views = sh.ops, sh.views
         H = model.linear2_node.out_features
         n_own, n_local, e_own, e_local = sh.n_own, sh.n_local, sh.e_own, sh.e_local
@@ -133,15 +131,23 @@ class _TrainStep(torch.autograd.Function):
             sh.halo_finish()
             if n_local > n_own:
                 ops.linear(h[n_own:], Wcat, bcat, out=P[n_own:])
-            xe, m_e, v_e = ops.edge_gate_raw_stats(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight), rows_stats=e_own)
-            mean_e, rstd_e, sc_e, sh_e = _bn_train(sh, conv.bn_e, m_e, v_e, e_own, sh.e_global, updates=2)
-            e_new = ops.bn_relu_res(xe, sc_e, sh_e, e)
+            mean_e = rstd_e = sc_e = sh_e = mean_h = rstd_h = sc_h = sh_h = None
+            if layer_norm:   # per-row statistics: nothing crosses rows (or ranks), and there are no running buffers
+                xe = ops.edge_gate_raw(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight))
+                e_new = ops.ln_relu_res(xe, d(conv.bn_e.weight), d(conv.bn_e.bias), e)
+            else:
+                xe, m_e, v_e = ops.edge_gate_raw_stats(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight), rows_stats=e_own)
+                mean_e, rstd_e, sc_e, sh_e = _bn_train(sh, conv.bn_e, m_e, v_e, e_own, sh.e_global, updates=2)
+                e_new = ops.bn_relu_res(xe, sc_e, sh_e, e)
             v, hf, rdf, hb, rdb = ops.node_aggregate_raw(e_new, blk(P, "A1"), blk(P, "A2"), blk(P, "A3"), views, 1, n_own,
                                                          rows_alloc=n_local)
-            m_h, v_h = ops.batch_stats(v[:n_own])
-            mean_h, rstd_h, sc_h, sh_h = _bn_train(sh, conv.bn_h, m_h, v_h, n_own, sh.n_global, updates=1)
             h_next = new(n_local, H)
-            ops.bn_relu_res(v[:n_own], sc_h, sh_h, h[:n_own], out=h_next[:n_own])
+            if layer_norm:
+                ops.ln_relu_res(v[:n_own], d(conv.bn_h.weight), d(conv.bn_h.bias), h[:n_own], out=h_next[:n_own])
+            else:
+                m_h, v_h = ops.batch_stats(v[:n_own])
+                mean_h, rstd_h, sc_h, sh_h = _bn_train(sh, conv.bn_h, m_h, v_h, n_own, sh.n_global, updates=1)
+                ops.bn_relu_res(v[:n_own], sc_h, sh_h, h[:n_own], out=h_next[:n_own])
             mask = None
             if conv.dropout > 0.0:
                 mask = new(n_own, H).bernoulli_(1.0 - conv.dropout).div_(1.0 - conv.dropout)
@@ -214,8 +220,12 @@ class _TrainStep(torch.autograd.Function):
                 dh[:n_own].copy_(ops.mul23(dh[:n_own], s["mask"], s["mask"])[0])
             # h' = relu(bn_h(v)) + h_in      (owned rows)
             dv = (torch.zeros if n_local > n_own else torch.empty)((n_local, H), dtype=torch.float32, device=dev)
-            g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = _bn_bwd(sh, dh[:n_own], s["v"][:n_own], s["sc_h"], s["sh_h"], s["mean_h"],
-                                                                   s["rstd_h"], sh.n_global, n_own, dv[:n_own])
+            if s["sc_h"] is None:   # LayerNorm: per-row backward, linear in dy, so partial gradients of replicas simply add
+                _, g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = ops.ln_bwd(dh[:n_own], s["v"][:n_own], d(conv.bn_h.weight),
+                                                                             d(conv.bn_h.bias), out=dv[:n_own])
+            else:
+                g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = _bn_bwd(sh, dh[:n_own], s["v"][:n_own], s["sc_h"], s["sh_h"], s["mean_h"],
+                                                                       s["rstd_h"], sh.n_global, n_own, dv[:n_own])
             dh_in = dh
             # v = A1h + fwd + bwd
             Tf, Uf = ops.mul23(dv, s["rdf"], s["hf"])
@@ -224,8 +234,11 @@ class _TrainStep(torch.autograd.Function):
             ops.agg_edge_bwd(s["e_new"], Tf, Uf, Tb, Ub, blk(s["P"], "A2"), blk(s["P"], "A3"), views, de)  # de += ...
             # e' = relu(bn_e(xe)) + e_in ;  xe = B1h[src] + B2h[dst] + e_in W3^T
             dxe = torch.empty_like(de)
-            g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
-                                                                   sh.e_global, e_own, dxe)
+            if s["sc_e"] is None:
+                _, g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = ops.ln_bwd(de, s["xe"], d(conv.bn_e.weight), d(conv.bn_e.bias), out=dxe)
+            else:
+                g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
+                                                                       sh.e_global, e_own, dxe)
             g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"])
             ops.linear(dxe, d(conv.B_3.weight).t().contiguous(), None, out=de, accumulate=True)   # d e_in = d e' + dxe W3
             dB1 = ops.segment_sum(dxe, views.out_ptr, views.out_pos, n_local)

@@ -209,6 +209,15 @@ int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const float* scale,
                             int hidden, const float* a, const float* c1, const float* c2, const float* mean,
                             const float* rstd, float* dx, void* stream);
 
+/* LayerNorm variant (normalization='layer', gated_gcn_full.py:40-42,106,119,132) of the two groups above:
+ *   out = relu(LN(x) * gamma + beta) + res, LN over the `hidden` entries of each row (biased variance, eps 1e-5);
+ *   backward: dx = rstd_row (g - mean_row(g) - xhat mean_row(g xhat)) with g = dy m gamma, m the relu mask;
+ *   dbeta[c] += sum_r dy m, dgamma[c] += sum_r dy m xhat (deterministic; zeroed by the caller; workspace as colsum2). */
+int gnnome_ln_relu_res_f32(const float* x, const float* gamma, const float* beta, const float* res, int64_t rows, int hidden,
+                           float* out, void* stream);
+int gnnome_ln_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, int64_t rows, int hidden, float* dx,
+                      float* dbeta, float* dgamma, void* workspace, size_t workspace_bytes, void* stream);
+
 /* o1 = a*b, o2 = a*b*c (count floats, count % 4 == 0);  out = a + b;  dx = dy*(y > 0) */
 int gnnome_mul23_f32(const float* a, const float* b, const float* c, int64_t count, float* o1, float* o2, void* stream);
 int gnnome_add_f32(const float* a, const float* b, int64_t count, float* out, void* stream);

@@ -181,6 +181,31 @@ def bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd, out=None):
     return out
 
 
+def _ln_parts(x):
+    mu = x.mean(1, keepdim=True)
+    rstd = torch.rsqrt(((x - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+    return (x - mu) * rstd, rstd
+
+
+def ln_relu_res(x, gamma, beta, res, out=None):
+    y = torch.relu(_ln_parts(x)[0] * gamma + beta) + res
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
+def ln_bwd(dy, x, gamma, beta, out=None):
+    xh, rstd = _ln_parts(x)
+    dm = dy * (xh * gamma + beta > 0)
+    g = dm * gamma
+    dx = rstd * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    if out is not None:
+        out.copy_(dx)
+        dx = out
+    return dx, (dm * xh).sum(0), dm.sum(0)
+
+
 def mul23(a, b, c):
     return a * b, a * b * c
 

@@ -22,7 +22,7 @@ def worker(rank, world, port, case, out_dir):
         from gnnome_amd import dist as gdist
         from gnnome_amd import engine
         g = torch.load(case, weights_only=False)
-        m = gnnome_amd.models.SymGatedGCNModel(2, 2, g["hidden"], 16, g["layers"], 64, "batch", dropout=0.0).eval()
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, g["hidden"], 16, g["layers"], 64, g.get("normalization", "batch"), dropout=0.0).eval()
         m.load_state_dict(g["state_dict"])
         if g.get("device") == "cuda":
             # both ranks on the one GPU of the test box: HIP kernels as compute, gloo (host-staged) as transport

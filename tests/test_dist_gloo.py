@@ -116,3 +116,18 @@ def test_partitioned_training_on_a_mostly_cut_graph_matches_oracle_autograd(tmp_
         check_grads(o["grads"], {k: p.grad for k, p in om.named_parameters()}, rtol=2e-3)
         for k, b in om.named_buffers():
             assert torch.allclose(o["buffers"][k].float(), b.float(), atol=1e-5, rtol=1e-4), k
+
+
+def test_partitioned_layernorm_training_step_matches_reference_golden_g8(tmp_path):
+    """normalization='layer': per-row statistics need no cross-rank reduction; the partial gradients of replicated
+    edges still add up because the LayerNorm backward is linear in the incoming gradient."""
+    from test_train_host import check_grads
+    g = load_golden("g8_layernorm_train_h64.pt")
+    sd = {k: v for k, v in random_state_dict(64, seed=g["seed"]).items() if "running_" not in k and "num_batches" not in k}
+    case = dict(src=g["src"], dst=g["dst"], num_nodes=g["num_nodes"], x=g["x"], e=g["e"], y=g["y"], pos_weight=g["pos_weight"],
+                hidden=64, layers=8, state_dict=sd, train=True, normalization="layer")
+    outs = _run(2, case, tmp_path)
+    for o in outs:
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(g["logits"].squeeze(-1))).abs().max().item() < 1e-4
+        assert abs(o["loss"].item() - g["loss"].item()) < 1e-5
+        check_grads(o["grads"], g["grads"], rtol=1e-3)

@@ -309,3 +309,56 @@ def test_training_step_is_bit_reproducible():
         assert torch.equal(runs[0][2][k], runs[1][2][k]), k
     for k in runs[0][3]:
         assert torch.equal(runs[0][3][k], runs[1][3][k]), k
+
+
+@pytest.mark.parametrize("rows,H", [(777, 64), (40_003, 128), (300, 256), (5000, 16)])
+def test_layernorm_kernels(rows, H):
+    """gnnome_ln_relu_res_f32 / gnnome_ln_bwd_f32 against an fp64 evaluation of their contract (torch autograd)."""
+    g = torch.Generator().manual_seed(rows + H)
+    x = (50.0 + 3.0 * torch.randn(rows, H, generator=g))
+    gamma, beta, res, dy = 0.5 + torch.rand(H, generator=g), 0.3 * torch.randn(H, generator=g), torch.randn(rows, H, generator=g), torch.randn(rows, H, generator=g)
+    x64, g64, b64 = x.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    out64 = torch.relu(torch.nn.functional.layer_norm(x64, (H,), g64, b64, 1e-5)) + res.double()
+    out64.backward(dy.double())
+    out = ops.ln_relu_res(x.to(dev()), gamma.to(dev()), beta.to(dev()), res.to(dev()))
+    close(out, out64.detach(), tol=2e-5, scale=5.0)
+    dx, dgamma, dbeta = ops.ln_bwd(dy.to(dev()), x.to(dev()), gamma.to(dev()), beta.to(dev()))
+    # (a pre-activation within one fp32 rounding of zero may fall on the other side of the relu than in fp64; through the
+    #  row means that moves the whole row's dx: count ROWS, allow a handful in five million elements)
+    bad_rows = ((dx.double().cpu() - x64.grad).abs().amax(1) > 2e-4).sum().item()
+    assert bad_rows <= 2 + rows // 5000, f"{bad_rows} rows off"
+    close(dgamma, g64.grad, tol=1e-3, scale=rows ** 0.5 * 4)
+    close(dbeta, b64.grad, tol=1e-3, scale=rows ** 0.5 * 4)
+    again = ops.ln_bwd(dy.to(dev()), x.to(dev()), gamma.to(dev()), beta.to(dev()))
+    assert all(torch.equal(p, q) for p, q in zip((dx, dgamma, dbeta), again))   # deterministic column sums
+
+
+def test_layernorm_training_step_matches_reference_golden_g8():
+    g = load_golden("g8_layernorm_train_h64.pt")
+    sd = {k: v for k, v in random_state_dict(64, seed=g["seed"]).items() if "running_" not in k and "num_batches" not in k}
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 8, 64, "layer", dropout=0.0)
+    m.load_state_dict(sd)
+    m.to(dev()).train()
+    logits = m((g["src"], g["dst"], g["num_nodes"]), g["x"].to(dev()), g["e"].to(dev()))
+    loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), g["y"].to(dev()), pos_weight=g["pos_weight"].to(dev()))
+    loss.backward()
+    assert (torch.sigmoid(logits.detach().cpu()) - torch.sigmoid(g["logits"])).abs().max().item() < 1e-4
+    assert abs(loss.item() - g["loss"].item()) < 1e-5
+    _check_grads({k: p.grad for k, p in m.named_parameters()}, g["grads"], rtol=1e-3)
+    # H = 128 against the oracle's autograd
+    n, e = 2000, 20000
+    gr = make_graph(n, e, seed=12)
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = {k: v for k, v in random_state_dict(128, seed=6).items() if "running_" not in k and "num_batches" not in k}
+    om = OracleModel(2, 2, 128, 16, 8, 64, "layer", dropout=0.0)
+    om.load_state_dict(sd)
+    om.train()
+    want = om((gr["src"], gr["dst"], n), x, gr["e"])
+    bce_loss(want, gr["y"], gr["pos_weight"]).backward()
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 128, 16, 8, 64, "layer", dropout=0.0)
+    m.load_state_dict(sd)
+    m.to(dev()).train()
+    got = m((gr["src"], gr["dst"], n), x.to(dev()), gr["e"].to(dev()))
+    F.binary_cross_entropy_with_logits(got.squeeze(-1), gr["y"].to(dev()), pos_weight=gr["pos_weight"].to(dev())).backward()
+    assert (torch.sigmoid(got.detach().cpu()) - torch.sigmoid(want.detach())).abs().max().item() < 1e-4
+    _check_grads({k: p.grad for k, p in m.named_parameters()}, {k: p.grad for k, p in om.named_parameters()}, rtol=3e-2)

@@ -34,3 +34,19 @@ def test_whole_graph_step_on_checker_backend_matches_reference_golden_g3():
     for k, want in g["buffers_after"].items():
         assert torch.allclose(bufs[k].float(), want.float(), atol=1e-5, rtol=1e-4), k
     assert bufs["gnn.convs.0.bn_e.num_batches_tracked"].item() == 2 and bufs["gnn.convs.0.bn_h.num_batches_tracked"].item() == 1
+
+
+def test_layernorm_training_step_on_checker_backend_matches_reference_golden_g8():
+    """normalization='layer' (gated_gcn_full.py:40-42) in train mode: per-row statistics, hand-written LayerNorm backward."""
+    g = load_golden("g8_layernorm_train_h64.pt")
+    sd = {k: v for k, v in random_state_dict(64, seed=g["seed"]).items() if "running_" not in k and "num_batches" not in k}
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 8, 64, "layer", dropout=0.0)
+    m.load_state_dict(sd)
+    m.train()
+    views = cpu_ops.CpuViews(g["src"], g["dst"], g["num_nodes"])
+    logits = train_forward_on(m, WholeGraph(views, cpu_ops), g["x"], g["e"])
+    loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), g["y"], pos_weight=g["pos_weight"])
+    loss.backward()
+    assert (torch.sigmoid(logits.detach()) - torch.sigmoid(g["logits"])).abs().max().item() < 1e-4
+    assert abs(loss.item() - g["loss"].item()) < 1e-5
+    check_grads({k: p.grad for k, p in m.named_parameters()}, g["grads"], rtol=1e-3)
