@@ -309,6 +309,130 @@ __global__ __launch_bounds__(64 * CB * RB) void k_linear_bf(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Barrier-free streaming form of the above (the shipped default).  The W chunk (64 columns, three bf16 planes) is all
+// that lives in LDS; every wave owns 32 rows x 64 columns of the output and streams its A rows STRAIGHT FROM GLOBAL
+// MEMORY INTO MFMA FRAGMENTS - a lane's share of a 32x32x16 operand is 8 consecutive k of one row, 32 contiguous
+// bytes - so there is no A staging, no per-tile barrier and no output detour through LDS (a 32-lane half wave stores
+// 128 contiguous bytes of one output row).  Latency is hidden by occupancy: ~150 VGPRs and 52 KB of LDS allow three
+// 4-wave workgroups (12 waves) per CU.
+// ---------------------------------------------------------------------------------------------------
+template <int K>
+struct LinBF2 {
+    static constexpr int NW = 4, NT = 64 * NW, TM = 32 * NW, NC = 64, PLD = 2 * K + 16, kPlaneBytes = NC * PLD;
+    static constexpr int kWPieces = NC * (K / 8) / NT;
+    static_assert(NC * (K / 8) % NT == 0, "piece count");
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void k_linear_bf2(const float* __restrict__ A, int64_t M, int lda, const float* __restrict__ W,
+                                                    int ldw, const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                    int num_tiles, int tiles_per_group, int accumulate) {
+    using P = LinBF2<K>;
+    constexpr int PLD = P::PLD, PB = P::kPlaneBytes, KS = K / 16, HS = 2;   // fragments are fetched two K = 16 steps at a time
+    __shared__ __attribute__((aligned(16))) unsigned char Wp[3 * PB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 31, half = lane >> 5;
+    const int t0 = blockIdx.x * tiles_per_group, t_end = min(num_tiles, t0 + tiles_per_group);
+    if (t0 >= t_end) return;
+    const int col0 = blockIdx.y * P::NC;
+#pragma unroll
+    for (int it = 0; it < P::kWPieces; ++it) {   // split the W chunk once: eight consecutive k of one W row per piece
+        const int f = tid + P::NT * it, row = f / (K / 8), c8 = f % (K / 8);
+        const float* src = W + (int64_t)(col0 + row) * ldw + 8 * c8;
+        uint4 p1, p2, p3;
+        lin_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), p1, p2, p3);
+        unsigned char* dst = Wp + row * PLD + 16 * c8;
+        *reinterpret_cast<uint4*>(dst) = p1;
+        *reinterpret_cast<uint4*>(dst + PB) = p2;
+        *reinterpret_cast<uint4*>(dst + 2 * PB) = p3;
+    }
+    const float b0 = bias != nullptr ? bias[col0 + cl] : 0.f, b1 = bias != nullptr ? bias[col0 + 32 + cl] : 0.f;
+    __syncthreads();   // the only barrier
+
+    auto bf = [](const uint4 v) { return __builtin_bit_cast(lin_bf16x8, v); };
+    const unsigned char* wp = Wp + cl * PLD + 16 * half;   // + 32 * 32 rows for the second column block, + 32 q, + plane * PB
+    for (int t = t0; t < t_end; ++t) {
+        const int64_t row0 = (int64_t)t * P::TM + 32 * wave;
+        if (row0 >= M) continue;
+        const int64_t arow = min(row0 + cl, M - 1);   // rows past the end read the last row (never stored)
+        const float* ap = A + arow * lda + 8 * half;  // + 16 q
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = b0;
+            acc1[r] = b1;
+        }
+#pragma unroll
+        for (int hq = 0; hq < KS; hq += HS) {
+            f32x4 x[HS][2];
+#pragma unroll
+            for (int q = 0; q < HS; ++q) {
+                x[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * (hq + q));
+                x[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * (hq + q) + 4);
+            }
+#pragma unroll
+            for (int q = 0; q < HS; ++q) {
+                uint4 a1, a2, a3;
+                lin_split8(x[q][0], x[q][1], a1, a2, a3);
+                const unsigned char* w = wp + 32 * (hq + q);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const uint4 w1 = *reinterpret_cast<const uint4*>(w + cb * 32 * PLD), w2 = *reinterpret_cast<const uint4*>(w + cb * 32 * PLD + PB),
+                                w3 = *reinterpret_cast<const uint4*>(w + cb * 32 * PLD + 2 * PB);
+                    f32x16 c = cb == 0 ? acc0 : acc1;   // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a3), bf(w1), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(w3), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2), bf(w2), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2), bf(w1), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(w2), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(w1), c, 0, 0, 0);
+                    if (cb == 0) {
+                        acc0 = c;
+                    } else {
+                        acc1 = c;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the next batch's loads here: hoisted to the top they cost 64 registers
+        }
+        float* out = C + row0 * ldc + col0 + cl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = cd_row(r, lane);
+            if (row0 + lr < M) {
+                float* o = out + (int64_t)lr * ldc;
+                if (accumulate) {
+                    o[0] += acc0[r];
+                    o[32] += acc1[r];
+                } else {
+                    o[0] = acc0[r];
+                    o[32] = acc1[r];
+                }
+            }
+        }
+    }
+}
+
+template <int K>
+static int launch_linear_bf2(const float* A, int64_t M, int lda, const float* W, int ldw, const float* bias, int Nout, float* C,
+                             int ldc, hipStream_t s, int accumulate) {
+    using P = LinBF2<K>;
+    const int n_chunks = Nout / P::NC;
+    const int64_t tiles = (M + P::TM - 1) / P::TM;
+    GN_REQUIRE(tiles < (1ll << 31), "linear: too many tiles");
+    int groups = 3 * kNumCUs / n_chunks;   // three resident workgroups per CU; all chunks of a group share an XCD (see launch_linear_ws)
+    if (groups >= kXcds) groups -= groups % kXcds;
+    if (groups < 1) groups = 1;
+    if (groups > tiles) groups = (int)tiles;
+    const int tpg = (int)((tiles + groups - 1) / groups);
+    hipLaunchKernelGGL((k_linear_bf2<K>), dim3(groups, n_chunks), dim3(P::NT), 0, s, A, M, lda, W, ldw, bias, C, ldc, (int)tiles, tpg,
+                       accumulate);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
 template <int K, int CB, int RB>
 static int launch_linear_bf(const float* A, int64_t M, int lda, const float* W, int ldw, const float* bias, int Nout,
                             float* C, int ldc, hipStream_t s, int accumulate) {
@@ -374,7 +498,11 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
     if (tuning(kTuneLinearVariant) == 0 && accumulate && bias == nullptr && K == Nout && (K == 64 || K == 128) && lda == K &&
         ldc == K && aligned_out && M >= 32768)   // edge-sized square residual GEMM: the wave-specialised edge-tile kernel
         return ws_linear_acc(A, M, K, W, ldw, C, s);
-    if (tuning(kTuneLinearVariant) == 0 && aligned_out && ldw % 4 == 0) {   // the shipped default: bf16x6 weight-stationary kernel
+    if (tuning(kTuneLinearVariant) == 0 && ldw % 4 == 0 && Nout % 64 == 0) {   // the shipped default: bf16x6, barrier-free streaming
+        if (K == 128) return launch_linear_bf2<128>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+        if (K == 64) return launch_linear_bf2<64>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+    }
+    if (tuning(kTuneLinearVariant) == 3 && aligned_out && ldw % 4 == 0) {   // 3: bf16x6 with A staged through LDS
         if (K == 128 && Nout % 64 == 0) return launch_linear_bf<128, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
         if (K == 64 && Nout % 64 == 0) return launch_linear_bf<64, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
     }

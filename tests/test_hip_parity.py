@@ -101,8 +101,8 @@ def test_linear(m, k, nout):
     base = torch.randn(m, nout, generator=g)
     acc = ops.linear(A.to(dev()), W.to(dev()), b.to(dev()), out=base.to(dev()).clone(), accumulate=True)
     _assert_close(acc, want + base.double(), scale=float(k) ** 0.5 * 4)
-    try:  # the exact-fp32-MFMA kernels behind the same entry point: one tile per workgroup (1), weight-stationary (2)
-        for variant in (1, 2):
+    try:  # other kernels behind the same entry point: tile kernel (1), exact-fp32 weight-stationary (2), bf16x6 with LDS-staged A (3)
+        for variant in (1, 2, 3):
             ops.set_tuning(2, variant)
             _assert_close(ops.linear(A.to(dev()), W.to(dev()), b.to(dev())), want, scale=float(k) ** 0.5 * 4)
     finally:

@@ -92,7 +92,8 @@ def main():
         print(f"  wave-specialised gate, {nm:36s} median {timed(gate, 10)[0]:.3f} ms")
     ops.set_tuning(1, 0)
     ops.set_tuning(0, 0)
-    lv = {1: "tile kernel, exact-fp32 MFMA", 2: "weight-stationary, exact-fp32 MFMA", 0: "weight-stationary, bf16x6 (default)"}
+    lv = {1: "tile kernel, bf16x6", 2: "weight-stationary, exact-fp32 MFMA", 3: "weight-stationary, bf16x6, A staged in LDS",
+          0: "streaming, bf16x6, barrier-free (default)"}
     res = {k: [] for k in lv}
     for _ in range(5):
         for k in lv:
@@ -100,7 +101,7 @@ def main():
             res[k].append(timed(lin, 5)[0])
     ops.set_tuning(2, 0)
     for k, v in res.items():
-        print(f"  linear [N,{H}]x[{H},{5 * H}] variant {lv[k]:28s} median {sorted(v)[len(v) // 2]:.3f}  min {min(v):.3f} ms")
+        print(f"  linear [N,{H}]x[{H},{5 * H}] variant {lv[k]:44s} median {sorted(v)[len(v) // 2]:.3f}  min {min(v):.3f} ms")
     # ablations (results are wrong by construction; timing only)
     abl = {0: "full", 1: "no node gathers", 2: "no e_out stores", 4: "no HBM tile loads", 7: "MFMA + LDS only"}
     res = {k: [] for k in abl}
