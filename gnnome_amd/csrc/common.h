@@ -45,6 +45,9 @@ struct GateBfArgs {
     GateEnc enc;              // mode 0 with the folded edge encoder
 };
 int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& args, hipStream_t s);
+// H = 256, affine norm, e_out != e_in: barrier-free streaming gate (edge_gate_stream.hip)
+int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn, const int32_t* ss,
+                       const int32_t* sd, const float* W3, int ldw, const float* scale, const float* shift, hipStream_t s);
 
 // C[M,K] += A[M,K] * W[K,K]^T for K in {64,128}, contiguous 16-byte aligned A and C: the wave-specialised
 // edge-tile kernel (edge_gate.hip) in accumulate mode; linear.hip routes the backward's [E,H] dgrad here.

@@ -609,6 +609,11 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
             return launch_gate_ws<2, 2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
         }
     }
+    // H = 256 with separate input and output buffers: the streaming kernel (its column chunks run in different workgroups,
+    // so it cannot update e in place; in place - or LayerNorm - goes to the 128-edge tile kernel below)
+    if (hidden == 256 && norm_kind == GNNOME_NORM_AFFINE && variant == 0 && e_in != e_out && ld_node % 4 == 0 &&
+        ((uintptr_t)e_out % 16 == 0))
+        return gate_stream_launch(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
     switch (hidden) {
         case 64: return launch_gate<2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);
         case 128: return launch_gate<4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);

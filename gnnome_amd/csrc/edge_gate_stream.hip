@@ -1,0 +1,157 @@
+// Edge gate for H = 256, where W3 fits neither the registers of four compute waves (edge_gate_bf.hip: 3 x 128 KB as bf16
+// planes) nor, whole, LDS.  Same barrier-free streaming scheme as k_linear_bf2: a workgroup of 8 waves keeps the three bf16
+// planes of ONE 64-column chunk of W3 in LDS (101 KB) and walks 256-edge tiles; every wave owns 32 edges x 64 output
+// columns, takes its e rows straight from global memory into MFMA fragments (bf16x6 product, gemm_tile.h), and applies the
+// gate epilogue in the accumulator layout: G = B1h[src] + B2h[dst] gathered as dwords (issued before the MFMA loop, added
+// after it), bn + relu + residual, 128-byte row-segment stores.  The four column chunks of a row run in different
+// workgroups, so the update CANNOT be in place: e_out must be a different buffer (the host ping-pongs two at H = 256).
+// With K = 256 a 32 x 64 output block carries 192 MFMAs against ~160 vector-memory instructions: the dword accesses
+// that sink the 128-edge tile kernel are a small part of the work here.
+#include "gemm_tile.h"
+
+namespace gnnome {
+
+template <int K>
+struct GateStream {
+    static constexpr int NW = 8, NT = 64 * NW, TM = 32 * NW, NC = 64, PLD = 2 * K + 16, kPlaneBytes = NC * PLD;
+    static constexpr int kWPieces = NC * (K / 4) / NT;
+    static_assert(NC * (K / 4) % NT == 0, "piece count");
+};
+
+template <int K>
+__global__ __launch_bounds__(512) void k_edge_gate_stream(const float* __restrict__ e_in, float* __restrict__ e_out, int64_t E,
+                                                          const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
+                                                          const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst,
+                                                          const float* __restrict__ W3, int ldw, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int num_tiles, int tiles_per_group) {
+    using P = GateStream<K>;
+    constexpr int PLD = P::PLD, PB = P::kPlaneBytes, KS = K / 16, H = K;
+    __shared__ __attribute__((aligned(16))) unsigned char Wp[3 * PB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 31, half = lane >> 5;
+    const int t0 = blockIdx.x * tiles_per_group, t_end = min(num_tiles, t0 + tiles_per_group);
+    if (t0 >= t_end) return;
+    const int col0 = blockIdx.y * P::NC;
+#pragma unroll
+    for (int it = 0; it < P::kWPieces; ++it) {   // split the W3 chunk once
+        const int f = tid + P::NT * it, row = f / (K / 4), c4 = f % (K / 4);
+        uint2 p1, p2, p3;
+        tile_split4(*reinterpret_cast<const f32x4*>(W3 + (int64_t)(col0 + row) * ldw + 4 * c4), p1, p2, p3);
+        unsigned char* dst = Wp + row * PLD + 8 * c4;
+        *reinterpret_cast<uint2*>(dst) = p1;
+        *reinterpret_cast<uint2*>(dst + PB) = p2;
+        *reinterpret_cast<uint2*>(dst + 2 * PB) = p3;
+    }
+    const float sc0 = scale[col0 + cl], sc1 = scale[col0 + 32 + cl], sh0 = shift[col0 + cl], sh1 = shift[col0 + 32 + cl];
+    __syncthreads();   // the only barrier
+
+    auto bf = [](const uint4 v) { return __builtin_bit_cast(tile_bf16x8, v); };
+    const unsigned char* wp = Wp + cl * PLD + 16 * half;
+    for (int t = t0; t < t_end; ++t) {
+        const int64_t row0 = (int64_t)t * P::TM + 32 * wave;
+        if (row0 >= E) continue;
+        const int64_t arow = min(row0 + cl, E - 1);   // rows past the end read the last row (never stored)
+        // the gathers of this tile go out first; they are consumed after the MFMA loop
+        const int my_s = srt_src[arow], my_d = srt_dst[arow];
+        float g0[16], g1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = cd_row(r, lane);
+            const int s = __shfl(my_s, lr), d = __shfl(my_d, lr);
+            const float* p1 = B1h + (int64_t)s * ldn + col0 + cl;
+            const float* p2 = B2h + (int64_t)d * ldn + col0 + cl;
+            g0[r] = p1[0] + p2[0];
+            g1[r] = p1[32] + p2[32];
+        }
+        const float* ap = e_in + arow * H + 8 * half;  // + 16 q
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = 0.f;
+            acc1[r] = 0.f;
+        }
+        // fragments are fetched two K = 16 steps at a time, one batch AHEAD of the MFMAs that consume them
+        f32x4 x[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            x[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * q);
+            x[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * q + 4);
+        }
+#pragma unroll
+        for (int hq = 0; hq < KS; hq += 2) {
+            f32x4 nx[2][2];
+            const int hn = hq + 2 < KS ? hq + 2 : hq;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                nx[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * (hn + q));
+                nx[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * (hn + q) + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the next batch's loads are in flight before this batch's MFMAs start
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                uint2 l1, l2, l3, h1, h2, h3;
+                tile_split4(x[q][0], l1, l2, l3);
+                tile_split4(x[q][1], h1, h2, h3);
+                const uint4 a1 = make_uint4(l1.x, l1.y, h1.x, h1.y), a2 = make_uint4(l2.x, l2.y, h2.x, h2.y),
+                            a3 = make_uint4(l3.x, l3.y, h3.x, h3.y);
+                const unsigned char* w = wp + 32 * (hq + q);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const uint4 w1 = *reinterpret_cast<const uint4*>(w + cb * 32 * PLD), w2 = *reinterpret_cast<const uint4*>(w + cb * 32 * PLD + PB),
+                                w3 = *reinterpret_cast<const uint4*>(w + cb * 32 * PLD + 2 * PB);
+                    f32x16 c = cb == 0 ? acc0 : acc1;   // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a3), bf(w1), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(w3), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2), bf(w2), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2), bf(w1), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(w2), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(w1), c, 0, 0, 0);
+                    if (cb == 0) {
+                        acc0 = c;
+                    } else {
+                        acc1 = c;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                x[q][0] = nx[q][0];
+                x[q][1] = nx[q][1];
+            }
+        }
+        // epilogue: e' = relu((e W3^T + G) * scale + shift) + e   (gated_gcn_full.py:104-110)
+        const float* res = e_in + row0 * H + col0 + cl;
+        float* out = e_out + row0 * H + col0 + cl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = cd_row(r, lane);
+            if (row0 + lr < E) {
+                const float* rr = res + (int64_t)lr * H;
+                float* o = out + (int64_t)lr * H;
+                o[0] = fmaxf((acc0[r] + g0[r]) * sc0 + sh0, 0.f) + rr[0];
+                o[32] = fmaxf((acc1[r] + g1[r]) * sc1 + sh1, 0.f) + rr[32];
+            }
+        }
+    }
+}
+
+int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn, const int32_t* ss,
+                       const int32_t* sd, const float* W3, int ldw, const float* scale, const float* shift, hipStream_t s) {
+    using P = GateStream<256>;
+    const int n_chunks = 256 / P::NC;
+    const int64_t tiles = (E + P::TM - 1) / P::TM;
+    GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
+    int groups = kNumCUs / n_chunks;   // one resident workgroup per CU (LDS); the four chunks of a group share an XCD's L2
+    if (groups >= kXcds) groups -= groups % kXcds;
+    if (groups > tiles) groups = (int)tiles;
+    if (groups < 1) groups = 1;
+    const int tpg = (int)((tiles + groups - 1) / groups);
+    hipLaunchKernelGGL((k_edge_gate_stream<256>), dim3(groups, n_chunks), dim3(P::NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd, W3,
+                       ldw, scale, shift, (int)tiles, tpg);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+}  // namespace gnnome

@@ -317,18 +317,18 @@ __global__ __launch_bounds__(64 * CB * RB) void k_linear_bf(const float* __restr
 // 128 contiguous bytes of one output row).  Latency is hidden by occupancy: ~150 VGPRs and 52 KB of LDS allow three
 // 4-wave workgroups (12 waves) per CU.
 // ---------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int NW_ = 4>
 struct LinBF2 {
-    static constexpr int NW = 4, NT = 64 * NW, TM = 32 * NW, NC = 64, PLD = 2 * K + 16, kPlaneBytes = NC * PLD;
+    static constexpr int NW = NW_, NT = 64 * NW, TM = 32 * NW, NC = 64, PLD = 2 * K + 16, kPlaneBytes = NC * PLD;
     static constexpr int kWPieces = NC * (K / 8) / NT;
     static_assert(NC * (K / 8) % NT == 0, "piece count");
 };
 
-template <int K>
-__global__ __launch_bounds__(256) void k_linear_bf2(const float* __restrict__ A, int64_t M, int lda, const float* __restrict__ W,
+template <int K, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_linear_bf2(const float* __restrict__ A, int64_t M, int lda, const float* __restrict__ W,
                                                     int ldw, const float* __restrict__ bias, float* __restrict__ C, int ldc,
                                                     int num_tiles, int tiles_per_group, int accumulate) {
-    using P = LinBF2<K>;
+    using P = LinBF2<K, NW>;
     constexpr int PLD = P::PLD, PB = P::kPlaneBytes, KS = K / 16, HS = 2;   // fragments are fetched two K = 16 steps at a time
     __shared__ __attribute__((aligned(16))) unsigned char Wp[3 * PB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -364,14 +364,23 @@ __global__ __launch_bounds__(256) void k_linear_bf2(const float* __restrict__ A,
             acc0[r] = b0;
             acc1[r] = b1;
         }
+        // fragments are fetched HS K = 16 steps at a time, one batch AHEAD of the MFMAs that consume them
+        f32x4 x[HS][2];
+#pragma unroll
+        for (int q = 0; q < HS; ++q) {
+            x[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * q);
+            x[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * q + 4);
+        }
 #pragma unroll
         for (int hq = 0; hq < KS; hq += HS) {
-            f32x4 x[HS][2];
+            f32x4 nx[HS][2];
+            const int hn = hq + HS < KS ? hq + HS : hq;
 #pragma unroll
             for (int q = 0; q < HS; ++q) {
-                x[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * (hq + q));
-                x[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * (hq + q) + 4);
+                nx[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * (hn + q));
+                nx[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * (hn + q) + 4);
             }
+            __builtin_amdgcn_sched_barrier(0);   // the next batch's loads are in flight before this batch's MFMAs start
 #pragma unroll
             for (int q = 0; q < HS; ++q) {
                 uint4 a1, a2, a3;
@@ -395,7 +404,12 @@ __global__ __launch_bounds__(256) void k_linear_bf2(const float* __restrict__ A,
                     }
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the next batch's loads here: hoisted to the top they cost 64 registers
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < HS; ++q) {
+                x[q][0] = nx[q][0];
+                x[q][1] = nx[q][1];
+            }
         }
         float* out = C + row0 * ldc + col0 + cl;
 #pragma unroll
@@ -415,19 +429,20 @@ __global__ __launch_bounds__(256) void k_linear_bf2(const float* __restrict__ A,
     }
 }
 
-template <int K>
+template <int K, int NW = 4, int WGS_PER_CU = 3>
 static int launch_linear_bf2(const float* A, int64_t M, int lda, const float* W, int ldw, const float* bias, int Nout, float* C,
                              int ldc, hipStream_t s, int accumulate) {
-    using P = LinBF2<K>;
+    using P = LinBF2<K, NW>;
     const int n_chunks = Nout / P::NC;
     const int64_t tiles = (M + P::TM - 1) / P::TM;
     GN_REQUIRE(tiles < (1ll << 31), "linear: too many tiles");
-    int groups = 3 * kNumCUs / n_chunks;   // three resident workgroups per CU; all chunks of a group share an XCD (see launch_linear_ws)
+    int groups = WGS_PER_CU * kNumCUs / n_chunks;   // resident workgroups per CU (LDS: 52 KB of W planes at K = 128, 101 KB at 256); all
+                                                   // chunks of a group share an XCD (see launch_linear_ws)
     if (groups >= kXcds) groups -= groups % kXcds;
     if (groups < 1) groups = 1;
     if (groups > tiles) groups = (int)tiles;
     const int tpg = (int)((tiles + groups - 1) / groups);
-    hipLaunchKernelGGL((k_linear_bf2<K>), dim3(groups, n_chunks), dim3(P::NT), 0, s, A, M, lda, W, ldw, bias, C, ldc, (int)tiles, tpg,
+    hipLaunchKernelGGL((k_linear_bf2<K, NW>), dim3(groups, n_chunks), dim3(P::NT), 0, s, A, M, lda, W, ldw, bias, C, ldc, (int)tiles, tpg,
                        accumulate);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
@@ -501,6 +516,8 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
     if (tuning(kTuneLinearVariant) == 0 && ldw % 4 == 0 && Nout % 64 == 0) {   // the shipped default: bf16x6, barrier-free streaming
         if (K == 128) return launch_linear_bf2<128>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
         if (K == 64) return launch_linear_bf2<64>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+        // (K = 256: 101 KB of W planes leave one 8-wave workgroup per CU, too few waves to hide the fragment fetches:
+        //  1.06 ms against 0.91 ms for the tile kernel at N = 250k, Nout = 1280 - measured, so K = 256 falls through)
     }
     if (tuning(kTuneLinearVariant) == 3 && aligned_out && ldw % 4 == 0) {   // 3: bf16x6 with A staged through LDS
         if (K == 128 && Nout % 64 == 0) return launch_linear_bf<128, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);

@@ -262,6 +262,7 @@ def run_partitioned(ops, prep, part, x_local, e_local, group=None, reduce_result
     H = prep.hidden
     h = ops.encode(x_local, *prep.enc_node)  # halo rows of layer 0 come straight from the input features
     e = engine.encode_edges(ops, prep, views, e_local)   # None: layer 0's gate encodes the edge tile itself
+    scratch = {}
     for li, lw in enumerate(prep.layers):
         if li > 0:
             xchg.start(h)
@@ -270,7 +271,7 @@ def run_partitioned(ops, prep, part, x_local, e_local, group=None, reduce_result
         if e is None:
             e = ops.edge_gate_encode(e_local, prep.enc_edge, B1, B2, views, lw.W3, lw.scale_e, lw.shift_e)
         else:
-            ops.edge_gate(e, B1, B2, views, lw.W3, lw.norm, lw.scale_e, lw.shift_e)
+            e = engine.gate_update(ops, lw, views, e, B1, B2, scratch)
         h = ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_own)
     xchg.start(h)
     pw = prep.predictor

@@ -132,8 +132,23 @@ def _refuse_training(module):
 # kernel sequences (ops = gnnome_amd.ops in the product)
 # ---------------------------------------------------------------------------------------------------
 
-def layer_step(ops, lw, views, h, e, n_out=None, raw_edges=None):
-    """One SymGatedGCN layer on sorted-order e (updated in place); returns (new h, e).  With e = None and
+def gate_update(ops, lw, views, e, B1, B2, scratch=None):
+    """e <- gate(e): in place, except at H = 256 with the affine norm, where the streaming kernel needs separate input
+    and output buffers (its column chunks run in different workgroups): two [E,H] buffers then take turns, the spare
+    one lives in `scratch` for the duration of the forward."""
+    if scratch is not None and e.shape[1] == 256 and lw.norm == 0 and getattr(ops, "edge_gate_out_of_place_at_256", False):
+        spare = scratch.get("e_spare")
+        if spare is None or spare.shape != e.shape or spare.device != e.device:
+            spare = torch.empty_like(e)
+        ops.edge_gate(e, B1, B2, views, lw.W3, lw.norm, lw.scale_e, lw.shift_e, out=spare)
+        scratch["e_spare"] = e
+        return spare
+    ops.edge_gate(e, B1, B2, views, lw.W3, lw.norm, lw.scale_e, lw.shift_e)
+    return e
+
+
+def layer_step(ops, lw, views, h, e, n_out=None, raw_edges=None, scratch=None):
+    """One SymGatedGCN layer on sorted-order e (updated in place, see gate_update); returns (new h, e).  With e = None and
     raw_edges = (e_raw, encoder weights) the edge encoder is folded into the gate (layer 0)."""
     H = h.shape[1]
     P = ops.linear(h, lw.Wcat, lw.bcat)
@@ -143,7 +158,7 @@ def layer_step(ops, lw, views, h, e, n_out=None, raw_edges=None):
     if e is None:
         e = ops.edge_gate_encode(raw_edges[0], raw_edges[1], B1, B2, views, lw.W3, lw.scale_e, lw.shift_e)
     else:
-        ops.edge_gate(e, B1, B2, views, lw.W3, lw.norm, lw.scale_e, lw.shift_e)
+        e = gate_update(ops, lw, views, e, B1, B2, scratch)
     return ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_out), e
 
 
@@ -171,10 +186,11 @@ def run_stack(ops, prep, views, x, e_raw, exchange=None, n_own=None, n_score=Non
     sorted positions (both used by the destination-range partition, dist.py)."""
     h = ops.encode(x, *prep.enc_node)
     e = encode_edges(ops, prep, views, e_raw)
+    scratch = {}
     for lw in prep.layers:
         if exchange is not None:
             h = exchange(h)
-        h, e = layer_step(ops, lw, views, h, e, n_out=n_own, raw_edges=(e_raw, prep.enc_edge))
+        h, e = layer_step(ops, lw, views, h, e, n_out=n_own, raw_edges=(e_raw, prep.enc_edge), scratch=scratch)
     if exchange is not None:
         h = exchange(h)
     if logits is None:

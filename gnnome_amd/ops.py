@@ -102,6 +102,9 @@ class GraphViews:
         return r
 
 
+edge_gate_out_of_place_at_256 = True   # engine.gate_update: the H = 256 streaming gate needs out != e
+
+
 def set_tuning(key, value):
     """Select a kernel variant for A/B measurements (see gnnome_set_tuning in include/gnnome_hip.h)."""
     _lib.check(_lib.load().gnnome_set_tuning(int(key), int(value)), "set_tuning")

