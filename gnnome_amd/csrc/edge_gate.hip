@@ -227,7 +227,7 @@ __device__ __forceinline__ void flag_wait(unsigned addr, unsigned want, int nap 
     for (;;) {
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
         if (__builtin_amdgcn_readfirstlane(v) >= want) break;
-        if (++spins > (1u << 22)) __builtin_trap();  // a lost hand-over must end the launch, not hang the queue
+        if (++spins > (1u << 26)) __builtin_trap();  // a lost hand-over must end the launch, not hang the queue
         // consumers (nap 3) poll tightly: their wait is on the critical path.  Producers run a whole slot ahead and
         // poll rarely (nap 0 = 64 x 64 cycles): their ds_reads compete with the compute waves' operand reads.
         if (nap == 0) {

@@ -47,7 +47,7 @@ __device__ __forceinline__ void flag_wait_bf(unsigned addr, unsigned want, int n
     for (;;) {
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
         if (__builtin_amdgcn_readfirstlane(v) >= want) break;
-        if (++spins > (1u << 22)) __builtin_trap();  // a lost hand-over must end the launch, not hang the queue
+        if (++spins > (1u << 26)) __builtin_trap();  // a lost hand-over must end the launch, not hang the queue
         if (nap == 0) {
             __builtin_amdgcn_s_sleep(1);
         } else if (nap == 1) {
