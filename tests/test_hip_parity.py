@@ -445,3 +445,15 @@ def test_full_size_properties(n, e, hidden):
     perm = torch.randperm(e, generator=torch.Generator().manual_seed(3)).to(dev())
     d = m((graph[0][perm], graph[1][perm], n), x, ef[perm])
     assert _prob_diff(a[perm], d) < PROB_TOL
+
+
+def test_counter_synchronised_kernels_soak():
+    """tools/gate_soak.py: a few hundred launches of the edge-tile kernels at random sizes and in every mode, each checked
+    against the barrier-synchronised / tile kernels; bounded, so that a lost hand-over fails the test instead of hanging it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "gate_soak.py"), "3", "300"], capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0 and "soak ok" in res.stdout, res.stdout[-500:] + res.stderr[-500:]
