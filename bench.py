@@ -193,10 +193,24 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.one_gpu_gloo:
+        gloo_transport = args.one_gpu_gloo
+        if gloo_transport:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            try:   # RCCL over xGMI; a collective is run right away so that a broken transport shows here, on every rank alike
+                dist.init_process_group("nccl", device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as ex:  # noqa: BLE001 - keep the scaling run alive on host-staged gloo and SAY so in the line
+                print(f"[bench] rank {rank}: RCCL unavailable ({type(ex).__name__}: {ex}); falling back to host-staged gloo", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                dist.init_process_group("gloo")
+                gloo_transport = True
 
     n, e, hidden = WORKLOADS[args.workload]
     g = make_graph(n, e, seed=1, kind=args.kind)
@@ -298,7 +312,8 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-        parallelism = f"dst-range x{world}" + (" (ALL RANKS ON ONE GPU over gloo: plumbing check, not a measurement)" if args.one_gpu_gloo else "")
+        parallelism = f"dst-range x{world}" + (" (ALL RANKS ON ONE GPU over gloo: plumbing check, not a measurement)" if args.one_gpu_gloo
+                                               else " (RCCL FAILED: host-staged gloo transport)" if gloo_transport else "")
 
     # HIP events in the timed region go around ONE launch of the dominant kernel per step (the 8 layers launch
     # the same shape): a pair around every launch of every kernel cost ~1.6 ms per step here (56 events, ~28 us
@@ -328,7 +343,7 @@ def main():
     timed = dominant
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.one_gpu_gloo else dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo_transport else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
