@@ -257,7 +257,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_ws(
     GateEnc enc, int xp, float* __restrict__ stats = nullptr) {
     static_assert(MODE == 0 || (FLAGS && !ENC && ABL == 0), "raw modes: counter hand-over only");
     using P = GateWS<CB, RB>;
-    constexpr int H = P::H, TM = P::TM, LDK = P::LDK, QS = H / 8, EPQ = 16 / QS, NP = P::NP, SLOT = P::kSlotFloats;
+    constexpr int H = P::H, TM = P::TM, LDK = P::LDK, QS = H / 8, NP = P::NP, SLOT = P::kSlotFloats;
     constexpr int kEncFloats = ENC ? 16 * H + H + 48 : 0;  // W2^T [16][H], b2 [H], W1 [32], b1 [16]
     __shared__ __attribute__((aligned(16))) float lds[P::kLdsFloats + kEncFloats];
     float* Aring = lds;                       // [RING][TM][LDK]  e tiles
