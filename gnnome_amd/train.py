@@ -59,6 +59,12 @@ class WholeGraph:
         return logits
 
 
+def dropout_mask(rows, cols, p, device):
+    """Scaled keep-mask of F.dropout(h, p, training=True) (gated_gcn_full.py:139): Bernoulli(1 - p) / (1 - p), drawn from
+    torch's generator of `device`.  A module-level function so that the tests can substitute known masks."""
+    return torch.empty((rows, cols), dtype=torch.float32, device=device).bernoulli_(1.0 - p).div_(1.0 - p)
+
+
 def _cat_layer(conv):
     Wcat = torch.cat([conv.A_1.weight, conv.A_2.weight, conv.A_3.weight, conv.B_1.weight, conv.B_2.weight], 0).detach().contiguous()
     bcat = torch.cat([conv.A_1.bias, conv.A_2.bias, conv.A_3.bias, conv.B_1.bias, conv.B_2.bias + conv.B_3.bias], 0).detach().contiguous()
@@ -150,7 +156,7 @@ class _TrainStep(torch.autograd.Function):
                 ops.bn_relu_res(v[:n_own], sc_h, sh_h, h[:n_own], out=h_next[:n_own])
             mask = None
             if conv.dropout > 0.0:
-                mask = new(n_own, H).bernoulli_(1.0 - conv.dropout).div_(1.0 - conv.dropout)
+                mask = dropout_mask(n_own, H, conv.dropout, x.device)
                 h_next[:n_own].copy_(ops.mul23(h_next[:n_own], mask, mask)[0])
             saved.append(dict(h=h, P=P, e=e, xe=xe, e_new=e_new, mean_e=mean_e, rstd_e=rstd_e, v=v, hf=hf, rdf=rdf, hb=hb, rdb=rdb,
                               mean_h=mean_h, rstd_h=rstd_h, mask=mask, Wcat=Wcat, sc_e=sc_e, sh_e=sh_e, sc_h=sc_h, sh_h=sh_h))

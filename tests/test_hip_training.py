@@ -362,3 +362,43 @@ def test_layernorm_training_step_matches_reference_golden_g8():
     F.binary_cross_entropy_with_logits(got.squeeze(-1), gr["y"].to(dev()), pos_weight=gr["pos_weight"].to(dev())).backward()
     assert (torch.sigmoid(got.detach().cpu()) - torch.sigmoid(want.detach())).abs().max().item() < 1e-4
     _check_grads({k: p.grad for k, p in m.named_parameters()}, {k: p.grad for k, p in om.named_parameters()}, rtol=3e-2)
+
+
+def test_dropout_training_step_matches_the_checker_backend_with_the_same_masks(monkeypatch):
+    """dropout = 0.2 (the reference's default, configs/hyperparameters.py:29): GPU step against the CPU checker-backend
+    step - itself pinned to oracle autograd in tests/test_train_host.py - with identical masks injected into both."""
+    from gnnome_amd import train as gtrain
+    from gnnome_amd.train import WholeGraph, train_forward_on
+    n, e, H, L, p = 3000, 30000, 128, 8, 0.2
+    gr = make_graph(n, e, seed=17)
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(H, num_layers=L, seed=8)
+    g = torch.Generator().manual_seed(5)
+    masks = [(torch.rand(n, H, generator=g) >= p).float() / (1.0 - p) for _ in range(L)]
+    results = []
+    for where in ("cpu", "gpu"):
+        it = iter(masks)
+        monkeypatch.setattr(gtrain, "dropout_mask", lambda rows, cols, pp, device: next(it).to(device))
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, H, 16, L, 64, "batch", dropout=p)
+        m.load_state_dict(sd)
+        if where == "cpu":
+            m.train()
+            logits = train_forward_on(m, WholeGraph(cpu_ops.CpuViews(gr["src"], gr["dst"], n), cpu_ops), x, gr["e"])
+            y, pw = gr["y"], gr["pos_weight"]
+        else:
+            m.to(dev()).train()
+            logits = m((gr["src"], gr["dst"], n), x.to(dev()), gr["e"].to(dev()))
+            y, pw = gr["y"].to(dev()), gr["pos_weight"].to(dev())
+        F.binary_cross_entropy_with_logits(logits.squeeze(-1), y, pos_weight=pw).backward()
+        results.append((logits.detach().cpu(), {k: q.grad.cpu() for k, q in m.named_parameters()}))
+    monkeypatch.undo()
+    assert (torch.sigmoid(results[1][0]) - torch.sigmoid(results[0][0])).abs().max().item() < 1e-4
+    _check_grads(results[1][1], results[0][1], rtol=3e-2)
+    # the default generator on the device
+    mk = gtrain.dropout_mask(4000, 64, 0.2, dev())
+    assert set(mk.unique().tolist()) == {0.0, 1.25} and abs(mk.mean().item() - 1.0) < 0.02
+    # and eval mode ignores dropout
+    m.eval()
+    with torch.no_grad():
+        a, b = m((gr["src"], gr["dst"], n), x.to(dev()), gr["e"].to(dev())), m((gr["src"], gr["dst"], n), x.to(dev()), gr["e"].to(dev()))
+    assert torch.equal(a, b)

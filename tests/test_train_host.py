@@ -50,3 +50,48 @@ def test_layernorm_training_step_on_checker_backend_matches_reference_golden_g8(
     assert (torch.sigmoid(logits.detach()) - torch.sigmoid(g["logits"])).abs().max().item() < 1e-4
     assert abs(loss.item() - g["loss"].item()) < 1e-5
     check_grads({k: p.grad for k, p in m.named_parameters()}, g["grads"], rtol=1e-3)
+
+
+def _fixed_masks(n, H, layers, p, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.rand(n, H, generator=g) >= p).float() / (1.0 - p) for _ in range(layers)]
+
+
+def test_dropout_training_step_matches_oracle_autograd_with_the_same_masks(monkeypatch):
+    """dropout = 0.2 is the reference's default training configuration (configs/hyperparameters.py:29).  The masks are
+    random, so both sides are given the SAME ones: the oracle through F.dropout, the step through train.dropout_mask."""
+    import oracle.symgated_oracle as osg
+    from gnnome_amd import train as gtrain
+    from gnnome_amd.synth import make_graph
+    n, e, H, L, p = 300, 3000, 64, 3, 0.2
+    gr = make_graph(n, e, seed=13)
+    x = osg.degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(H, num_layers=L, seed=7)
+    masks = _fixed_masks(n, H, L, p, seed=99)
+
+    it = iter(masks)
+    monkeypatch.setattr(osg.F, "dropout", lambda h, pp, training=True: h * next(it) if training and pp > 0 else h)
+    om = osg.OracleModel(2, 2, H, 16, L, 64, "batch", dropout=p)
+    om.load_state_dict(sd)
+    om.train()
+    want = om((gr["src"], gr["dst"], n), x, gr["e"])
+    want_loss = osg.bce_loss(want, gr["y"], gr["pos_weight"])
+    want_loss.backward()
+    monkeypatch.undo()
+
+    it2 = iter(masks)
+    monkeypatch.setattr(gtrain, "dropout_mask", lambda rows, cols, pp, device: next(it2).to(device))
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, H, 16, L, 64, "batch", dropout=p)
+    m.load_state_dict(sd)
+    m.train()
+    views = cpu_ops.CpuViews(gr["src"], gr["dst"], n)
+    got = train_forward_on(m, WholeGraph(views, cpu_ops), x, gr["e"])
+    loss = F.binary_cross_entropy_with_logits(got.squeeze(-1), gr["y"], pos_weight=gr["pos_weight"])
+    loss.backward()
+    assert (torch.sigmoid(got.detach()) - torch.sigmoid(want.detach())).abs().max().item() < 1e-4
+    assert abs(loss.item() - want_loss.item()) < 1e-5
+    check_grads({k: q.grad for k, q in m.named_parameters()}, {k: q.grad for k, q in om.named_parameters()}, rtol=2e-3)
+    # and the default mask generator: right mean, right support
+    monkeypatch.undo()
+    mk = gtrain.dropout_mask(2000, 64, 0.2, torch.device("cpu"))
+    assert set(mk.unique().tolist()) == {0.0, 1.25} and abs(mk.mean().item() - 1.0) < 0.02
