@@ -257,14 +257,24 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
         };
         // ENC: e0[p,:] = W2e relu(W1e e_raw + b1e) + b2e for this lane's pieces (models/full_graph.py:27)
         auto encode_pending = [&]() {
+            // in the reference's order (torch nn.Linear on the CPU = k-ascending fma chain from zero, then + bias)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) av[p] = *reinterpret_cast<const f32x4*>(b2s + 4 * c4);
+            for (int p = 0; p < NP; ++p) av[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
             for (int j = 0; j < 16; ++j) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(w2t + j * H + 4 * c4);
                 const float wa = w1s[2 * j], wb = w1s[2 * j + 1], bj = b1s[j];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) av[p] += fmaxf(fmaf(wb, raw1[p], fmaf(wa, raw0[p], bj)), 0.f) * w;
+                for (int p = 0; p < NP; ++p) {
+                    const float t = fmaxf(__builtin_fmaf(raw1[p], wb, raw0[p] * wa) + bj, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) av[p][i] = __builtin_fmaf(t, w[i], av[p][i]);
+                }
+            }
+            {
+                const f32x4 b2v = *reinterpret_cast<const f32x4*>(b2s + 4 * c4);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) av[p] += b2v;
             }
         };
         if (group < n) {

@@ -45,26 +45,26 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(const float* __restrict_
         for (int k = 0; k < KMAX; ++k) {
             const int j = li + k * LPR;
             float s = 0.f;
-            if (j < M) {
-                s = b1s[j];
+            if (j < M) {   // torch's nn.Linear on the CPU: one k-ascending fma chain from zero, bias added afterwards
 #pragma unroll
                 for (int f = 0; f < kEncMaxF; ++f)
-                    if (f < F) s += w1s[j * F + f] * xin[f];
-                s = fmaxf(s, 0.f);
+                    if (f < F) s = __builtin_fmaf(xin[f], w1s[j * F + f], s);
+                s = fmaxf(s + b1s[j], 0.f);
             }
             t[k] = s;
         }
-        f32x4 acc = bias;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int jn = min(LPR, M - k * LPR);
             for (int jj = 0; jj < jn; ++jj) {
                 const float tj = __shfl(t[k], lane_base + jj);
                 const f32x4 w = *reinterpret_cast<const f32x4*>(&w2t[(k * LPR + jj) * H + c]);
-                acc += tj * w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(tj, w[i], acc[i]);
             }
         }
-        if (live) *reinterpret_cast<f32x4*>(out + r * H + c) = acc;
+        if (live) *reinterpret_cast<f32x4*>(out + r * H + c) = acc + bias;
     }
 }
 
@@ -101,13 +101,16 @@ __global__ __launch_bounds__(kEncThreads) void k_encode_f2m16(const float* __res
     for (int64_t r = (int64_t)blockIdx.x * RPB + rg; r < rows; r += (int64_t)gridDim.x * RPB) {
         const int64_t rin = gather != nullptr ? (int64_t)gather[r] : r;
         const float x0 = in[2 * rin], x1 = in[2 * rin + 1];
-        f32x4 acc = bias;
+        // the reference's order (torch nn.Linear on the CPU: k-ascending fma chain from zero, then + bias; see
+        // reference_order.hip) - two more VALU operations per hidden unit than the bias-first form, nothing at this size
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-            const float t = fmaxf(fmaf(w1b[j], x1, fmaf(w1a[j], x0, bb[j])), 0.f);
-            acc += t * w2[j];
+            const float t = fmaxf(__builtin_fmaf(x1, w1b[j], x0 * w1a[j]) + bb[j], 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(t, w2[j][i], acc[i]);
         }
-        *reinterpret_cast<f32x4*>(out + r * H + c) = acc;
+        *reinterpret_cast<f32x4*>(out + r * H + c) = acc + bias;
     }
 }
 

@@ -246,10 +246,10 @@ def _project(ops, lw, h, n_own, xchg):
     """P = h * Wcat^T + bcat; the owned rows are projected while the halo rows are still in flight."""
     P = torch.empty((h.shape[0], lw.Wcat.shape[0]), dtype=torch.float32, device=h.device)
     if n_own > 0:
-        ops.linear(h[:n_own], lw.Wcat, lw.bcat, out=P[:n_own])
+        engine.project(ops, lw, h[:n_own], out=P[:n_own])
     xchg.finish()
     if h.shape[0] > n_own:
-        ops.linear(h[n_own:], lw.Wcat, lw.bcat, out=P[n_own:])
+        engine.project(ops, lw, h[n_own:], out=P[n_own:])
     return P
 
 
@@ -268,10 +268,7 @@ def run_partitioned(ops, prep, part, x_local, e_local, group=None, reduce_result
             xchg.start(h)
         P = _project(ops, lw, h, n_own, xchg)
         A1, A2, A3, B1, B2 = (P[:, i * H:(i + 1) * H] for i in range(5))
-        if e is None:
-            e = ops.edge_gate_encode(e_local, prep.enc_edge, B1, B2, views, lw.W3, lw.scale_e, lw.shift_e)
-        else:
-            e = engine.gate_update(ops, lw, views, e, B1, B2, scratch)
+        e = engine.gate(ops, lw, views, e, B1, B2, (e_local, prep.enc_edge), scratch)
         h = ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_own)
     xchg.start(h)
     pw = prep.predictor

@@ -16,6 +16,8 @@ from .graph import views_for
 
 
 class SymGatedGCN(nn.Module):
+    arithmetic = "auto"   # see SymGatedGCNModel.arithmetic (layer-level API)
+
     def __init__(self, in_channels, out_channels, normalization, dropout=None, residual=True):
         super().__init__()
         if in_channels != out_channels:

@@ -12,6 +12,10 @@ weights/weights.pt, same call.  Differences, all deliberate:
     HIP device and the logits are returned on the inputs' device.  The compute always runs on the
     MI355X; without the HIP library or a GPU the call raises.
   * the stray `print(x.shape)` of models/full_graph.py:25 is not reproduced.
+  * `model.arithmetic` ("auto" | "reference" | "fast", default "auto") chooses, per layer, between the bf16x6
+    matrix-core kernels and kernels that evaluate the layer's dense products in the reference's own ORDER (bit for bit
+    what torch's CPU nn.Linear computes); "auto" uses the latter for layers whose eval-BatchNorm gain magnifies fp32
+    reorder noise (engine.REFERENCE_ORDER_GAIN; the shipped checkpoint's layer 0).  Eval mode only.
 """
 import torch.nn as nn
 
@@ -20,6 +24,8 @@ from .layers import ScorePredictor, SymGatedGCN_processor
 
 
 class SymGatedGCNModel(nn.Module):
+    arithmetic = "auto"
+
     def __init__(self, node_features, edge_features, hidden_features, hidden_ne_features, num_layers,
                  hidden_edge_scores, normalization, dropout=None):
         super().__init__()

@@ -178,6 +178,57 @@ def edge_gate_encode(e_raw, enc, B1h, B2h, views, W3, scale, shift):
     return out
 
 
+def linear_ref(A, W, bias, out=None):
+    """out[M,Nout] = A @ W.T + bias in the REFERENCE'S ORDER of evaluation (k-ascending fma chain from zero, bias added
+    afterwards: what torch's CPU nn.Linear computes, bit for bit).  K in {64,128}, Nout % 8 == 0."""
+    lib = _lib.load()
+    A, lda = _rows(A, "linear_ref.A")
+    W, ldw = _rows(W, "linear_ref.W")
+    M, K = A.shape
+    Nout = W.shape[0]
+    if out is None:
+        out = torch.empty((M, Nout), dtype=torch.float32, device=A.device)
+    out, ldc = _rows(out, "linear_ref.out")
+    with _on(A.device):
+        _lib.check(lib.gnnome_linear_ref_f32(_ptr(A), M, K, lda, _ptr(W), ldw, _ptr(bias), Nout, _ptr(out), ldc, _stream(A.device)),
+                   "linear_ref_f32")
+    return out
+
+
+def reference_order_supported(hidden, norm_kind, B1h=None):
+    """Shapes the reference-order kernels take (gnnome_linear_ref_f32 / gnnome_edge_gate_ref_f32)."""
+    return hidden in (64, 128) and norm_kind == NORM_AFFINE
+
+
+def edge_gate_ref(e, B1h, B2h, views, W3, b3, scale, shift, raw_edges=None, num_edges=None):
+    """The gate in the reference's order of evaluation (see gnnome_edge_gate_ref_f32); b3 separate, NOT folded into B2h.
+    e[E,H] is updated in place and returned; with e = None and raw_edges = (e_raw, (W1, b1, W2, b2)) the edge encoder's
+    output is computed on the fly (layer 0) and a fresh e'[E,H] is returned."""
+    lib = _lib.load()
+    B1h, ldn = _rows(B1h, "edge_gate_ref.B1h")
+    B2h, ldn2 = _rows(B2h, "edge_gate_ref.B2h")
+    W3, ldw = _rows(W3, "edge_gate_ref.W3")
+    assert ldn == ldn2
+    H = W3.shape[0]
+    if e is None:
+        e_raw, (W1, b1, W2, b2) = raw_edges
+        e_raw = _dense(e_raw, "edge_gate_ref.e_raw")
+        E = views.num_edges if num_edges is None else int(num_edges)
+        out = torch.empty((views.num_edges, H), dtype=torch.float32, device=e_raw.device)
+        enc = (_ptr(e_raw), _ptr(views.srt_eid), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2))
+        e_in = _ptr(None)
+    else:
+        e = _dense(e, "edge_gate_ref.e")
+        E = int(e.shape[0] if num_edges is None else num_edges)
+        out, e_in = e, _ptr(e)
+        enc = (_ptr(None),) * 6
+    with _on(out.device):
+        _lib.check(lib.gnnome_edge_gate_ref_f32(e_in, _ptr(out), E, H, _ptr(B1h), _ptr(B2h), ldn, _ptr(views.srt_src),
+                                                _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(b3), _ptr(scale), _ptr(shift), *enc,
+                                                _stream(out.device)), "edge_gate_ref_f32")
+    return out
+
+
 def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_nodes_out=None):
     lib = _lib.load()
     A1h, ldn = _rows(A1h, "node_aggregate.A1h")

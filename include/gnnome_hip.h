@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 3
+#define GNNOME_ABI_VERSION 4
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -88,10 +88,16 @@ int gnnome_encode_f32(const float* in, int64_t rows, int in_features, const int3
                       int hidden, float* out, void* stream);
 
 /* ---- dense linear on the matrix cores -----------------------------------------------------------
- * C[M,Nout] = A[M,K] * W[Nout,K]^T + bias (torch nn.Linear layout), exact fp32 (v_mfma_f32_32x32x2_f32).
+ * C[M,Nout] = A[M,K] * W[Nout,K]^T + bias (torch nn.Linear layout).
  * Replaces the five node projections A_1,A_2,A_3,B_1,B_2 (gated_gcn_full.py:91-96, one call with the
  * weights concatenated) and the node halves of predictor.W1 (score_predictor.py:13-14).
- *   K % 64 == 0; bias may be NULL; A and W 16-byte aligned with lda, ldw % 4 == 0
+ * Arithmetic: the fp32-faithful "bf16x6" product on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): every fp32
+ * operand is split EXACTLY into three bf16 and six of the nine partial products are accumulated in fp32; the dropped
+ * terms are <= 3 * 2^-24 |a b| per product, i.e. one fp32 rounding, so |C - exact| <= ~(K + 3) * 2^-24 * sum|a b| like
+ * any fp32 dot product - but the fp32 number produced is not the one a k-ordered fma chain produces (see
+ * gnnome_linear_ref_f32 for that).  The exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) stay selectable with
+ * gnnome_set_tuning(2, 2).
+ *   K % 32 == 0; bias may be NULL; A and W 16-byte aligned with lda, ldw % 4 == 0
  */
 int gnnome_linear_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias,
                       int Nout, float* C, int ldc, void* stream);
@@ -120,6 +126,30 @@ int gnnome_edge_gate_encode_f32(const float* e_raw, const int32_t* srt_eid, cons
                                 const float* B1h, const float* B2h, int ld_node, const int32_t* srt_src,
                                 const int32_t* srt_dst, const float* W3, int ldw, const float* norm_scale,
                                 const float* norm_shift, void* stream);
+
+/* ---- the same two operations in the REFERENCE'S ORDER of evaluation --------------------------------
+ * torch's CPU nn.Linear evaluates every output element as one k-ascending chain of fused multiply-adds that starts
+ * from zero and adds the bias afterwards; its eval-mode BatchNorm1d is fma(x, alpha, beta).  These two entry points
+ * reproduce that sequence operation for operation, so their results equal the reference's CPU results BIT FOR BIT on
+ * equal inputs (tests/test_reference_order.py) - which matters for layers whose normalisation magnifies reorder noise
+ * (weights/weights.pt layer 0: bn_e gain up to 135).  One row per lane, weights through scalar
+ * loads, fp32 VALU.  K / hidden in {64,128}.
+ *
+ * gnnome_linear_ref_f32: C[M,Nout] = chain(A W^T) + bias;  Nout % 8 == 0  (gated_gcn_full.py:91-96)
+ * gnnome_edge_gate_ref_f32 (gated_gcn_full.py:97,104-110; B_3's bias is NOT folded into B2h here):
+ *   B3e  = chain(e W3^T) + b3
+ *   x    = (B1h[srt_src[p]] + B2h[srt_dst[p]]) + B3e
+ *   e'   = max(fma(x, norm_scale, norm_shift), 0) + e
+ *   with e = e_in[p,:], or - when e_raw != NULL - the edge encoder's output for edge srt_eid[p], computed in registers
+ *   in the same order (models/full_graph.py:27; in_features 2, hidden_ne 16).  e_out may alias e_in.
+ */
+int gnnome_linear_ref_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias, int Nout,
+                          float* C, int ldc, void* stream);
+int gnnome_edge_gate_ref_f32(const float* e_in, float* e_out, int64_t num_edges, int hidden, const float* B1h,
+                             const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst, const float* W3,
+                             int ldw, const float* b3, const float* norm_scale, const float* norm_shift, const float* e_raw,
+                             const int32_t* srt_eid, const float* encW1, const float* encb1, const float* encW2,
+                             const float* encb2, void* stream);
 
 /* ---- fused gated aggregation + node update -------------------------------------------------------
  * For every node i < num_nodes_out, with s_p = sigmoid(e[p,:]):
@@ -228,7 +258,8 @@ int gnnome_relu_bwd_f32(const float* dy, const float* y, int64_t count, float* d
 int gnnome_segment_sum_f32(const float* X, int width, const int32_t* ptr, const int32_t* pos, int64_t num_nodes,
                            float* out, int ld_out, void* stream);
 
-/* C[Ka,Kb] = A[rows,Ka]^T * B[rows,Kb]: nn.Linear weight gradients, exact fp32 MFMA, chunked over rows with a
+/* C[Ka,Kb] = A[rows,Ka]^T * B[rows,Kb]: nn.Linear weight gradients on the bf16 matrix cores as the fp32-faithful
+ * bf16x6 product (see gnnome_linear_f32; error of the size of an fp32 dot product's), chunked over rows with a
  * deterministic second-stage sum.  Ka, Kb % 4 == 0; A, B 16-byte aligned. */
 int gnnome_wgrad_workspace_bytes(int64_t rows, int Ka, int Kb, size_t* bytes_host);
 int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C, int ldc,

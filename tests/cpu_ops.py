@@ -70,6 +70,34 @@ def edge_gate(e, B1h, B2h, views, W3, norm_kind, scale, shift, out=None, num_edg
     return out
 
 
+def linear_ref(A, W, bias, out=None):
+    """torch's own CPU nn.Linear IS the reference order (MKL: k-ascending fma chain from zero, then + bias)."""
+    y = torch.nn.functional.linear(A, W, bias)
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
+def reference_order_supported(hidden, norm_kind, B1h=None):
+    return hidden in (64, 128) and norm_kind == NORM_AFFINE
+
+
+def _fma(a, b, c):
+    return (a.double() * b.double() + c.double()).to(a.dtype)   # fp32: exact product, one rounding (double rounding ~2^-29)
+
+
+def edge_gate_ref(e, B1h, B2h, views, W3, b3, scale, shift, raw_edges=None, num_edges=None):
+    if e is None:
+        e_raw, (W1, b1, W2, b2) = raw_edges
+        e = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(e_raw[views.srt_eid.long()], W1, b1)), W2, b2)
+    E = e.shape[0] if num_edges is None else num_edges
+    s, d = views.srt_src[:E].long(), views.srt_dst[:E].long()
+    x = (B1h[s] + B2h[d]) + torch.nn.functional.linear(e[:E], W3, b3)
+    e[:E] = torch.relu(_fma(x, scale, shift)) + e[:E]
+    return e
+
+
 def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_nodes_out=None):
     n = h_in.shape[0]
     n_out = n if num_nodes_out is None else num_nodes_out
