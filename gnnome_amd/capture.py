@@ -28,9 +28,15 @@ class CapturedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = model(self.views, self.x, self.e)
+        from .engine import _state_key
+        self._key = _state_key(model, device)   # the recording holds the weights as PREPARED at capture time
 
     def __call__(self, x=None, e=None):
         """Replay; new features (same shapes, same graph) may be supplied.  Returns the static output tensor."""
+        from .engine import _state_key
+        if _state_key(self.model, self.device) != self._key:
+            raise RuntimeError("the model's parameters or buffers changed since this forward was captured (the recording "
+                               "replays the weights prepared at capture time): build a new CapturedForward")
         if x is not None:
             self.x.copy_(x)
         if e is not None:

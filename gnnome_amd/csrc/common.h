@@ -75,7 +75,10 @@ int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, flo
 
 constexpr int kWave = 64;       // gfx950 wavefront
 constexpr int kXcds = 8;        // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
-constexpr int kNumCUs = 256;
+constexpr int kNumCUs = 256;    // MI355X in SPX mode: also the upper bound the per-workgroup scratch buffers are sized for
+// Workgroups of a persistent launch (one per CU): the current device's CU count, rounded down to a multiple of kXcds and
+// capped at kNumCUs (a partitioned MI355X - CPX / DPX modes - exposes fewer CUs per device).
+int persistent_grid();
 constexpr float kAggEps = 1e-6f;   // gated_gcn_full.py:114,127
 constexpr float kNormEps = 1e-5f;  // torch BatchNorm1d / LayerNorm default eps
 

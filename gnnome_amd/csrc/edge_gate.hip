@@ -490,9 +490,9 @@ static int launch_gate_ws(const float* e_in, float* e_out, int64_t E, const floa
     using P = GateWS<CB, RB>;
     const int64_t tiles = (E + P::TM - 1) / P::TM;
     GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
-    const int tpb = (int)((tiles + kNumCUs - 1) / kNumCUs);  // one resident workgroup per CU (LDS-limited)
+    const int tpb = (int)((tiles + persistent_grid() - 1) / persistent_grid());  // one resident workgroup per CU (LDS-limited)
     const int interleave = tuning(kTuneGateTileOrder) == 1 ? 0 : 1;
-    const int grid = interleave ? kNumCUs : (int)((tiles + tpb - 1) / tpb);
+    const int grid = interleave ? persistent_grid() : (int)((tiles + tpb - 1) / tpb);
     const bool flags = tuning(kTuneGateVariant) != 6;   // 6 = hand-over through workgroup barriers (the earlier form)
     const int xp = tuning(kTuneGateExperiment);
     if (enc != nullptr) {
@@ -534,10 +534,10 @@ static int launch_ws_raw_stats(const float* e_in, float* x_out, int64_t E, const
     using P = GateWS<CB, RB>;
     const int64_t tiles = (E + P::TM - 1) / P::TM;
     GN_REQUIRE(tiles < (1ll << 31), "edge_gate_raw_stats: too many tiles");
-    const int tpb = (int)((tiles + kNumCUs - 1) / kNumCUs);
+    const int tpb = (int)((tiles + persistent_grid() - 1) / persistent_grid());
     GN_HIP(hipMemsetAsync(stats, 0, sizeof(float) * kNumCUs * RB * 2 * P::H, s));   // idle workgroups leave zeros
     const GateEnc none = {};
-    hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, false, true, 1>), dim3(kNumCUs), dim3(P::NT), 0, s, e_in, x_out, E, B1h, B2h, ldn, ss,
+    hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, false, true, 1>), dim3(persistent_grid()), dim3(P::NT), 0, s, e_in, x_out, E, B1h, B2h, ldn, ss,
                        sd, W3, ldw, center, nullptr, (int)tiles, tpb, 1, none, tuning(kTuneGateExperiment), stats);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
@@ -549,9 +549,9 @@ static int launch_ws_acc(const float* A, float* C, int64_t M, const float* W, in
     using P = GateWS<CB, RB>;
     const int64_t tiles = (M + P::TM - 1) / P::TM;
     GN_REQUIRE(tiles < (1ll << 31), "linear_acc: too many tiles");
-    const int tpb = (int)((tiles + kNumCUs - 1) / kNumCUs);
+    const int tpb = (int)((tiles + persistent_grid() - 1) / persistent_grid());
     const GateEnc none = {};
-    hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, false, true, 2>), dim3(kNumCUs), dim3(P::NT), 0, s, A, C, M, C, nullptr, P::H, nullptr,
+    hipLaunchKernelGGL((k_edge_gate_ws<CB, RB, 0, false, true, 2>), dim3(persistent_grid()), dim3(P::NT), 0, s, A, C, M, C, nullptr, P::H, nullptr,
                        nullptr, W, ldw, nullptr, nullptr, (int)tiles, tpb, 1, none, tuning(kTuneGateExperiment), nullptr);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;

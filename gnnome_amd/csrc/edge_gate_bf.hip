@@ -379,7 +379,7 @@ static int launch_bf(const GateBfArgs& args, hipStream_t s) {
     a.xp = tuning(kTuneGateExperiment);
     a.prof = g_gate_prof;
     if (MODE == 1) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * kNumCUs * P::RING * P::LWAVES * 2 * P::H, s));   // idle waves leave zeros
-    hipLaunchKernelGGL((k_edge_gate_bf<CB, RB, MODE, ENC>), dim3(kNumCUs), dim3(P::NT), 0, s, a);
+    hipLaunchKernelGGL((k_edge_gate_bf<CB, RB, MODE, ENC>), dim3(persistent_grid()), dim3(P::NT), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

@@ -143,7 +143,7 @@ int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* 
     const int n_chunks = 256 / P::NC;
     const int64_t tiles = (E + P::TM - 1) / P::TM;
     GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
-    int groups = kNumCUs / n_chunks;   // one resident workgroup per CU (LDS); the four chunks of a group share an XCD's L2
+    int groups = persistent_grid() / n_chunks;   // one resident workgroup per CU (LDS); the four chunks of a group share an XCD's L2
     if (groups >= kXcds) groups -= groups % kXcds;
     if (groups > tiles) groups = (int)tiles;
     if (groups < 1) groups = 1;

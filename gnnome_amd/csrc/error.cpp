@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/gnnome_hip.h"
 
 namespace gnnome {
@@ -15,6 +17,19 @@ void set_error(const char* fmt, ...) {
 }
 static int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 int tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key] : 0; }
+
+int persistent_grid() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cus = cus > 256 ? 256 : cus;
+        cached[dev] = cus >= 8 ? cus / 8 * 8 : 8;
+    }
+    return cached[dev];
+}
 }  // namespace gnnome
 
 extern "C" int gnnome_set_tuning(int key, int value) {

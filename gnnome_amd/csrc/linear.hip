@@ -436,7 +436,7 @@ static int launch_linear_bf2(const float* A, int64_t M, int lda, const float* W,
     const int n_chunks = Nout / P::NC;
     const int64_t tiles = (M + P::TM - 1) / P::TM;
     GN_REQUIRE(tiles < (1ll << 31), "linear: too many tiles");
-    int groups = WGS_PER_CU * kNumCUs / n_chunks;   // resident workgroups per CU (LDS: 52 KB of W planes at K = 128, 101 KB at 256); all
+    int groups = WGS_PER_CU * persistent_grid() / n_chunks;   // resident workgroups per CU (LDS: 52 KB of W planes at K = 128, 101 KB at 256); all
                                                    // chunks of a group share an XCD (see launch_linear_ws)
     if (groups >= kXcds) groups -= groups % kXcds;
     if (groups < 1) groups = 1;
@@ -455,7 +455,7 @@ static int launch_linear_bf(const float* A, int64_t M, int lda, const float* W, 
     const int n_chunks = Nout / P::NC;
     const int64_t tiles = (M + P::TM - 1) / P::TM;
     GN_REQUIRE(tiles < (1ll << 31), "linear: too many tiles");
-    int groups = kNumCUs / n_chunks;   // see launch_linear_ws
+    int groups = persistent_grid() / n_chunks;   // see launch_linear_ws
     if (groups >= kXcds) groups -= groups % kXcds;
     if (groups < 1) groups = 1;
     const int tpg = (int)((tiles + groups - 1) / groups);
@@ -474,7 +474,7 @@ static int launch_linear_ws(const float* A, int64_t M, int lda, const float* W, 
     GN_REQUIRE(tiles < (1ll << 31), "linear: too many tiles");
     // linear block id = chunk * groups + group and block b runs on XCD b % 8: with groups a multiple of 8 all
     // chunks of one group (which read the same A tiles) share one XCD's L2
-    int groups = kNumCUs / n_chunks;
+    int groups = persistent_grid() / n_chunks;
     if (groups >= kXcds) groups -= groups % kXcds;
     if (groups < 1) groups = 1;
     const int tpg = (int)((tiles + groups - 1) / groups);

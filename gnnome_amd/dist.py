@@ -13,8 +13,9 @@ inference.py:388).  This is the north_star's scheme:
   * once per layer the owners send the h rows their peers hold as halo: a packed all_to_all_single
     over RCCL/xGMI (direct peer-to-peer, per-link bound), received straight into the halo rows of h.
     The node projection of the owned rows runs while the exchange is in flight;
-  * the scorer writes the logits of owned in-edges (every global edge exactly once) at their GLOBAL
-    edge id into an [E] buffer; one all_reduce(SUM) over disjoint supports assembles the result.
+  * the scorer writes the logits of owned in-edges (every global edge exactly once) as one contiguous piece in
+    sorted order; ONE all_gather of the pieces (E*4/G bytes each, padded to the largest) and one index_select
+    through a map built with the plan put them into global edge-id order (SURVEY.md 8e "Scorer").
 
 All tensor math goes through an `ops` namespace exactly like engine.run_stack: the product passes
 gnnome_amd.ops (HIP); the CPU/gloo tests pass the checker backend to exercise this host logic.
@@ -55,6 +56,8 @@ class PartitionedGraph:
         self.send_idx = None        # int32 [sum(send_counts)] owned local rows to pack, grouped by peer
         self.send_counts = None     # python list, rows to send to each peer
         self.recv_counts = None     # python list, halo rows received from each peer (in halo order)
+        self.score_pad = 0          # rows of the padded logits piece every rank contributes to the all_gather
+        self.score_index = None     # int64 [E_global]: where global edge id k sits in the flattened [world, score_pad] gather
 
     @classmethod
     def from_global(cls, src, dst, num_nodes, rank, world, device, ops=hip_ops, group=None):
@@ -107,7 +110,35 @@ class PartitionedGraph:
             all_to_all_rows(wanted, halo.to(device).contiguous(), self.send_counts, self.recv_counts, group)
         assert wanted.numel() == 0 or (int(wanted.min()) >= lo and int(wanted.max()) < hi)
         self.send_idx = (wanted - lo).int().to(device)
+        self._plan_logits(device, group)
         return self
+
+    def _plan_logits(self, device, group):
+        """Assembly of the logits: every rank scores its owned in-edges (a prefix of its sorted positions) into one piece;
+        the pieces are all-gathered (padded to the largest) and un-permuted with one index_select.  The map from global
+        edge id to its slot in the gathered buffer is exchanged here, once."""
+        world = self.world
+        if world == 1:
+            self.score_pad, self.score_index = self.n_score, None
+            return
+        counts = all_gather_rows(torch.tensor([self.n_score], dtype=torch.int64, device=device), world, group).view(-1).tolist()
+        self.score_pad = pad = max(max(counts), 1)
+        mine = torch.full((pad,), -1, dtype=torch.int64, device=device)
+        mine[:self.n_score] = self.srt_geid.long()
+        every = all_gather_rows(mine, world, group).view(-1)                 # [world * pad] global edge ids, -1 = padding
+        slots = torch.nonzero(every >= 0).squeeze(1)
+        index = torch.full((self.num_edges_global,), -1, dtype=torch.int64, device=device)
+        index[every[slots]] = slots
+        assert sum(counts) == self.num_edges_global and int(index.min()) >= 0, "every edge must be scored exactly once"
+        self.score_index = index
+
+    def assemble_logits(self, piece, group=None):
+        """piece[score_pad] (this rank's owned in-edges in sorted order, tail unused) -> logits[E_global] in edge-id order,
+        complete on every rank."""
+        if self.world == 1:
+            raise RuntimeError("single rank: the scorer writes edge-id order itself")
+        gathered = all_gather_rows(piece, self.world, group).view(-1)
+        return gathered.index_select(0, self.score_index)
 
     def local_node_rows(self, x_global):
         return x_global[self.node_gid.to(x_global.device)]
@@ -238,8 +269,9 @@ class PartitionShard:
             at += t.numel()
         return out
 
-    def finish_logits(self, logits):
-        return all_reduce_sum(logits, self.group) if self.world > 1 else logits
+    def finish_logits(self, piece):
+        """world > 1: this rank's piece (owned in-edges, sorted order) -> the complete logits in edge-id order."""
+        return self.part.assemble_logits(piece, self.group) if self.world > 1 else piece
 
 
 def _project(ops, lw, h, n_own, xchg):
@@ -275,15 +307,19 @@ def run_partitioned(ops, prep, part, x_local, e_local, group=None, reduce_result
     hs = pw["hs"]
     xchg.finish()
     PQ = ops.linear(h, pw["W_nodes"], pw["b_nodes"])
-    logits = torch.zeros(part.num_edges_global, dtype=torch.float32, device=h.device)
-    if part.n_score > 0:
+    score_views = _ScoreViews(views, part.srt_geid)
+    if part.world == 1 or not reduce_result:
         # scatter straight to GLOBAL edge ids: a GraphViews-like shim whose srt_eid is the global map
-        score_views = _ScoreViews(views, part.srt_geid)
-        ops.edge_score(e, PQ[:, :hs], PQ[:, hs:], score_views, pw["W1_e"], pw["W2"], pw["b2"], pw["W3"], pw["b3"], logits,
-                       num_edges=part.n_score)
-    if reduce_result and part.world > 1:
-        all_reduce_sum(logits, group)  # disjoint supports: a concatenation
-    return logits
+        logits = (torch.zeros if part.world > 1 else torch.empty)(part.num_edges_global, dtype=torch.float32, device=h.device)
+        if part.n_score > 0:
+            ops.edge_score(e, PQ[:, :hs], PQ[:, hs:], score_views, pw["W1_e"], pw["W2"], pw["b2"], pw["W3"], pw["b3"], logits,
+                           num_edges=part.n_score)
+        return logits
+    piece = torch.empty(part.score_pad, dtype=torch.float32, device=h.device)
+    if part.n_score > 0:
+        ops.edge_score(e, PQ[:, :hs], PQ[:, hs:], score_views, pw["W1_e"], pw["W2"], pw["b2"], pw["W3"], pw["b3"], piece,
+                       num_edges=part.n_score, scatter_to_edge_id=False)
+    return part.assemble_logits(piece, group)
 
 
 class _ScoreViews:

@@ -154,6 +154,11 @@ def _refuse_training(module):
     if module.training and (torch.is_grad_enabled() or any(isinstance(m, torch.nn.BatchNorm1d) for m in module.modules())):
         raise NotImplementedError("train mode is supported through SymGatedGCNModel.forward only; call .eval() for the "
                                   "layer-level API")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        # the layer-level entries return tensors WITHOUT autograd history: say so instead of handing back None gradients
+        import warnings
+        warnings.warn("gnnome_amd layer-level forward is inference-only: its outputs carry no autograd history "
+                      "(wrap the call in torch.no_grad(), or train through SymGatedGCNModel.forward)", stacklevel=3)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -258,6 +263,7 @@ def model_forward(model, graph, x, e):
         xd = x.detach().to(device=device, dtype=torch.float32).contiguous()
         ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
         logits = run_stack(hip_ops, prep, views, xd, ed)
+    views.check_range()   # a fresh graph's deferred endpoint check, after the whole forward has been enqueued
     return logits.unsqueeze(1).to(out_device)
 
 
@@ -280,6 +286,7 @@ def layer_forward_edge_id_order(conv, g, h, e):
 
 
 def score_forward_edge_id_order(pred, graph, x, e):
+    _refuse_training(pred)
     out_device = x.device
     device = compute_device(x, e)
     pw = prepared_for(pred, device, prepare_predictor)

@@ -38,13 +38,16 @@ def views_for(graph, device):
             key = graph
         except TypeError:  # not weak-referenceable
             hit = None
-        if hit is not None and hit.device == device and hit.num_edges == int(graph.num_edges()) \
-                and hit.num_nodes == int(graph.num_nodes()):
-            return hit
+        if hit is not None and hit.device == device and hit.num_nodes == int(graph.num_nodes()):
+            # (a graph mutated in place is a new graph to DGL as well - node_subgraph / reverse return fresh objects;
+            # the edge count is re-checked where the object can tell it without building the edge list)
+            count = getattr(graph, "num_edges", None)
+            if count is None or hit.num_edges == int(count()):
+                return hit
     src, dst, n = edge_list(graph)
     src = src.to(device=device, dtype=torch.int32).contiguous()
     dst = dst.to(device=device, dtype=torch.int32).contiguous()
-    views = GraphViews(src, dst, n)
+    views = GraphViews(src, dst, n, validate="lazy")   # range check deferred: engine.model_forward / train_forward
     if key is not None:
         try:
             _cache[key] = views

@@ -25,6 +25,9 @@ class SymGatedGCN(nn.Module):
                              "(layers/processor.py:12-14); unequal widths are not supported")
         if not residual:
             raise ValueError("residual=False is never used by the reference drivers and is not supported")
+        if in_channels not in (64, 128, 256):
+            raise ValueError(f"hidden_features={in_channels}: the HIP kernels are built for 64 (the reference's default, "
+                             "configs/hyperparameters.py:22), 128 and 256")
         self.dropout = dropout if dropout else 0.0
         self.normalization = normalization
         self.residual = residual
@@ -67,6 +70,9 @@ class SymGatedGCN_processor(nn.Module):
 class ScorePredictor(nn.Module):
     def __init__(self, in_features, hidden_edge_scores):
         super().__init__()
+        if in_features not in (64, 128, 256) or hidden_edge_scores not in (32, 64, 128):
+            raise ValueError(f"ScorePredictor({in_features}, {hidden_edge_scores}): the HIP kernels are built for "
+                             "in_features in {64,128,256} and hidden_edge_scores in {32,64,128} (reference default 64, 64)")
         self.W1 = nn.Linear(3 * in_features, hidden_edge_scores)
         self.W2 = nn.Linear(hidden_edge_scores, 32)
         self.W3 = nn.Linear(32, 1)

@@ -29,6 +29,9 @@ class SymGatedGCNModel(nn.Module):
     def __init__(self, node_features, edge_features, hidden_features, hidden_ne_features, num_layers,
                  hidden_edge_scores, normalization, dropout=None):
         super().__init__()
+        if not (1 <= node_features <= 8 and 1 <= edge_features <= 8 and 1 <= hidden_ne_features <= 64):
+            raise ValueError("the encoder kernels take node/edge features <= 8 and hidden_ne_features <= 64 "
+                             "(reference: 2, 2, 16 - configs/hyperparameters.py:20-25)")
         self.linear1_node = nn.Linear(node_features, hidden_ne_features, bias=True)
         self.linear2_node = nn.Linear(hidden_ne_features, hidden_features, bias=True)
         self.linear1_edge = nn.Linear(edge_features, hidden_ne_features, bias=True)

@@ -61,20 +61,27 @@ class GraphViews:
     """In-edge / out-edge orderings of one edge list (see include/gnnome_hip.h, "graph views")."""
 
     __slots__ = ("num_nodes", "num_edges", "in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst", "device",
-                 "transposed", "__weakref__")
+                 "transposed", "_range", "__weakref__")
 
-    def __init__(self, src, dst, num_nodes):
+    def __init__(self, src, dst, num_nodes, validate="now"):
+        """validate = "now": endpoints are range-checked before anything is built (one host sync).  "lazy": no host sync -
+        the extremes are reduced on the device, the endpoints are clamped into range so that no kernel can fault, and
+        check_range() raises later (the model call does it once everything is enqueued); for callers that hand over a
+        fresh graph every step (train.py:96, :336).  False: trusted input."""
         lib = _lib.load()
         _i32(src, "src"), _i32(dst, "dst")
         dev = src.device
         n, e = int(num_nodes), int(src.numel())
         if dst.numel() != e:
             raise ValueError("src and dst differ in length")
-        if e > 0:
-            lo = int(torch.minimum(src.min(), dst.min()))
-            hi = int(torch.maximum(src.max(), dst.max()))
-            if lo < 0 or hi >= n:
-                raise IndexError(f"edge endpoint out of range [0,{n}): min {lo}, max {hi}")
+        self._range = None
+        if e > 0 and validate:
+            ext = torch.stack([torch.minimum(src.min(), dst.min()), torch.maximum(src.max(), dst.max())])
+            self._range = (ext, n)
+            if validate == "lazy":
+                src, dst = src.clamp(0, max(n - 1, 0)), dst.clamp(0, max(n - 1, 0))
+            else:
+                self.check_range()
         self.num_nodes, self.num_edges, self.device, self.transposed = n, e, dev, False
         mk = lambda k: torch.empty(k, dtype=torch.int32, device=dev)  # noqa: E731
         self.in_ptr, self.out_ptr = mk(n + 1), mk(n + 1)
@@ -89,6 +96,14 @@ class GraphViews:
                                                     _stream(dev)),
                        "build_graph_views")
             ws.record_stream(torch.cuda.current_stream(dev))
+
+    def check_range(self):
+        """Raise IndexError if an endpoint lay outside [0, N) (the deferred half of validate="lazy"; one host sync, once)."""
+        if self._range is not None:
+            (ext, n), self._range = self._range, None
+            lo, hi = (int(v) for v in ext.tolist())
+            if lo < 0 or hi >= n:
+                raise IndexError(f"edge endpoint out of range [0,{n}): min {lo}, max {hi}")
 
     def reversed(self):
         """Views of dgl.reverse(g, copy_ndata=True, copy_edata=True) - endpoints swapped, edge ids and edge
@@ -531,11 +546,14 @@ def _closure_workspace(device):
 
 
 def degree_features(views, reverse=False):
-    """x[N,2] = z-scored in/out degree read off the views' CSR pointers (inference.py:416-420; train.py:112-122)."""
+    """x[N,2] = [zscore(in_degree) | zscore(out_degree)] read off the views' CSR pointers; `reverse` = the reference's
+    argument (train.py:112-122): columns swapped.  The degrees are those of the edge list the views were BUILT from - like
+    the reference's stored ndata['in_deg'] / ['out_deg'], which dgl.reverse(g, True, True) copies and does not recompute
+    (train.py:165-166) - so `views.reversed()` gives the same features as `views`, and the reference's second pass is
+    `degree_features(views.reversed(), reverse=True)`, literally."""
     x = torch.empty((views.num_nodes, 2), dtype=torch.float32, device=views.device)
     ws = _closure_workspace(views.device)
-    swap = bool(reverse) != bool(views.transposed)  # a transposed view already has in <-> out exchanged
-    _call("gnnome_degree_features_f32", views.device, _ptr(views.in_ptr), _ptr(views.out_ptr), views.num_nodes, int(swap), _ptr(x),
+    _call("gnnome_degree_features_f32", views.device, _ptr(views.in_ptr), _ptr(views.out_ptr), views.num_nodes, int(bool(reverse)), _ptr(x),
           _ptr(ws), ws.numel())
     return x
 

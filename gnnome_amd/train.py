@@ -171,12 +171,16 @@ class _TrainStep(torch.autograd.Function):
         sh.halo_finish()
         PQ = ops.linear(h, W_nodes, b_nodes)
         ps, qd = (PQ[:, hs:], PQ[:, :hs]) if views.transposed else (PQ[:, :hs], PQ[:, hs:])
-        # every edge of the graph is scored once, by the rank that owns its destination, at its GLOBAL edge id
-        logits = (torch.zeros if sh.world > 1 else torch.empty)(sh.e_global, dtype=torch.float32, device=h.device)
+        # every edge of the graph is scored once, by the rank that owns its destination
         z1 = new(e_own, hs)
-        ops.edge_score(e, ps, qd, sh.score_views, W1[:, 2 * H:], d(pred.W2.weight), d(pred.W2.bias), d(pred.W3.weight.reshape(-1)),
-                       d(pred.W3.bias.reshape(-1)), logits, num_edges=e_own, z1_out=z1)
-        logits = sh.finish_logits(logits)
+        w_tail = (W1[:, 2 * H:], d(pred.W2.weight), d(pred.W2.bias), d(pred.W3.weight.reshape(-1)), d(pred.W3.bias.reshape(-1)))
+        if sh.world > 1:    # one contiguous piece per rank in sorted order; finish_logits all-gathers and un-permutes them
+            piece = torch.empty(sh.part.score_pad, dtype=torch.float32, device=h.device)
+            ops.edge_score(e, ps, qd, sh.score_views, *w_tail, piece, num_edges=e_own, scatter_to_edge_id=False, z1_out=z1)
+            logits = sh.finish_logits(piece)
+        else:
+            logits = torch.empty(sh.e_global, dtype=torch.float32, device=h.device)
+            ops.edge_score(e, ps, qd, sh.score_views, *w_tail, logits, num_edges=e_own, z1_out=z1)
         ctx.model, ctx.sh, ctx.names, ctx.saved = model, sh, names, saved
         ctx.tail = dict(h=h, e=e, z1=z1, W1=W1, W_nodes=W_nodes, x=x, e_raw=e_raw)
         return logits.unsqueeze(1)
@@ -184,6 +188,9 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         model, sh, saved, tail = ctx.model, ctx.sh, ctx.saved, ctx.tail
+        if saved is None:
+            raise RuntimeError("the activations of this training step were released by its first backward(); "
+                               "retain_graph=True is not supported - run the forward again")
         ops, views = sh.ops, sh.views
         H = model.linear2_node.out_features
         n_own, n_local, e_own, e_local = sh.n_own, sh.n_local, sh.e_own, sh.e_local
@@ -290,7 +297,9 @@ def train_forward(model, graph, x, e):
     views = views_for(graph, device)
     xd = x.detach().to(device=device, dtype=torch.float32).contiguous()
     ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
-    return train_forward_on(model, WholeGraph(views), xd, ed)
+    out = train_forward_on(model, WholeGraph(views), xd, ed)
+    views.check_range()   # a fresh graph's deferred endpoint check (GraphViews validate="lazy")
+    return out
 
 
 def train_forward_on(model, shard, x_local, e_local):

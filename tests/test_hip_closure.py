@@ -57,8 +57,15 @@ def test_feature_preparation_matches_reference_golden_g7():
     x = features.degree_features_hip(views)
     assert (x.cpu() - g["x"]).abs().max().item() <= 2e-6
     assert (features.degree_features_hip(views, reverse=True).cpu() - g["x_reversed"]).abs().max().item() <= 2e-6
-    # the reversed view describes dgl.reverse(g): its in-degrees are the original out-degrees (train.py:116-117)
-    assert torch.equal(features.degree_features_hip(views.reversed()), features.degree_features_hip(views, reverse=True))
+    # train.py:165-166, literally: g = dgl.reverse(g, True, True); get_full_ne_features(g, reverse=True).  The degrees are
+    # stored features that dgl.reverse copies, so only the flag swaps the columns
+    assert torch.equal(features.degree_features_hip(views.reversed(), reverse=True), features.degree_features_hip(views, reverse=True))
+    assert torch.equal(features.degree_features_hip(views.reversed()), x)
+
+    class _Stored:   # a GNNome DGLGraph carries the degrees as ndata (graph_parser.py); reversed graphs keep the copies
+        ndata = {"in_deg": torch.bincount(g["dst"].long(), minlength=g["num_nodes"]), "out_deg": torch.bincount(g["src"].long(), minlength=g["num_nodes"])}
+    assert (features.degree_features(_Stored(), device=dev()).cpu() - g["x"]).abs().max().item() <= 2e-6
+    assert (features.degree_features(_Stored(), reverse=True, device=dev()).cpu() - g["x_reversed"]).abs().max().item() <= 2e-6
     e = features.edge_features_hip(g["overlap_length"].to(dev()), g["overlap_similarity"].to(dev()))
     assert (e.cpu() - g["e"]).abs().max().item() <= 2e-6 and torch.equal(e[:, 1].cpu(), g["overlap_similarity"])
 

@@ -57,6 +57,16 @@ def test_graph_views_bit_exact(n, e):
 def test_graph_views_rejects_out_of_range():
     with pytest.raises(IndexError):
         ops.GraphViews(torch.tensor([0, 9], dtype=torch.int32, device=dev()), torch.tensor([1, 2], dtype=torch.int32, device=dev()), 4)
+    # a graph handed to the model is checked lazily (no host sync before the kernels are enqueued; endpoints clamped so that
+    # nothing can fault) and the call still raises
+    lazy = ops.GraphViews(torch.tensor([0, 9], dtype=torch.int32, device=dev()), torch.tensor([1, -2], dtype=torch.int32, device=dev()), 4,
+                          validate="lazy")
+    assert int(lazy.srt_src.max()) <= 3 and int(lazy.srt_dst.min()) >= 0
+    with pytest.raises(IndexError):
+        lazy.check_range()
+    m = gnnome_amd.SymGatedGCNModel(2, 2, 64, 16, 2, 64, "batch").eval().to(dev())
+    with pytest.raises(IndexError):
+        m((torch.tensor([0, 9]), torch.tensor([1, 2]), 4), torch.randn(4, 2, device=dev()), torch.randn(2, 2, device=dev()))
 
 
 # ------------------------------------------------------------------------------------ kernels
