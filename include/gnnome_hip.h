@@ -321,6 +321,31 @@ int gnnome_edge_loss_f32(const float* logits, const float* logits_rev, const flo
                          const float* pos_weight, float alpha, float grad_scale, float* loss, float* dlogits,
                          float* dlogits_rev, int64_t* tfpn, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- greedy decode of the edge scores into contig walks -----------------------------
+ * What inference.py:70-165 (greedy_forwards, greedy_backwards_rc, run_greedy_both_ways) and :29-36 (get_contig_length)
+ * do with Python dicts and sets, for all sampled start edges of one iteration of get_contigs_greedy (:193-300) in one
+ * launch, one wavefront per candidate.
+ *   succ_ptr/succ_nbr/succ_eid  successor lists in EDGE-ID order (graph_parser.py:31-37) and the edge id of every slot
+ *   logp        float[E]  log(sigmoid(score)) by edge id (inference.py:184); prefix_len int32[E]; read_len int32[N]
+ *   visited     uint8[N]  nodes consumed by earlier contigs; cand_* the sampled edges (endpoints and edge id)
+ *   walks_f[c,:len_f[c]]  forward walk from dst; walks_b[c,:len_b[c]] the walk from src^1 on the reverse-complement
+ *   strand in walk order (the contig is reversed(walks_b ^ 1) followed by walks_f, inference.py:157, :254)
+ *   sum_f/sum_b  fp32 sums of the chosen log-probabilities in walk order; contig_len[c] int64 as get_contig_length
+ *   status[c]    0, or bit 0: a walk reached `capacity` and was cut, bit 1: an edge of the backward half has no mate
+ *   exact ties for the best successor are resolved as torch.topk(k=1) resolves them on the CPU (decode.hip)
+ * Node 2r+1 is the reverse complement of node 2r (x ^ 1, as in the reference); N even.
+ */
+int gnnome_greedy_walks_workspace_bytes(int64_t num_nodes, int num_candidates, size_t* bytes_host);
+int gnnome_greedy_walks(const int32_t* succ_ptr, const int32_t* succ_nbr, const int32_t* succ_eid, const float* logp,
+                        const int32_t* prefix_len, const int32_t* read_len, const uint8_t* visited, int64_t num_nodes,
+                        const int32_t* cand_src, const int32_t* cand_dst, const int32_t* cand_eid, int num_candidates,
+                        int32_t* walks_f, int32_t* walks_b, int64_t capacity, int32_t* len_f, int32_t* len_b, float* sum_f,
+                        float* sum_b, int64_t* contig_len, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+/* visited[n] = visited[n^1] = 1 for every node of `walk` and for every node it jumped over: for consecutive (ss, dd),
+ * succs[ss] & preds[dd] and their mates (inference.py:313-318, :334). */
+int gnnome_mark_walk_visited(const int32_t* succ_ptr, const int32_t* succ_nbr, const int32_t* walk, int64_t walk_len,
+                             uint8_t* visited, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
