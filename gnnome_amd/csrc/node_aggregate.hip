@@ -16,11 +16,58 @@
 // walks G = 64/(H/4) edges at once (4 at H=64, 2 at H=128, 1 at H=256), lane group g taking every
 // G-th item of the node's list, and the groups are combined with __shfl_xor at the end.  The
 // summation order is a function of the graph alone, never of scheduling: results are bit-reproducible.
+//
+// Skew ("Skew"): one wave per node is the right shape for assembly graphs (degree ~10), but a repeat-induced hub
+// with 10^5 incident edges would keep ONE wave busy for milliseconds while the chip idles.  Nodes whose in + out list
+// exceeds kHubThreshold items are therefore found on the device at every call (k_find_hubs: N threads, microseconds),
+// their lists are cut into kHubChunks fixed chunks that a first launch reduces to per-chunk partial sums, one wave per
+// chunk (k_hub_partials), and the node's own wave then adds the partials IN CHUNK ORDER instead of walking the list: the
+// result is still a function of the graph alone (bit-reproducible), only a different - fixed - association than the
+// single-wave sum.  Up to kHubCap hubs per call take this path; any further ones fall back to the single wave.
 #include "common.h"
 
 namespace gnnome {
 
 constexpr int kAggThreads = 256;
+constexpr int kHubThreshold = 4096;   // items (in-edges + out-edges) above which a node's list is split
+constexpr int kHubChunks = 128;       // chunks per hub = waves working on it
+constexpr int kHubCap = 64;           // hubs per call that get the split path
+constexpr int kHubMaxH = 256;
+
+struct HubScratch {
+    const void *key_in = nullptr, *key_out = nullptr;   // the CSR arrays the hub list was last built from
+    int64_t key_n = -1;
+    int* count = nullptr;       // [1]
+    int* nodes = nullptr;       // [kHubCap]
+    float* partials = nullptr;  // [kHubCap][kHubChunks][4][H]
+};
+
+// Per-device scratch of the hub path, allocated on first use (never inside a stream capture: the first call of any
+// process is an eager one - CapturedForward and the benchmarks warm up before they record).  One buffer per device:
+// launches of this library on one device are stream-ordered.
+static HubScratch* hub_scratch() {
+    static HubScratch table[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    HubScratch& h = table[dev];
+    if (h.count == nullptr) {
+        if (hipMalloc(&h.count, sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMalloc(&h.nodes, sizeof(int) * kHubCap) != hipSuccess) return nullptr;
+        if (hipMalloc(&h.partials, sizeof(float) * (size_t)kHubCap * kHubChunks * 4 * kHubMaxH) != hipSuccess) return nullptr;
+    }
+    return &h;
+}
+
+__global__ __launch_bounds__(256) void k_find_hubs(const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ out_ptr, int64_t n,
+                                                   int* __restrict__ count, int* __restrict__ nodes) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cnt = (in_ptr[i + 1] - in_ptr[i]) + (out_ptr[i + 1] - out_ptr[i]);
+    if (cnt > kHubThreshold) {
+        const int slot = atomicAdd(count, 1);
+        if (slot < kHubCap) nodes[slot] = (int)i;
+    }
+}
 
 template <int H>
 __device__ __forceinline__ float group_sum(float v) {
@@ -40,45 +87,26 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
-// One wave per node.  The node's in-edges and out-edges form ONE work list of (sorted position,
-// neighbour row, direction) items; each lane first fetches the indices of one item (so the dependent
-// index loads happen once per 64 items, not once per edge), then the wave walks the list with U items
-// per lane group in flight: 2*U*G independent H*4-byte row loads per wave.
-// MODE 0: the fused inference update.  MODE 1 (train forward): h_out = A1h + fwd + bwd (pre-normalisation) and the
-// four node tables the backward needs (aux0..3 = fwd, 1/(den_f+eps), bwd, 1/(den_b+eps)).  MODE 2 (aggregation
-// backward): aux0 = sum_in s*A2h[src], aux2 = sum_out s*A3h[dst], the raw gated sums with caller-chosen tables.
-template <int H, int NORM, int MODE>
-__global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
-    const float* __restrict__ e, int64_t n_out, const float* __restrict__ A1h, const float* __restrict__ A2h,
-    const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src,
-    const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_dst,
-    const float* __restrict__ h_in, int ldh, float* __restrict__ h_out, const float* __restrict__ scale,
-    const float* __restrict__ shift, int total_blocks, float* __restrict__ aux0, float* __restrict__ aux1,
-    float* __restrict__ aux2, float* __restrict__ aux3) {
+// The gated sums over items [lo, hi) of one node's work list (in-edges first, then out-edges), lane group g taking every
+// G-th item of every 64-item batch; per-lane-group partial sums (combine with group_sum).
+template <int H>
+__device__ __forceinline__ void accumulate_items(const float* __restrict__ e, const float* __restrict__ A2h, const float* __restrict__ A3h,
+                                                 int ldn, const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_pos,
+                                                 const int32_t* __restrict__ out_dst, int ib, int din, int ob, int lo, int hi, int lane,
+                                                 int group, int c, f32x4& nf, f32x4& df, f32x4& nb, f32x4& db) {
     constexpr int LPR = H / 4, G = 64 / LPR, U = (H == 256) ? 8 : 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t node = (int64_t)xcd_remap(blockIdx.x, total_blocks) * (kAggThreads / 64) + wave;
-    if (node >= n_out) return;
-    const int group = lane / LPR, c = (lane % LPR) * 4;
-
-    const int ib = in_ptr[node], din = in_ptr[node + 1] - ib;
-    const int ob = out_ptr[node], cnt = din + out_ptr[node + 1] - ob;
-    f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
-    if (MODE != 2) a1 = *reinterpret_cast<const f32x4*>(A1h + node * ldn + c);
-
-    f32x4 nf = {0.f, 0.f, 0.f, 0.f}, df = nf, nb = nf, db = nf;
-    for (int base = 0; base < cnt; base += 64) {
+    for (int base = lo; base < hi; base += 64) {
         // lane l owns item base + l
         const int j = base + lane;
         int my_p = 0, my_n = 0;
         if (j < din) {
             my_p = ib + j;
             my_n = srt_src[my_p];
-        } else if (j < cnt) {
+        } else if (j < hi) {
             my_p = out_pos[ob + j - din];
             my_n = out_dst[ob + j - din];
         }
-        const int m = min(64, cnt - base);
+        const int m = min(64, hi - base);
         for (int j0 = 0; j0 < m; j0 += G * U) {
             f32x4 x[U], a[U];
             bool live[U], fwd[U];
@@ -109,6 +137,99 @@ __global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
                 }
             }
         }
+    }
+}
+
+// First launch of the hub path: wave (blockIdx.x * 4 + wave) reduces chunk c of EVERY split hub to (sum s*A2h, sum s,
+// sum s*A3h, sum s) partials; chunk boundaries are a function of the node's item count only.
+template <int H>
+__global__ __launch_bounds__(kAggThreads) void k_hub_partials(const float* __restrict__ e, const float* __restrict__ A2h,
+                                                              const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr,
+                                                              const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_ptr,
+                                                              const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_dst,
+                                                              int64_t n_out, const int* __restrict__ hub_count,
+                                                              const int* __restrict__ hub_nodes, float* __restrict__ partials) {
+    constexpr int LPR = H / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ch = blockIdx.x * (kAggThreads / 64) + wave;
+    const int group = lane / LPR, c = (lane % LPR) * 4;
+    const int nh = min(*hub_count, kHubCap);
+    for (int h = 0; h < nh; ++h) {
+        const int64_t node = hub_nodes[h];
+        if (node >= n_out) continue;
+        const int ib = in_ptr[node], din = in_ptr[node + 1] - ib;
+        const int ob = out_ptr[node], cnt = din + out_ptr[node + 1] - ob;
+        const int per = ((cnt + kHubChunks - 1) / kHubChunks + 63) / 64 * 64;   // whole 64-item batches per chunk
+        const int lo = min(cnt, ch * per), hi = min(cnt, lo + per);
+        f32x4 nf = {0.f, 0.f, 0.f, 0.f}, df = nf, nb = nf, db = nf;
+        accumulate_items<H>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, lo, hi, lane, group, c, nf, df, nb, db);
+        f32x4 o0, o1, o2, o3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o0[k] = group_sum<H>(nf[k]);
+            o1[k] = group_sum<H>(df[k]);
+            o2[k] = group_sum<H>(nb[k]);
+            o3[k] = group_sum<H>(db[k]);
+        }
+        if (group == 0) {
+            float* pp = partials + ((int64_t)h * kHubChunks + ch) * 4 * H + c;
+            *reinterpret_cast<f32x4*>(pp) = o0;
+            *reinterpret_cast<f32x4*>(pp + H) = o1;
+            *reinterpret_cast<f32x4*>(pp + 2 * H) = o2;
+            *reinterpret_cast<f32x4*>(pp + 3 * H) = o3;
+        }
+    }
+}
+
+// One wave per node.  The node's in-edges and out-edges form ONE work list of (sorted position,
+// neighbour row, direction) items; each lane first fetches the indices of one item (so the dependent
+// index loads happen once per 64 items, not once per edge), then the wave walks the list with U items
+// per lane group in flight: 2*U*G independent H*4-byte row loads per wave.
+// MODE 0: the fused inference update.  MODE 1 (train forward): h_out = A1h + fwd + bwd (pre-normalisation) and the
+// four node tables the backward needs (aux0..3 = fwd, 1/(den_f+eps), bwd, 1/(den_b+eps)).  MODE 2 (aggregation
+// backward): aux0 = sum_in s*A2h[src], aux2 = sum_out s*A3h[dst], the raw gated sums with caller-chosen tables.
+template <int H, int NORM, int MODE>
+__global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
+    const float* __restrict__ e, int64_t n_out, const float* __restrict__ A1h, const float* __restrict__ A2h,
+    const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src,
+    const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_dst,
+    const float* __restrict__ h_in, int ldh, float* __restrict__ h_out, const float* __restrict__ scale,
+    const float* __restrict__ shift, int total_blocks, float* __restrict__ aux0, float* __restrict__ aux1,
+    float* __restrict__ aux2, float* __restrict__ aux3, const int* __restrict__ hub_count, const int* __restrict__ hub_nodes,
+    const float* __restrict__ hub_partials) {
+    constexpr int LPR = H / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t node = (int64_t)xcd_remap(blockIdx.x, total_blocks) * (kAggThreads / 64) + wave;
+    if (node >= n_out) return;
+    const int group = lane / LPR, c = (lane % LPR) * 4;
+
+    const int ib = in_ptr[node], din = in_ptr[node + 1] - ib;
+    const int ob = out_ptr[node], cnt = din + out_ptr[node + 1] - ob;
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+    if (MODE != 2) a1 = *reinterpret_cast<const f32x4*>(A1h + node * ldn + c);
+
+    f32x4 nf = {0.f, 0.f, 0.f, 0.f}, df = nf, nb = nf, db = nf;
+    int hub_slot = -1;
+    if (cnt > kHubThreshold && hub_nodes != nullptr) {   // wave-uniform: was this node given the split path?
+        const int nh = min(*hub_count, kHubCap);
+        for (int base = 0; base < nh; base += 64) {
+            const unsigned long long m = __ballot(base + lane < nh && hub_nodes[base + lane] == (int)node);
+            if (m) hub_slot = base + __ffsll((long long)m) - 1;
+        }
+    }
+    if (hub_slot >= 0) {
+        // add the chunk partials in chunk order (lane group 0 carries the sums; the others stay zero for group_sum)
+        if (group == 0) {
+            const float* pp = hub_partials + ((int64_t)hub_slot * kHubChunks) * 4 * H + c;
+            for (int ch = 0; ch < kHubChunks; ++ch, pp += 4 * H) {
+                nf += *reinterpret_cast<const f32x4*>(pp);
+                df += *reinterpret_cast<const f32x4*>(pp + H);
+                nb += *reinterpret_cast<const f32x4*>(pp + 2 * H);
+                db += *reinterpret_cast<const f32x4*>(pp + 3 * H);
+            }
+        }
+    } else {
+        accumulate_items<H>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
     }
 
     f32x4 v, t0, t1, t2, t3;
@@ -167,24 +288,41 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
                       float* aux2 = nullptr, float* aux3 = nullptr) {
     const int64_t blocks = (n_out + (kAggThreads / 64) - 1) / (kAggThreads / 64);
     GN_REQUIRE(blocks < (1ll << 31), "node_aggregate: too many nodes");
+    // the hub path (see the header comment): find the long lists, reduce them chunk-wise, let the node's wave add the chunks
+    HubScratch* hub = tuning(kTuneAggHubs) == 1 ? nullptr : hub_scratch();
+    const int* hub_count = hub ? hub->count : nullptr;
+    const int* hub_nodes = hub ? hub->nodes : nullptr;
+    const float* hub_partials = hub ? hub->partials : nullptr;
+    if (hub) {
+        // The list is rebuilt when the CSR arrays change (8 layers share one graph).  A stale list - another graph at the
+        // same addresses - costs speed only: the kernels re-read every count, a listed node that is no hub takes the normal
+        // path, an unlisted hub the single-wave path, and the partials are recomputed at every call.
+        if (hub->key_in != in_ptr || hub->key_out != out_ptr || hub->key_n != n_out) {
+            GN_HIP(hipMemsetAsync(hub->count, 0, sizeof(int), s));
+            hipLaunchKernelGGL(k_find_hubs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, in_ptr, out_ptr, n_out, hub->count, hub->nodes);
+            hub->key_in = in_ptr, hub->key_out = out_ptr, hub->key_n = n_out;
+        }
+        hipLaunchKernelGGL((k_hub_partials<H>), dim3(kHubChunks / (kAggThreads / 64)), dim3(kAggThreads), 0, s, e, A2h, A3h, ldn, in_ptr, ss, out_ptr,
+                           out_pos, od, n_out, hub->count, hub->nodes, hub->partials);
+    }
     // (measurement knob: unused dynamic LDS caps the workgroups resident per CU, i.e. the window of nodes in flight)
     const size_t dyn = (size_t)tuning(kTuneAggLdsKiB) * 1024;
     if (mode == 1) {
         hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 1>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
                            n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
-                           (int)blocks, aux0, aux1, aux2, aux3);
+                           (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials);
     } else if (mode == 2) {
         hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 2>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
                            n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
-                           (int)blocks, aux0, aux1, aux2, aux3);
+                           (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials);
     } else if (norm == GNNOME_NORM_AFFINE) {
         hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 0>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
                            n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
-                           (int)blocks, aux0, aux1, aux2, aux3);
+                           (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials);
     } else {
         hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_LAYER, 0>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
                            n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
-                           (int)blocks, aux0, aux1, aux2, aux3);
+                           (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials);
     }
     GN_LAUNCH_CHECK();
     return GNNOME_OK;

@@ -202,6 +202,53 @@ def test_node_aggregate(hidden, norm):
     assert torch.equal(got_part[:100], got[:100])
 
 
+@pytest.mark.parametrize("hidden,deg", [(128, 100_000), (64, 5000), (256, 20_000)])
+def test_node_aggregate_hub_split_path(hidden, deg):
+    """SURVEY.md 7 "Skew": a node with `deg` in-edges and `deg` out-edges (a repeat-induced hub).  Its list is split into
+    fixed chunks reduced by separate waves and added in chunk order: same result as the contract to fp32 accuracy, the same
+    bits on every run, and the other nodes untouched by the change of path."""
+    import time
+    n = 3000
+    g = torch.Generator().manual_seed(deg + hidden)
+    e_bg = 20_000
+    src = torch.randint(0, n - 3, (e_bg + 2 * deg,), generator=g).int()
+    dst = torch.randint(0, n - 3, (e_bg + 2 * deg,), generator=g).int()
+    hub = 17
+    dst[e_bg:e_bg + deg] = hub          # deg in-edges
+    src[e_bg + deg:] = hub              # deg out-edges
+    E, H = src.numel(), hidden
+    t = {"e": 2.0 * torch.randn(E, H, generator=g), "h": torch.randn(n, H, generator=g), "P": torch.randn(n, 3 * H, generator=g),
+         "scale": 0.5 + torch.rand(H, generator=g), "shift": torch.randn(H, generator=g)}
+    gv, cv = _views_pair(src, dst, n)
+    d = {k: v.to(dev()) for k, v in t.items()}
+    P64 = t["P"].double()
+    want = cpu_ops.node_aggregate(t["e"].double(), P64[:, :H], P64[:, H:2 * H], P64[:, 2 * H:], cv, t["h"].double(), 0, t["scale"].double(),
+                                  t["shift"].double())
+    run = lambda: ops.node_aggregate(d["e"], d["P"][:, :H], d["P"][:, H:2 * H], d["P"][:, 2 * H:], gv, d["h"], 0, d["scale"], d["shift"])  # noqa: E731
+    got = run()
+    _assert_close(got, want, scale=10.0)
+    assert torch.equal(got, run())                                           # bit-reproducible
+    try:   # the single-wave path (hub split off): every OTHER node has the same bits, the hub the same value to rounding
+        ops.set_tuning(6, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        single = run()
+        torch.cuda.synchronize()
+        t_single = time.perf_counter() - t0
+    finally:
+        ops.set_tuning(6, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    t_split = time.perf_counter() - t0
+    mask = torch.ones(n, dtype=torch.bool)
+    mask[hub] = False
+    assert torch.equal(got[mask.to(dev())], single[mask.to(dev())])
+    _assert_close(single[hub], want[hub], scale=10.0)
+    print(f"hub of 2 x {deg} edges, H={hidden}: split path {t_split * 1e3:.3f} ms, single wave {t_single * 1e3:.3f} ms")
+
+
 @pytest.mark.parametrize("hidden,hs", [(64, 64), (128, 64), (256, 64), (64, 32), (128, 128)])
 def test_edge_score(hidden, hs):
     n, e = 400, 1500
