@@ -42,4 +42,58 @@ def edge_features(overlap_length, overlap_similarity):
     return ops.edge_features(overlap_length, overlap_similarity)
 
 
+class MaskedGraph:
+    """Result of mask_graph_strandwise: the induced subgraph on the kept reads (both strands of each), relabelled.
+
+    src, dst     int32[E']  endpoints in the subgraph's own numbering (kept nodes in ascending original order)
+    nid          int64[N']  original node id of subgraph node i   (the reference's sub_g.ndata[dgl.NID])
+    eid          int64[E']  original edge id of subgraph edge k   (sub_g.edata[dgl.EID]; original order kept)
+    views        GraphViews of the subgraph, ready for model(views, x[nid], e[eid])
+    Works as the `graph` argument of the model (edges() / num_nodes())."""
+
+    def __init__(self, src, dst, num_nodes, nid, eid, views):
+        self.src, self.dst, self._n, self.nid, self.eid, self.views = src, dst, num_nodes, nid, eid, views
+
+    def edges(self):
+        return self.src, self.dst
+
+    def num_nodes(self):
+        return self._n
+
+    def num_edges(self):
+        return int(self.src.numel())
+
+
+def mask_graph_strandwise(graph, fraction, device=None, keep_half=None):
+    """train.py:91-100 on the device: keep each READ with probability `fraction` - both its strands, nodes 2r and 2r+1 -
+    and return the induced subgraph (dgl.node_subgraph(g, keep, store_ids=True): kept nodes renumbered in ascending order,
+    the edges whose two endpoints are kept in their original order, original ids stored).  `graph`: (src, dst, N), a
+    DGLGraph, or GraphViews.  `keep_half` (bool[N/2]) overrides the random draw (the reference draws
+    torch.rand(N // 2, device=device) < fraction; pass that tensor to reproduce its stream)."""
+    device = device or (graph.device if isinstance(graph, ops.GraphViews) else torch.device("cuda", torch.cuda.current_device()))
+    if isinstance(graph, ops.GraphViews):
+        if graph.transposed:
+            raise ValueError("mask the original orientation and reverse the result")
+        src = torch.empty(graph.num_edges, dtype=torch.int32, device=device)
+        dst = torch.empty_like(src)
+        src[graph.srt_eid.long()], dst[graph.srt_eid.long()] = graph.srt_src, graph.srt_dst     # back to edge-id order
+        n = graph.num_nodes
+    else:
+        from .graph import edge_list
+        src, dst, n = edge_list(graph)
+        src, dst = src.to(device=device, dtype=torch.int32), dst.to(device=device, dtype=torch.int32)
+    if n % 2:
+        raise ValueError("nodes come in (read, reverse complement) pairs: N must be even")
+    if keep_half is None:
+        keep_half = torch.rand(n // 2, device=device) < fraction
+    keep = keep_half.to(device).repeat_interleave(2)
+    new_id = torch.cumsum(keep, 0, dtype=torch.int32) - 1
+    edge_keep = keep[src.long()] & keep[dst.long()]
+    eid = torch.nonzero(edge_keep).squeeze(1)
+    nid = torch.nonzero(keep).squeeze(1)
+    s2, d2 = new_id[src[eid].long()].contiguous(), new_id[dst[eid].long()].contiguous()
+    views = ops.GraphViews(s2, d2, int(nid.numel()), validate=False)
+    return MaskedGraph(s2, d2, int(nid.numel()), nid, eid, views)
+
+
 degree_features_hip, edge_features_hip = degree_features, edge_features   # earlier names
