@@ -504,6 +504,52 @@ def test_full_size_properties(n, e, hidden):
     assert _prob_diff(a[perm], d) < PROB_TOL
 
 
+def test_h256_shard_of_configs3_properties():
+    """One GPU's eighth of BASELINE configs[3] (N = 250k, E = 2.5M, H = 256): run-to-run identical, the reversed-graph /
+    swapped-roles identity, edge-id permutation equivariance - the size-independent properties of the path, at the width
+    and per-GPU size the 8-GPU configurations run."""
+    n, e, hidden = 250_000, 2_500_000, 256
+    gr = make_graph(n, e, seed=1, kind="banded")
+    x = degree_features(gr["src"], gr["dst"], n).to(dev())
+    ef = gr["e"].to(dev())
+    sd = random_state_dict(hidden, seed=1)
+    m = _model(sd, hidden)
+    graph = (gr["src"].to(dev()), gr["dst"].to(dev()), n)
+    views = views_for(graph, dev())
+    a = m(views, x, ef)
+    assert a.shape == (e, 1) and torch.isfinite(a).all() and torch.equal(a, m(views, x, ef))
+    b = _model(_swap_roles(sd, hidden), hidden)(views.reversed(), x, ef)
+    assert _prob_diff(a, b) < PROB_TOL
+    perm = torch.randperm(e, generator=torch.Generator().manual_seed(3)).to(dev())
+    d = m((graph[0][perm], graph[1][perm], n), x, ef[perm])
+    assert _prob_diff(a[perm], d) < PROB_TOL
+    del a, b, d
+    torch.cuda.empty_cache()
+
+
+def test_kernel_called_through_a_binding_built_from_the_header_alone():
+    """The C ABI as a maintainer of the reference would bind it: ctypes prototypes parsed out of include/gnnome_hip.h
+    (tests/header_binding.py), raw device pointers, torch only as the allocator."""
+    import ctypes
+
+    import header_binding
+    from gnnome_amd import _lib
+    lib = header_binding.bind(_lib.LIB_PATH, _lib.HEADER_PATH)
+    g = torch.Generator().manual_seed(4)
+    x, W1, b1 = torch.randn(999, 2, generator=g), torch.randn(16, 2, generator=g), torch.randn(16, generator=g)
+    W2, b2 = torch.randn(128, 16, generator=g), torch.randn(128, generator=g)
+    d = [t.to(dev()).contiguous() for t in (x, W1, b1, W2, b2)]
+    out = torch.empty(999, 128, device=dev())
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.gnnome_encode_f32(p(d[0]), 999, 2, None, p(d[1]), p(d[2]), 16, p(d[3]), p(d[4]), 128, p(out), stream)
+    assert rc == 0, lib.gnnome_last_error()
+    want = cpu_ops.encode(x.double(), W1.double(), b1.double(), W2.double(), b2.double())
+    _assert_close(out, want)
+    assert lib.gnnome_encode_f32(p(d[0]), 999, 2, None, p(d[1]), p(d[2]), 16, p(d[3]), p(d[4]), 96, p(out), stream) == -1
+    assert b"hidden=96" in lib.gnnome_last_error()
+
+
 def test_counter_synchronised_kernels_soak():
     """tools/gate_soak.py: a few hundred launches of the edge-tile kernels at random sizes and in every mode, each checked
     against the barrier-synchronised / tile kernels; bounded, so that a lost hand-over fails the test instead of hanging it."""

@@ -73,3 +73,39 @@ def test_two_ranks_training_step_matches_reference_golden_g3(tmp_path):
             assert torch.allclose(o["buffers"][k].float(), want.float(), atol=1e-5, rtol=1e-4), k
     for k in outs[0]["grads"]:
         assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k
+
+
+@pytest.mark.parametrize("hidden", [128, 256])
+def test_two_ranks_at_the_widths_of_configs_3_and_4(tmp_path, hidden):
+    """BASELINE configs[3] / [4] run at H = 256 (and the 10M-edge target at H = 128): the partitioned forward against the
+    reference goldens G5 at those widths, both ranks bit-identical."""
+    g = load_golden(f"g5_eval_h{hidden}.pt")
+    case = dict(src=g["src"], dst=g["dst"], num_nodes=g["num_nodes"], x=g["x"], e=g["e"], hidden=hidden, layers=8,
+                state_dict=random_state_dict(hidden, seed=g["seed"]), device="cuda")
+    outs = _run(2, case, tmp_path)
+    for o in outs:
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(g["logits"].squeeze(1))).abs().max().item() < 1e-4
+    assert torch.equal(outs[0]["logits"], outs[1]["logits"])
+    assert sum(o["n_score"] for o in outs) == g["src"].numel()
+
+
+def test_two_ranks_h256_banded_200k_edges_equals_one_rank(tmp_path):
+    """A layout-ordered graph at H = 256 large enough that every kernel runs many tiles per rank: two ranks against the
+    single-process forward (same kernels, different row sets and halo traffic)."""
+    import gnnome_amd
+    from gnnome_amd.synth import make_graph
+    from oracle.symgated_oracle import degree_features
+    n, e, hidden = 20_000, 200_000, 256
+    gr = make_graph(n, e, seed=3, kind="banded")
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(hidden, seed=2)
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], hidden=hidden, layers=8, state_dict=sd, device="cuda")
+    outs = _run(2, case, tmp_path)
+    m = gnnome_amd.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch").eval()
+    m.load_state_dict(sd)
+    dev = torch.device("cuda", 0)
+    want = m.to(dev)((gr["src"], gr["dst"], n), x.to(dev), gr["e"].to(dev)).squeeze(1).cpu()
+    for o in outs:
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(want)).abs().max().item() < 1e-5
+    assert torch.equal(outs[0]["logits"], outs[1]["logits"])
+    assert all(o["n_local"] > o["n_own"] for o in outs) and all(sum(o["send"]) < 0.2 * n for o in outs)   # banded: thin halo

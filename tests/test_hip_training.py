@@ -311,6 +311,64 @@ def test_training_step_is_bit_reproducible():
         assert torch.equal(runs[0][3][k], runs[1][3][k]), k
 
 
+def test_training_step_full_size_properties():
+    """BASELINE configs[2]'s shape (N = 1e5, E = 1e6, H = 128): a whole fwd + BCE + bwd step twice from the same state -
+    same bits (logits, loss, all 142 gradients, BatchNorm buffers), everything finite, BatchNorm counters advanced as the
+    reference advances them (bn_e twice per layer, gated_gcn_full.py:106,119), and the hipGraph replay of the step equal to
+    the eager step."""
+    from gnnome_amd.loss import bce_loss as hip_bce
+    n, e, hidden = 100_000, 1_000_000, 128
+    gr = make_graph(n, e, seed=1)
+    views = gnnome_amd.graph.views_for((gr["src"], gr["dst"], n), dev())
+    x, ef, y, pw = ops.degree_features(views), gr["e"].to(dev()), gr["y"].to(dev()), gr["pos_weight"].to(dev())
+    runs = []
+    for _ in range(2):
+        m = _train_model(random_state_dict(hidden, seed=5), hidden)
+        logits = m(views, x, ef)
+        loss = hip_bce(logits.squeeze(-1), y, pw)
+        loss.backward()
+        runs.append((logits.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                     {k: b.clone() for k, b in m.named_buffers()}))
+        del m, logits, loss
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and torch.isfinite(runs[0][1])
+    assert len(runs[0][2]) == 142
+    for k in runs[0][2]:
+        assert torch.isfinite(runs[0][2][k]).all() and torch.equal(runs[0][2][k], runs[1][2][k]), k
+    for k in runs[0][3]:
+        assert torch.equal(runs[0][3][k], runs[1][3][k]), k
+    assert runs[0][3]["gnn.convs.3.bn_e.num_batches_tracked"].item() == 2 and runs[0][3]["gnn.convs.3.bn_h.num_batches_tracked"].item() == 1
+    # the step recorded into a hipGraph (what bench.py times) replays to the same bits as the eager step
+    m = _train_model(random_state_dict(hidden, seed=5), hidden)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        logits = m(views, x, ef)
+        loss = hip_bce(logits.squeeze(-1), y, pw)
+        loss.backward()
+        return logits.detach(), loss.detach()
+
+    side = torch.cuda.Stream(device=dev())
+    side.wait_stream(torch.cuda.current_stream(dev()))
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream(dev()).wait_stream(side)
+    for k, b in m.named_buffers():   # back to the initial BatchNorm state: the recorded step must start where the eager ones did
+        b.copy_(dict(_train_model(random_state_dict(hidden, seed=5), hidden).named_buffers())[k])
+    graph = torch.cuda.CUDAGraph()
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    with torch.cuda.graph(graph):
+        logits = m(views, x, ef)
+        loss = hip_bce(logits.squeeze(-1), y, pw)
+        loss.backward()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(logits.detach(), runs[0][0]) and torch.equal(loss.detach(), runs[0][1])
+    for k, p in m.named_parameters():
+        assert torch.equal(p.grad, runs[0][2][k]), k
+
+
 @pytest.mark.parametrize("rows,H", [(777, 64), (40_003, 128), (300, 256), (5000, 16)])
 def test_layernorm_kernels(rows, H):
     """gnnome_ln_relu_res_f32 / gnnome_ln_bwd_f32 against an fp64 evaluation of their contract (torch autograd)."""

@@ -27,6 +27,22 @@ def test_library_exports_every_declared_symbol():
     assert int(m.group(1)) == _lib.ABI_VERSION
 
 
+def test_binding_built_from_the_header_text_alone():
+    """include/gnnome_hip.h is enough to bind the library.  Every prototype parses, and the
+    argument kinds (pointer / int / int64 / size_t / float) agree with the package's own table."""
+    import header_binding
+    parsed = header_binding.parse_header(_lib.HEADER_PATH)
+    assert set(parsed) == set(_lib.SIGNATURES)
+    kind = lambda t: "ptr" if t in (ctypes.c_void_p,) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)) else t  # noqa: E731
+    for name, (_, argtypes, names) in parsed.items():
+        assert [kind(t) for t in argtypes] == [kind(t) for t in _lib.SIGNATURES[name]], (name, names)
+    lib = header_binding.bind(_lib.LIB_PATH, _lib.HEADER_PATH)
+    assert lib.gnnome_abi_version() == _lib.ABI_VERSION
+    need = ctypes.c_size_t(0)
+    assert lib.gnnome_greedy_walks_workspace_bytes(1000, 7, ctypes.byref(need)) == 0 and need.value >= 7 * 32 * 4
+    assert lib.gnnome_linear_ref_f32(None, 4, 64, 64, None, 64, None, 8, None, 8, None) == -1 and b"null" in lib.gnnome_last_error()
+
+
 def test_argument_validation_without_a_gpu():
     lib = _lib.load()
     rc = lib.gnnome_linear_f32(None, 4, 60, 60, None, 60, None, 8, None, 8, None)
