@@ -89,12 +89,12 @@ __device__ __forceinline__ float row_sum(float v) {
 
 // The gated sums over items [lo, hi) of one node's work list (in-edges first, then out-edges), lane group g taking every
 // G-th item of every 64-item batch; per-lane-group partial sums (combine with group_sum).
-template <int H>
+template <int H, int U = (H == 256 ? 8 : 2)>
 __device__ __forceinline__ void accumulate_items(const float* __restrict__ e, const float* __restrict__ A2h, const float* __restrict__ A3h,
                                                  int ldn, const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_pos,
                                                  const int32_t* __restrict__ out_dst, int ib, int din, int ob, int lo, int hi, int lane,
                                                  int group, int c, f32x4& nf, f32x4& df, f32x4& nb, f32x4& db) {
-    constexpr int LPR = H / 4, G = 64 / LPR, U = (H == 256) ? 8 : 4;
+    constexpr int LPR = H / 4, G = 64 / LPR;
     for (int base = lo; base < hi; base += 64) {
         // lane l owns item base + l
         const int j = base + lane;
@@ -188,8 +188,13 @@ __global__ __launch_bounds__(kAggThreads) void k_hub_partials(const float* __res
 // MODE 0: the fused inference update.  MODE 1 (train forward): h_out = A1h + fwd + bwd (pre-normalisation) and the
 // four node tables the backward needs (aux0..3 = fwd, 1/(den_f+eps), bwd, 1/(den_b+eps)).  MODE 2 (aggregation
 // backward): aux0 = sum_in s*A2h[src], aux2 = sum_out s*A3h[dst], the raw gated sums with caller-chosen tables.
-template <int H, int NORM, int MODE>
-__global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
+// HUBFIN = false: the regular launch, one wave per node; a node on the hub list (and still longer than the threshold) is
+// left to the HUBFIN = true launch, which runs one wave per hub-list slot, adds the chunk partials in chunk order and
+// shares everything after the sums (two launches instead of a branch: the partial-sum loop cost the regular kernel 22
+// registers and a third of its occupancy).  U: items per lane group in flight, WPS: waves per SIMD asked of the register
+// allocator (0 = unconstrained).
+template <int H, int NORM, int MODE, bool HUBFIN = false, int U = (H == 256 ? 8 : 2), int WPS = 0>
+__global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggregate(
     const float* __restrict__ e, int64_t n_out, const float* __restrict__ A1h, const float* __restrict__ A2h,
     const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src,
     const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_dst,
@@ -199,25 +204,33 @@ __global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
     const float* __restrict__ hub_partials) {
     constexpr int LPR = H / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t node = (int64_t)xcd_remap(blockIdx.x, total_blocks) * (kAggThreads / 64) + wave;
+    int64_t node;
+    int hub_slot = -1;
+    if (HUBFIN) {
+        hub_slot = blockIdx.x * (kAggThreads / 64) + wave;
+        if (hub_slot >= min(*hub_count, kHubCap)) return;
+        node = hub_nodes[hub_slot];
+    } else {
+        node = (int64_t)xcd_remap(blockIdx.x, total_blocks) * (kAggThreads / 64) + wave;
+    }
     if (node >= n_out) return;
     const int group = lane / LPR, c = (lane % LPR) * 4;
 
     const int ib = in_ptr[node], din = in_ptr[node + 1] - ib;
     const int ob = out_ptr[node], cnt = din + out_ptr[node + 1] - ob;
+    if (HUBFIN) {
+        if (cnt <= kHubThreshold) return;   // a stale list entry: the regular launch has done this node
+    } else if (cnt > kHubThreshold && hub_nodes != nullptr) {   // wave-uniform: is this node on the hub list?
+        const int nh = min(*hub_count, kHubCap);
+        bool listed = false;
+        for (int base = 0; base < nh; base += 64) listed |= __ballot(base + lane < nh && hub_nodes[base + lane] == (int)node) != 0;
+        if (listed) return;
+    }
     f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
     if (MODE != 2) a1 = *reinterpret_cast<const f32x4*>(A1h + node * ldn + c);
 
     f32x4 nf = {0.f, 0.f, 0.f, 0.f}, df = nf, nb = nf, db = nf;
-    int hub_slot = -1;
-    if (cnt > kHubThreshold && hub_nodes != nullptr) {   // wave-uniform: was this node given the split path?
-        const int nh = min(*hub_count, kHubCap);
-        for (int base = 0; base < nh; base += 64) {
-            const unsigned long long m = __ballot(base + lane < nh && hub_nodes[base + lane] == (int)node);
-            if (m) hub_slot = base + __ffsll((long long)m) - 1;
-        }
-    }
-    if (hub_slot >= 0) {
+    if (HUBFIN) {
         // add the chunk partials in chunk order (lane group 0 carries the sums; the others stay zero for group_sum)
         if (group == 0) {
             const float* pp = hub_partials + ((int64_t)hub_slot * kHubChunks) * 4 * H + c;
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(kAggThreads) void k_node_aggregate(
             }
         }
     } else {
-        accumulate_items<H>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
+        accumulate_items<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
     }
 
     f32x4 v, t0, t1, t2, t3;
@@ -307,23 +320,35 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
     }
     // (measurement knob: unused dynamic LDS caps the workgroups resident per CU, i.e. the window of nodes in flight)
     const size_t dyn = (size_t)tuning(kTuneAggLdsKiB) * 1024;
+#define GN_AGG_LAUNCH(NORM_, MODE_, FIN_, U_, WPS_, GRID_)                                                                              \
+    hipLaunchKernelGGL((k_node_aggregate<H, NORM_, MODE_, FIN_, U_, WPS_>), dim3((unsigned)(GRID_)), dim3(kAggThreads), (FIN_) ? 0 : dyn, s, e, \
+                       n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift, (int)blocks, aux0, \
+                       aux1, aux2, aux3, hub_count, hub_nodes, hub_partials)
+    // items per lane group in flight: 2 at H <= 128 (62 registers, 8 waves per SIMD: 0.2115 ms at configs[1] against 0.2197 for 4
+    // and 0.2533 for 8 - tools/agg_time.py <H> variants; the kernel gets SLOWER with more loads in flight per wave)
+    constexpr int UD = H == 256 ? 8 : 2;
+    constexpr int kFinGrid = kHubCap / (kAggThreads / 64);
     if (mode == 1) {
-        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 1>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
-                           n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
-                           (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials);
+        GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 1, false, UD, 0, blocks);
+        if (hub) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 1, true, UD, 0, kFinGrid);
     } else if (mode == 2) {
-        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 2>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
-                           n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
-                           (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials);
+        GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 2, false, UD, 0, blocks);
+        if (hub) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 2, true, UD, 0, kFinGrid);
     } else if (norm == GNNOME_NORM_AFFINE) {
-        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 0>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
-                           n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
-                           (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials);
+        switch (tuning(kTuneAggVariant)) {   // A/B of occupancy against items in flight (tools/agg_time.py)
+            case 1: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 4, 8, blocks); break;
+            case 2: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 2, 8, blocks); break;
+            case 3: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 1, 0, blocks); break;
+            case 4: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 8, 0, blocks); break;
+            case 5: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 4, 0, blocks); break;
+            default: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks); break;
+        }
+        if (hub) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, true, UD, 0, kFinGrid);
     } else {
-        hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_LAYER, 0>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e,
-                           n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,
-                           (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials);
+        GN_AGG_LAUNCH(GNNOME_NORM_LAYER, 0, false, UD, 0, blocks);
+        if (hub) GN_AGG_LAUNCH(GNNOME_NORM_LAYER, 0, true, UD, 0, kFinGrid);
     }
+#undef GN_AGG_LAUNCH
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

@@ -20,6 +20,30 @@ h = torch.randn(n, H, device=dev, generator=gen)
 P = torch.randn(n, 5 * H, device=dev, generator=gen)
 sc, sh = torch.rand(H, device=dev, generator=gen) * 0.1, torch.randn(H, device=dev, generator=gen)
 A1, A2, A3 = (P[:, i * H:(i + 1) * H] for i in range(3))
+if len(sys.argv) > 2 and sys.argv[2] == "once":   # a few launches of the default kernel, for the PMC passes (tools/pmc_agg.sh)
+    for _ in range(5):
+        ops.node_aggregate(ee, A1, A2, A3, views, h, 0, sc, sh)
+    torch.cuda.synchronize()
+    sys.exit(0)
+VARIANTS = {0: "default (U=2 at H<=128, 8 at 256)", 1: "U=4, 8 waves/SIMD", 2: "U=2, 8 waves/SIMD", 3: "U=1", 4: "U=8", 5: "U=4"}
+if len(sys.argv) > 2 and sys.argv[2] == "variants":   # items in flight per lane group against occupancy (gnnome_set_tuning key 7)
+    for rnd in range(3):
+        for v, name in VARIANTS.items():
+            ops.set_tuning(7, v)
+            for _ in range(3):
+                ops.node_aggregate(ee, A1, A2, A3, views, h, 0, sc, sh)
+            evs = []
+            for _ in range(30):
+                s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                ops.node_aggregate(ee, A1, A2, A3, views, h, 0, sc, sh)
+                t.record()
+                evs.append((s, t))
+            torch.cuda.synchronize()
+            ts = sorted(x.elapsed_time(y) for x, y in evs)
+            print(f"round {rnd} variant {v} ({name}): median {ts[len(ts) // 2]:.4f} ms  min {ts[0]:.4f} ms", flush=True)
+    ops.set_tuning(7, 0)
+    sys.exit(0)
 for rnd in range(2):
     for kib in (0, 16, 24, 32, 40, 54, 80):
         ops.set_tuning(5, kib)
