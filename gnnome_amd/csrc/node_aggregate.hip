@@ -89,7 +89,7 @@ __device__ __forceinline__ float row_sum(float v) {
 
 // The gated sums over items [lo, hi) of one node's work list (in-edges first, then out-edges), lane group g taking every
 // G-th item of every 64-item batch; per-lane-group partial sums (combine with group_sum).
-template <int H, int U = (H == 256 ? 8 : 2)>
+template <int H, int U = (H == 256 ? 8 : 4)>
 __device__ __forceinline__ void accumulate_items(const float* __restrict__ e, const float* __restrict__ A2h, const float* __restrict__ A3h,
                                                  int ldn, const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_pos,
                                                  const int32_t* __restrict__ out_dst, int ib, int din, int ob, int lo, int hi, int lane,
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kAggThreads) void k_hub_partials(const float* __res
 // shares everything after the sums (two launches instead of a branch: the partial-sum loop cost the regular kernel 22
 // registers and a third of its occupancy).  U: items per lane group in flight, WPS: waves per SIMD asked of the register
 // allocator (0 = unconstrained).
-template <int H, int NORM, int MODE, bool HUBFIN = false, int U = (H == 256 ? 8 : 2), int WPS = 0>
+template <int H, int NORM, int MODE, bool HUBFIN = false, int U = (H == 256 ? 8 : 4), int WPS = 0>
 __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggregate(
     const float* __restrict__ e, int64_t n_out, const float* __restrict__ A1h, const float* __restrict__ A2h,
     const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src,
@@ -324,9 +324,12 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
     hipLaunchKernelGGL((k_node_aggregate<H, NORM_, MODE_, FIN_, U_, WPS_>), dim3((unsigned)(GRID_)), dim3(kAggThreads), (FIN_) ? 0 : dyn, s, e, \
                        n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift, (int)blocks, aux0, \
                        aux1, aux2, aux3, hub_count, hub_nodes, hub_partials)
-    // items per lane group in flight: 2 at H <= 128 (62 registers, 8 waves per SIMD: 0.2115 ms at configs[1] against 0.2197 for 4
-    // and 0.2533 for 8 - tools/agg_time.py <H> variants; the kernel gets SLOWER with more loads in flight per wave)
-    constexpr int UD = H == 256 ? 8 : 2;
+    // items per lane group in flight: 4 at H <= 128.  Measured at configs[1] (tools/agg_time.py <H> variants): 1 item 0.2105 ms,
+    // 2 items 0.2115, 4 items 0.2197, 8 items 0.2533 - the launch time hardly depends on the loads in flight per wave (the
+    // kernel sits at the HBM rate this access pattern sustains) - but with 2 items the 8 resident waves per SIMD widen the
+    // window of nodes in flight and the out-edge pass finds fewer of its rows still in L2: 979 MB fetched per launch against
+    // 764 MB.  4 % of launch time is not worth 28 % more HBM traffic.
+    constexpr int UD = H == 256 ? 8 : 4;
     constexpr int kFinGrid = kHubCap / (kAggThreads / 64);
     if (mode == 1) {
         GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 1, false, UD, 0, blocks);
@@ -340,7 +343,7 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
             case 2: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 2, 8, blocks); break;
             case 3: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 1, 0, blocks); break;
             case 4: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 8, 0, blocks); break;
-            case 5: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 4, 0, blocks); break;
+            case 5: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 2, 0, blocks); break;
             default: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks); break;
         }
         if (hub) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, true, UD, 0, kFinGrid);

@@ -1,29 +1,36 @@
 #!/bin/bash
-# round-end evidence: rocprofv3 kernel stats (infer + train), PMC traffic of the dominant kernel, bench lines.
+# round-end evidence in one GPU-box visit: rocprofv3 kernel stats (infer + train), PMC traffic of the dominant kernel and of
+# every kernel of one forward, bench lines for every workload.   usage: tools/final_profiles.sh <tag, e.g. r02>
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/final; mkdir -p $O
+TAG=${1:-r02}
+O=gpurun_out/final; rm -rf $O; mkdir -p $O
 for mode in infer train; do
-  timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_$mode -o r01 -- python bench.py --mode $mode --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers > $O/prof_$mode.bench.json 2> $O/prof_$mode.err
+  timeout 500 rocprofv3 --kernel-trace --stats -d $O/prof_$mode -o r -- python bench.py --mode $mode --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-extras > $O/prof_$mode.bench.json 2> $O/prof_$mode.err
   DB=$(find $O/prof_$mode -name "*.db" | head -1)
-  python tools/rocpd_summary.py "$DB" > $O/kernel_stats_$mode.md 2>&1
-  find $O/prof_$mode -name "*.db" -delete
-  head -14 $O/kernel_stats_$mode.md
+  python tools/rocpd_summary.py "$DB" > $O/${TAG}_c2_$mode.kernel_stats.md 2>&1
+  rm -rf $O/prof_$mode
+  head -14 $O/${TAG}_c2_$mode.kernel_stats.md
 done
 bash tools/pmc_traffic.sh $O/pmc
-python tools/pmc_to_json.py $O/pmc $O/gate_pmc.json k_edge_gate_bf | tail -8
-find $O/pmc -name "*.db" -delete
-timeout 400 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; tail -c 500 $O/bench_c2.json
-for w in 10m parity64 c4shard; do timeout 400 python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
-timeout 400 python bench.py --kind uniform --no-cpu-baseline > $O/bench_c2_uniform.json 2>/dev/null
-timeout 400 python bench.py --mode train --steps 10 --warmup 3 > $O/bench_train.json 2>/dev/null
-for f in c2 10m parity64 c4shard c2_uniform train; do python - "$f" <<'PY'
+python tools/pmc_to_json.py $O/pmc $O/${TAG}_gate_pmc.json k_edge_gate_bf | tail -8
+rm -rf $O/pmc
+bash tools/pmc_forward.sh $O/pmc_fwd > $O/${TAG}_forward_hbm_traffic.md 2>&1; tail -12 $O/${TAG}_forward_hbm_traffic.md
+rm -rf $O/pmc_fwd
+cp $O/${TAG}_gate_pmc.json profiles/   # so that the bench line below can quote the traffic of THIS build
+timeout 900 python bench.py > $O/${TAG}_bench_c2.json 2> $O/bench_c2.err; tail -c 400 $O/${TAG}_bench_c2.json
+for w in 10m parity64 c4shard; do timeout 400 python bench.py --workload $w --no-cpu-baseline --no-extras > $O/${TAG}_bench_$w.json 2>/dev/null; done
+timeout 400 python bench.py --kind uniform --no-cpu-baseline --no-extras > $O/${TAG}_bench_c2_uniform.json 2>/dev/null
+timeout 600 python bench.py --mode train > $O/${TAG}_bench_c3_train_step.json 2>/dev/null
+timeout 600 python bench.py --mode train --symmetry --no-cpu-baseline > $O/${TAG}_bench_c3_train_symmetry.json 2>/dev/null
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --one-gpu-gloo --workload c2 --steps 5 --warmup 2 > $O/${TAG}_bench_n2_plumbing.json 2>/dev/null
+for f in c2 10m parity64 c4shard c2_uniform c3_train_step c3_train_symmetry n2_plumbing; do python - "$f" "$TAG" <<'PY'
 import json,sys
-f=sys.argv[1]
+f,tag=sys.argv[1],sys.argv[2]
 try:
-    d=json.loads([l for l in open(f"gpurun_out/final/bench_{f}.json") if l.startswith("{")][-1])
+    d=json.loads([l for l in open(f"gpurun_out/final/{tag}_bench_{f}.json") if l.startswith("{")][-1])
     r=d.get("roofline",{})
-    print(f, round(d["ms_per_step"],3), "ms", round(d["value"]/1e6,1), "M edges/s | gate", round(r.get("avg_launch_ms",0),4), r.get("bound"), round(r.get("frac",0),3), "| cold", d.get("cold_ms_incl_graph_views"), "| cpu", (d.get("cpu_baseline") or {}).get("value"))
+    print(f, round(d["ms_per_step"],3), "ms", round(d["value"]/1e6,1), "M edges/s | gate", round(r.get("avg_launch_ms",0),4), r.get("bound"), round(r.get("frac",0),3), "traffic", r.get("traffic"), "| cpu", (d.get("cpu_baseline") or {}).get("value"))
 except Exception as ex:
     print(f, "FAILED", ex)
 PY

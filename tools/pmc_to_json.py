@@ -5,6 +5,7 @@ FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies 128-by
 (MI355X_MICROARCH.md, "HBM"); WRITE_SIZE is taken as is - it equals the kernel's exact output size, which calibrates it.
 usage: tools/pmc_to_json.py <dir with FETCH_SIZE/ and WRITE_SIZE/> <out.json> [kernel-name substring]"""
 import csv
+import hashlib
 import json
 import os
 import sys
@@ -28,7 +29,9 @@ def main():
     write, n_w = mean_counter(os.path.join(src, "WRITE_SIZE", "p_counter_collection.csv"), needle)
     e, hidden = 1_000_000, 128
     rd, wr = int(2 * fetch * 1024), int(write * 1024)
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnnome_amd", "lib", "libgnnome_hip.so")
     res = {
+        "so_sha16": hashlib.sha256(open(so, "rb").read()).hexdigest()[:16],   # bench.py quotes the file only for this build
         "kernel": needle, "workload": f"c2: N={e // 10} E={e} H={hidden} (tools/gate_only.py, {n_f} launches averaged)",
         "collected_with": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, one counter per pass",
         "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
