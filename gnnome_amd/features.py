@@ -64,6 +64,33 @@ class MaskedGraph:
         return int(self.src.numel())
 
 
+def _edge_list_on(graph, device):
+    if isinstance(graph, ops.GraphViews):
+        if graph.transposed:
+            raise ValueError("take the subgraph of the original orientation and reverse the result")
+        src = torch.empty(graph.num_edges, dtype=torch.int32, device=device)
+        dst = torch.empty_like(src)
+        src[graph.srt_eid.long()], dst[graph.srt_eid.long()] = graph.srt_src, graph.srt_dst     # back to edge-id order
+        return src, dst, graph.num_nodes
+    from .graph import edge_list
+    src, dst, n = edge_list(graph)
+    return src.to(device=device, dtype=torch.int32), dst.to(device=device, dtype=torch.int32), n
+
+
+def induced_subgraph(graph, keep, device=None):
+    """dgl.node_subgraph(g, keep, store_ids=True) on the device: `keep` bool[N]; kept nodes renumbered in ascending order,
+    the edges whose two endpoints are kept in their original order, original ids stored (MaskedGraph.nid / .eid)."""
+    device = device or (graph.device if isinstance(graph, ops.GraphViews) else torch.device("cuda", torch.cuda.current_device()))
+    src, dst, n = _edge_list_on(graph, device)
+    keep = keep.to(device)
+    new_id = torch.cumsum(keep, 0, dtype=torch.int32) - 1
+    eid = torch.nonzero(keep[src.long()] & keep[dst.long()]).squeeze(1)
+    nid = torch.nonzero(keep).squeeze(1)
+    s2, d2 = new_id[src[eid].long()].contiguous(), new_id[dst[eid].long()].contiguous()
+    views = ops.GraphViews(s2, d2, int(nid.numel()), validate=False)
+    return MaskedGraph(s2, d2, int(nid.numel()), nid, eid, views)
+
+
 def mask_graph_strandwise(graph, fraction, device=None, keep_half=None):
     """train.py:91-100 on the device: keep each READ with probability `fraction` - both its strands, nodes 2r and 2r+1 -
     and return the induced subgraph (dgl.node_subgraph(g, keep, store_ids=True): kept nodes renumbered in ascending order,
@@ -71,29 +98,13 @@ def mask_graph_strandwise(graph, fraction, device=None, keep_half=None):
     DGLGraph, or GraphViews.  `keep_half` (bool[N/2]) overrides the random draw (the reference draws
     torch.rand(N // 2, device=device) < fraction; pass that tensor to reproduce its stream)."""
     device = device or (graph.device if isinstance(graph, ops.GraphViews) else torch.device("cuda", torch.cuda.current_device()))
-    if isinstance(graph, ops.GraphViews):
-        if graph.transposed:
-            raise ValueError("mask the original orientation and reverse the result")
-        src = torch.empty(graph.num_edges, dtype=torch.int32, device=device)
-        dst = torch.empty_like(src)
-        src[graph.srt_eid.long()], dst[graph.srt_eid.long()] = graph.srt_src, graph.srt_dst     # back to edge-id order
-        n = graph.num_nodes
-    else:
-        from .graph import edge_list
-        src, dst, n = edge_list(graph)
-        src, dst = src.to(device=device, dtype=torch.int32), dst.to(device=device, dtype=torch.int32)
+    n = graph.num_nodes if isinstance(graph, ops.GraphViews) else (graph[2] if isinstance(graph, (tuple, list)) else graph.num_nodes())
+    n = int(n)
     if n % 2:
         raise ValueError("nodes come in (read, reverse complement) pairs: N must be even")
     if keep_half is None:
         keep_half = torch.rand(n // 2, device=device) < fraction
-    keep = keep_half.to(device).repeat_interleave(2)
-    new_id = torch.cumsum(keep, 0, dtype=torch.int32) - 1
-    edge_keep = keep[src.long()] & keep[dst.long()]
-    eid = torch.nonzero(edge_keep).squeeze(1)
-    nid = torch.nonzero(keep).squeeze(1)
-    s2, d2 = new_id[src[eid].long()].contiguous(), new_id[dst[eid].long()].contiguous()
-    views = ops.GraphViews(s2, d2, int(nid.numel()), validate=False)
-    return MaskedGraph(s2, d2, int(nid.numel()), nid, eid, views)
+    return induced_subgraph(graph, keep_half.to(device).repeat_interleave(2), device)
 
 
 degree_features_hip, edge_features_hip = degree_features, edge_features   # earlier names

@@ -95,3 +95,49 @@ def test_strandwise_mask_and_induced_subgraph():
     assert torch.equal(sub2.src, sub.src) and torch.equal(sub2.eid, sub.eid)
     sub3 = features.mask_graph_strandwise(views, 0.5)
     assert 0.3 * n < sub3.num_nodes() < 0.7 * n and bool((sub3.nid[0::2] + 1 == sub3.nid[1::2]).all())
+
+
+@pytest.mark.gpu
+def test_cluster_partition_with_halo():
+    """The role of dgl.metis_partition(g, k, extra_cached_hops=1) in train.py:333-346: every node is an inner node of exactly
+    one cluster, clusters are balanced, a cluster's subgraph holds all edges among its nodes and their 1-hop neighbours, and
+    it trains through the model like any graph."""
+    import gnnome_amd
+    from gnnome_amd import partition
+    from gnnome_amd.synth import make_graph, random_state_dict
+    n, e, k = 20_000, 200_000, 10
+    gr = make_graph(n, e, seed=6)
+    parts = partition.cluster_partition((gr["src"], gr["dst"], n), k, extra_cached_hops=1, device=dev())
+    assert len(parts) == k
+    owner = torch.full((n,), -1, dtype=torch.long)
+    src, dst = gr["src"].long(), gr["dst"].long()
+    for p, sub in parts.items():
+        nid, inner = sub.nid.cpu(), sub.inner_node.cpu()
+        assert (owner[nid[inner]] == -1).all()
+        owner[nid[inner]] = p
+        assert 0.5 * n / k <= int(inner.sum()) <= 1.3 * n / k + 2                        # balanced
+        keep = torch.zeros(n, dtype=torch.bool)
+        keep[nid] = True
+        # halo = exactly the 1-hop neighbourhood of the inner nodes; edges = all edges among kept nodes
+        inner_mask = torch.zeros(n, dtype=torch.bool)
+        inner_mask[nid[inner]] = True
+        want = inner_mask.clone()
+        want[dst[inner_mask[src]]] = True
+        want[src[inner_mask[dst]]] = True
+        assert torch.equal(keep, want)
+        assert torch.equal(sub.eid.cpu(), torch.nonzero(keep[src] & keep[dst]).squeeze(1))
+    assert (owner >= 0).all()
+    again = partition.cluster_partition((gr["src"], gr["dst"], n), k, device=dev())
+    assert all(torch.equal(again[p].nid, parts[p].nid) for p in parts)                   # deterministic
+    # one training step on a cluster (get_bce_loss_partition, train.py:148-156)
+    from gnnome_amd.loss import bce_loss
+    m = gnnome_amd.SymGatedGCNModel(2, 2, 64, 16, 2, 64, "batch").train()
+    m.load_state_dict(random_state_dict(64, num_layers=2, seed=1))
+    m.to(dev())
+    sub = parts[3]
+    from gnnome_amd import features
+    x_full = features.degree_features(gnnome_amd.graph.views_for((gr["src"], gr["dst"], n), dev()))
+    logits = m(sub, x_full[sub.nid], gr["e"].to(dev())[sub.eid])
+    loss = bce_loss(logits.squeeze(-1), gr["y"].to(dev())[sub.eid], gr["pos_weight"].to(dev()))
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())

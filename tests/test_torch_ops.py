@@ -1,0 +1,53 @@
+"""torch.ops.gnnome_hip.* (gnnome_amd/torch_ops.py): the C ABI's inference entry points as dispatcher operators -
+schemas and shape inference here, the kernels behind them on the GPU."""
+import pytest
+import torch
+
+import cpu_ops
+import gnnome_amd.torch_ops  # noqa: F401  (registers the operators)
+
+
+def test_operators_are_registered_with_schemas_and_trace_on_meta():
+    names = ("build_graph_views", "encode", "linear", "linear_ref", "edge_gate", "node_aggregate", "edge_score")
+    for n in names:
+        assert hasattr(torch.ops.gnnome_hip, n)
+    assert "Tensor? bias=None" in str(torch.ops.gnnome_hip.linear.default._schema)
+    # shape inference without a device (what FakeTensor tracing uses)
+    n, e, H = 50, 400, 64
+    m = lambda *s: torch.empty(s, device="meta")  # noqa: E731
+    views = torch.ops.gnnome_hip.build_graph_views(torch.empty(e, dtype=torch.int32, device="meta"), torch.empty(e, dtype=torch.int32, device="meta"), n)
+    assert [tuple(v.shape) for v in views] == [(n + 1,), (e,), (e,), (e,), (n + 1,), (e,), (e,)]
+    assert torch.ops.gnnome_hip.linear(m(n, H), m(5 * H, H), m(5 * H)).shape == (n, 5 * H)
+    assert torch.ops.gnnome_hip.edge_gate(m(e, H), m(n, H), m(n, H), views[1], views[2], m(H, H), m(H), m(H)).shape == (e, H)
+    assert torch.ops.gnnome_hip.edge_score(m(e, H), m(n, 64), m(n, 64), views[1], views[2], views[3], m(64, H), m(32, 64), m(32), m(32), m(1)).shape == (e,)
+    # there is no CPU kernel behind the operators
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.gnnome_hip.linear(torch.zeros(4, 64), torch.zeros(8, 64), None)
+
+
+@pytest.mark.gpu
+def test_operators_run_the_hip_kernels():
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    n, e, H = 300, 2500, 128
+    src, dst = torch.randint(0, n, (e,), generator=g).int(), torch.randint(0, n, (e,), generator=g).int()
+    cv = cpu_ops.CpuViews(src, dst, n)
+    in_ptr, ss, sd, eid, out_ptr, out_pos, out_dst = torch.ops.gnnome_hip.build_graph_views(src.to(dev), dst.to(dev), n)
+    assert torch.equal(eid.cpu(), cv.srt_eid) and torch.equal(out_pos.cpu(), cv.out_pos)
+    h, ee = torch.randn(n, H, generator=g), 3 * torch.randn(e, H, generator=g)
+    Wc, bc = torch.randn(5 * H, H, generator=g) / H ** 0.5, torch.randn(5 * H, generator=g)
+    W3 = torch.randn(H, H, generator=g) / H ** 0.5
+    sc, sh = 0.5 + torch.rand(H, generator=g), torch.randn(H, generator=g)
+    P = torch.ops.gnnome_hip.linear(h.to(dev), Wc.to(dev), bc.to(dev))
+    want_P = cpu_ops.linear(h.double(), Wc.double(), bc.double())
+    assert (P.cpu().double() - want_P).abs().max() < 1e-4
+    A1, A2, A3, B1, B2 = (P[:, i * H:(i + 1) * H] for i in range(5))
+    e_in = ee.to(dev)
+    e_new = torch.ops.gnnome_hip.edge_gate(e_in, B1, B2, ss, sd, W3.to(dev), sc.to(dev), sh.to(dev), 0)
+    assert torch.equal(e_in.cpu(), ee)                       # functional: the input is not modified
+    Pd = P.cpu().double()
+    want_e = cpu_ops.edge_gate(ee.double().clone(), Pd[:, 3 * H:4 * H], Pd[:, 4 * H:], cv, W3.double(), 0, sc.double(), sh.double())
+    assert (e_new.cpu().double() - want_e).abs().max() < 1e-3
+    h_new = torch.ops.gnnome_hip.node_aggregate(e_new, A1, A2, A3, in_ptr, ss, out_ptr, out_pos, out_dst, h.to(dev), sc.to(dev), sh.to(dev), 0)
+    want_h = cpu_ops.node_aggregate(want_e, Pd[:, :H], Pd[:, H:2 * H], Pd[:, 2 * H:3 * H], cv, h.double(), 0, sc.double(), sh.double())
+    assert (h_new.cpu().double() - want_h).abs().max() < 1e-3
