@@ -260,7 +260,9 @@ def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry
     model.to(dev)
     views = ops.GraphViews(g["src"].to(dev), g["dst"].to(dev), n)
     x, ef, y, pw = ops.degree_features(views), g["e"].to(dev), g["y"].to(dev), g["pos_weight"].to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+    # torch.optim.Adam as train.py:259 builds it, in its fused single-kernel form (fused / capturable are implementation
+    # switches of the same update rule; the default foreach form issues ~80 multi-tensor launches per step)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True, fused=True)
     rev, x_rev = views.reversed(), ops.degree_features(views, reverse=True)
 
     def eager_step():
@@ -269,7 +271,7 @@ def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry
             loss = symmetry_loss(logits.squeeze(-1), model(rev, x_rev, ef).squeeze(-1), y, pw, alpha=0.1)
         else:          # train.py:138-145
             loss = bce_loss(logits.squeeze(-1), y, pw)
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad()          # (set_to_none: the backward ASSIGNS the 142 gradients instead of zero-filling and adding)
         loss.backward()
         opt.step()
         return loss.detach()

@@ -519,6 +519,13 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
         // (K = 256: 101 KB of W planes leave one 8-wave workgroup per CU, too few waves to hide the fragment fetches:
         //  1.06 ms against 0.91 ms for the tile kernel at N = 250k, Nout = 1280 - measured, so K = 256 falls through)
     }
+    if (tuning(kTuneLinearVariant) == 4 && ldw % 4 == 0 && Nout % 64 == 0) {   // 4: the default kernel as 8-wave workgroups, two per CU
+        if (K == 128) return launch_linear_bf2<128, 8, 2>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+        if (K == 64) return launch_linear_bf2<64, 8, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+    }
+    if (tuning(kTuneLinearVariant) == 5 && ldw % 4 == 0 && Nout % 64 == 0) {   // 5: 2-wave workgroups, six per CU would need 6 x 52 KB: 3 fit
+        if (K == 128) return launch_linear_bf2<128, 2, 3>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+    }
     if (tuning(kTuneLinearVariant) == 3 && aligned_out && ldw % 4 == 0) {   // 3: bf16x6 with A staged through LDS
         if (K == 128 && Nout % 64 == 0) return launch_linear_bf<128, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
         if (K == 64 && Nout % 64 == 0) return launch_linear_bf<64, 2, 4>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);

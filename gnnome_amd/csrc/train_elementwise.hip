@@ -43,7 +43,7 @@ __device__ __forceinline__ void column_reduce(int64_t rows, int H, float* part, 
     }
 }
 
-// out[a][c] += sum_b part[a][c][b] in a FIXED order: one wave per (a, c) pair, lane l adds b = l, l + 64, ... and
+// out[a][c] = sum_b part[a][c][b] in a FIXED order: one wave per (a, c) pair, lane l adds b = l, l + 64, ... and
 // the 64 lane sums are folded by a butterfly (the same tree on every launch).
 __global__ __launch_bounds__(256) void k_col_finish(const float* __restrict__ part, int nblocks, int H, float* __restrict__ s1,
                                                     float* __restrict__ s2) {
@@ -56,11 +56,11 @@ __global__ __launch_bounds__(256) void k_col_finish(const float* __restrict__ pa
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) {
         float* out = j < H ? s1 : s2;
-        out[j < H ? j : j - H] += s;
+        out[j < H ? j : j - H] = s;
     }
 }
 
-// s1[c] += sum_r x'[r,c];  s2[c] += sum_r x'[r,c] * y'[r,c],  x' = x - center[c] (center NULL: 0), y' likewise when
+// s1[c] = sum_r x'[r,c];  s2[c] = sum_r x'[r,c] * y'[r,c],  x' = x - center[c] (center NULL: 0), y' likewise when
 // y aliases x.  With center = the column mean this is the second pass of a two-pass variance: sum (x-mean)^2 has
 // none of the cancellation of sum x^2 / n - mean^2 (the edge state reaches |e| ~ 500 with a spread of a few units).
 __global__ __launch_bounds__(kEwThreads) void k_colsum2(const float* __restrict__ x, const float* __restrict__ y, int64_t rows,
@@ -420,6 +420,86 @@ extern "C" int gnnome_add_f32(const float* a, const float* b, int64_t count, flo
     if (count == 0) return GNNOME_OK;
     GN_REQUIRE(a && b && out, "add: null pointer");
     hipLaunchKernelGGL(k_add, dim3(ew_grid(count / 4)), dim3(kEwThreads), 0, (hipStream_t)stream, a, b, count / 4, out);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-channel vector work of a train-mode BatchNorm1d in ONE launch (it used to be ~15 [H]-sized torch kernels per call,
+// 16 calls per step): from the shifted column sums of the batch (d1 = sum(x - c), d2 = sum((x - c)^2), c = `center`)
+//   mean = c + d1 / rows,  var = max(d2 / rows - (d1 / rows)^2, 0)                       (biased, what normalises)
+//   rstd = 1 / sqrt(var + eps),  scale = gamma * rstd,  shift = beta - mean * scale       (gated_gcn_full.py:106,119,132)
+// and nn.BatchNorm1d's buffer update, applied `updates` times (bn_e is called twice per layer on identical inputs):
+//   running_mean = (1 - m) running_mean + m mean,  running_var = (1 - m) running_var + m var rows / (rows - 1),
+//   num_batches_tracked += updates.
+namespace gnnome {
+__global__ __launch_bounds__(256) void k_bn_train_finish(const float* __restrict__ d1, const float* __restrict__ d2,
+                                                         const float* __restrict__ center, double rows, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                         int64_t* num_batches_tracked, float momentum, float eps, int updates, int H,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += updates;
+    if (c >= H) return;
+    const float inv = (float)(1.0 / rows);
+    const float m1 = d1[c] * inv;
+    const float mean = (center != nullptr ? center[c] : 0.f) + m1;
+    const float var = fmaxf(d2[c] * inv - m1 * m1, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float scale = gamma[c] * rstd;
+    mean_out[c] = mean;
+    rstd_out[c] = rstd;
+    scale_out[c] = scale;
+    shift_out[c] = beta[c] - mean * scale;
+    if (running_mean != nullptr) {
+        const float unbiased = var * (float)(rows / (rows > 1.0 ? rows - 1.0 : 1.0));
+        float rm = running_mean[c], rv = running_var[c];
+        for (int u = 0; u < updates; ++u) {
+            rm = rm * (1.0f - momentum) + momentum * mean;
+            rv = rv * (1.0f - momentum) + momentum * unbiased;
+        }
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
+}
+
+// Row 0 of the raw gate, x0 = B1h[src_0] + B2h[dst_0] + e[0,:] W3^T: the centre the batch statistics of the gate are
+// shifted by (any row is a sample of the distribution; the unshifted one-pass variance cancels catastrophically here).
+__global__ __launch_bounds__(256) void k_gate_center(const float* __restrict__ e, const float* __restrict__ B1h, const float* __restrict__ B2h,
+                                                     const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst,
+                                                     const float* __restrict__ W3, int ldw, int ldn, int H, float* __restrict__ center) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= H) return;
+    float acc = 0.f;
+    for (int k = 0; k < H; ++k) acc = fmaf(e[k], W3[(int64_t)j * ldw + k], acc);
+    center[j] = B1h[(int64_t)srt_src[0] * ldn + j] + B2h[(int64_t)srt_dst[0] * ldn + j] + acc;
+}
+}  // namespace gnnome
+
+extern "C" int gnnome_bn_train_finish_f32(const float* d1, const float* d2, const float* center, int64_t rows, int hidden,
+                                          const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                          int64_t* num_batches_tracked, float momentum, float eps, int updates, float* mean,
+                                          float* rstd, float* scale, float* shift, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(rows >= 1 && hidden >= 1 && updates >= 0, "bn_train_finish: bad sizes");
+    GN_REQUIRE(d1 && d2 && gamma && beta && mean && rstd && scale && shift, "bn_train_finish: null pointer");
+    GN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_finish: running_mean and running_var go together");
+    hipLaunchKernelGGL(k_bn_train_finish, dim3((hidden + 255) / 256), dim3(256), 0, (hipStream_t)stream, d1, d2, center, (double)rows, gamma,
+                       beta, running_mean, running_var, num_batches_tracked, momentum, eps, updates, hidden, mean, rstd, scale, shift);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_gate_center_f32(const float* e, int64_t num_edges, int hidden, const float* B1h, const float* B2h, int ld_node,
+                                      const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw, float* center,
+                                      void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(num_edges >= 1 && hidden >= 1, "gate_center: needs at least one edge");
+    GN_REQUIRE(e && B1h && B2h && srt_src && srt_dst && W3 && center && ld_node >= hidden && ldw >= hidden, "gate_center: bad arguments");
+    hipLaunchKernelGGL(k_gate_center, dim3((hidden + 255) / 256), dim3(256), 0, (hipStream_t)stream, e, B1h, B2h, srt_src, srt_dst, W3, ldw,
+                       ld_node, hidden, center);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

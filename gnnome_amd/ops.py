@@ -404,7 +404,7 @@ def colsum2(x, y=None, center=None):
     """(sum_r x', sum_r x'*y') per column with x' = x - center; y=None gives the (centred) sum of squares."""
     x = _dense(x, "colsum2.x")
     H = x.shape[1]
-    s = torch.zeros((2, H), dtype=torch.float32, device=x.device)
+    s = (torch.empty if x.shape[0] > 0 else torch.zeros)((2, H), dtype=torch.float32, device=x.device)   # the kernel overwrites both rows
     ws = _col_workspace(x.device)
     _call("gnnome_colsum2_f32", x.device, _ptr(x), _ptr(y), x.shape[0], H, _ptr(center), _ptr(s[0]), _ptr(s[1]), _ptr(ws), ws.numel())
     return s[0], s[1]
@@ -421,6 +421,52 @@ def batch_stats(x):
     return (c + m1).contiguous(), (d2 / rows - m1 * m1).clamp_min_(0.0)
 
 
+def batch_moments(x):
+    """(d1, d2, center, rows): shifted column sums of x[rows,H] - d1 = sum(x - c), d2 = sum((x - c)^2), c = x[0] - in one
+    pass; what bn_train_finish (and batch_stats) turn into mean / variance."""
+    c = x[0]
+    d1, d2 = colsum2(x, center=c)
+    return d1, d2, c, x.shape[0]
+
+
+def edge_gate_raw_moments(e, B1h, B2h, views, W3):
+    """-> (xe, (d1, d2, center, E)): the raw gate and the shifted column sums of its rows, ONE pass over [E,H] (the kernel
+    leaves per-workgroup partial sums, colsum2 adds them up in a fixed order); H in {64,128}, all E rows."""
+    H, E = e.shape[1], e.shape[0]
+    e = _dense(e, "edge_gate_raw_moments.e")
+    B1h, ldn = _rows(B1h, "edge_gate_raw_moments.B1h")
+    B2h, _ = _rows(B2h, "edge_gate_raw_moments.B2h")
+    W3, ldw = _rows(W3, "edge_gate_raw_moments.W3")
+    center = torch.empty(H, dtype=torch.float32, device=e.device)
+    _call("gnnome_gate_center_f32", e.device, _ptr(e), E, H, _ptr(B1h), _ptr(B2h), ldn, _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(W3), ldw,
+          _ptr(center))
+    rows = ctypes.c_int(0)
+    _lib.check(_lib.load().gnnome_edge_gate_raw_stats_rows(H, ctypes.byref(rows)), "edge_gate_raw_stats_rows")
+    partial = torch.empty((rows.value, 2 * H), dtype=torch.float32, device=e.device)
+    out = torch.empty_like(e)
+    _call("gnnome_edge_gate_raw_stats_f32", e.device, _ptr(e), _ptr(out), E, H, _ptr(B1h), _ptr(B2h), ldn, _ptr(views.srt_src),
+          _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(center), _ptr(partial))
+    sums = colsum2(partial)[0]
+    return out, (sums[:H], sums[H:], center, E)
+
+
+def can_fuse_gate_moments(e, B1h, B2h):
+    return (e.shape[1] in (64, 128) and e.shape[0] > 0 and B1h.stride(0) % 4 == 0 and B1h.data_ptr() % 16 == 0 and
+            B2h.data_ptr() % 16 == 0)
+
+
+def bn_train_finish(moments, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, updates):
+    """One launch for the per-channel arithmetic of a train-mode BatchNorm1d call (see gnnome_bn_train_finish_f32):
+    -> (mean, rstd, scale, shift); running_mean / running_var / num_batches_tracked advance in place `updates` times."""
+    d1, d2, center, rows = moments
+    H = d1.numel()
+    mean, rstd, scale, shift = (torch.empty(H, dtype=torch.float32, device=d1.device) for _ in range(4))
+    _call("gnnome_bn_train_finish_f32", d1.device, _ptr(d1), _ptr(d2), _ptr(center), int(rows), H, _ptr(weight), _ptr(bias), _ptr(running_mean),
+          _ptr(running_var), _ptr(num_batches_tracked), float(momentum), float(eps), int(updates), _ptr(mean), _ptr(rstd), _ptr(scale),
+          _ptr(shift))
+    return mean, rstd, scale, shift
+
+
 def bn_relu_res(x, scale, shift, res, out=None):
     x, res = _dense(x, "bn_relu_res.x"), _dense(res, "bn_relu_res.res")
     out = torch.empty_like(x) if out is None else _dense(out, "bn_relu_res.out")
@@ -430,7 +476,7 @@ def bn_relu_res(x, scale, shift, res, out=None):
 
 def bn_bwd_stats(dy, x, scale, shift, mean):
     H = x.shape[1]
-    s = torch.zeros((2, H), dtype=torch.float32, device=x.device)
+    s = (torch.empty if x.shape[0] > 0 else torch.zeros)((2, H), dtype=torch.float32, device=x.device)   # overwritten by the kernel
     ws = _col_workspace(x.device)
     _call("gnnome_bn_bwd_stats_f32", x.device, _ptr(_dense(dy, "dy")), _ptr(_dense(x, "x")), _ptr(scale), _ptr(shift), _ptr(mean),
           x.shape[0], H, _ptr(s[0]), _ptr(s[1]), _ptr(ws), ws.numel())
@@ -459,7 +505,7 @@ def ln_bwd(dy, x, gamma, beta, out=None):
     dy, x = _dense(dy, "ln_bwd.dy"), _dense(x, "ln_bwd.x")
     H = x.shape[1]
     dx = torch.empty_like(x) if out is None else _dense(out, "ln_bwd.out")
-    s = torch.zeros((2, H), dtype=torch.float32, device=x.device)
+    s = (torch.empty if x.shape[0] > 0 else torch.zeros)((2, H), dtype=torch.float32, device=x.device)
     ws = _col_workspace(x.device)
     _call("gnnome_ln_bwd_f32", x.device, _ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), x.shape[0], H, _ptr(dx), _ptr(s[0]), _ptr(s[1]),
           _ptr(ws), ws.numel())

@@ -94,6 +94,17 @@ def _bn_train(sh, bn, mean, var, n_local, rows, updates):
     return mean.contiguous(), rstd.contiguous(), scale.contiguous(), shift.contiguous()
 
 
+def _bn_train_fused(sh, bn, moments, updates):
+    """The single-rank case in one launch (gnnome_bn_train_finish_f32): no per-channel torch arithmetic, no host work."""
+    track = bn.track_running_stats
+    return sh.ops.bn_train_finish(moments, bn.weight.detach(), bn.bias.detach(), bn.running_mean if track else None,
+                                  bn.running_var if track else None, bn.num_batches_tracked if track else None, bn.momentum, bn.eps, updates)
+
+
+def _can_fuse_bn(sh, bn):
+    return sh.world == 1 and bn.momentum is not None and hasattr(sh.ops, "bn_train_finish")
+
+
 def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out):
     """out <- d(input of bn); returns this rank's share of (d gamma, d beta), for out = relu(x*scale + shift) + res with
     scale = gamma*rstd.  `rows` = rows of the whole graph.  dy may hold PARTIAL gradients of rows that are replicated
@@ -142,8 +153,12 @@ class _TrainStep(torch.autograd.Function):
                 xe = ops.edge_gate_raw(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight))
                 e_new = ops.ln_relu_res(xe, d(conv.bn_e.weight), d(conv.bn_e.bias), e)
             else:
-                xe, m_e, v_e = ops.edge_gate_raw_stats(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight), rows_stats=e_own)
-                mean_e, rstd_e, sc_e, sh_e = _bn_train(sh, conv.bn_e, m_e, v_e, e_own, sh.e_global, updates=2)
+                if _can_fuse_bn(sh, conv.bn_e) and ops.can_fuse_gate_moments(e, blk(P, "B1"), blk(P, "B2")):
+                    xe, mom = ops.edge_gate_raw_moments(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight))
+                    mean_e, rstd_e, sc_e, sh_e = _bn_train_fused(sh, conv.bn_e, mom, updates=2)
+                else:
+                    xe, m_e, v_e = ops.edge_gate_raw_stats(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight), rows_stats=e_own)
+                    mean_e, rstd_e, sc_e, sh_e = _bn_train(sh, conv.bn_e, m_e, v_e, e_own, sh.e_global, updates=2)
                 e_new = ops.bn_relu_res(xe, sc_e, sh_e, e)
             v, hf, rdf, hb, rdb = ops.node_aggregate_raw(e_new, blk(P, "A1"), blk(P, "A2"), blk(P, "A3"), views, 1, n_own,
                                                          rows_alloc=n_local)
@@ -151,8 +166,11 @@ class _TrainStep(torch.autograd.Function):
             if layer_norm:
                 ops.ln_relu_res(v[:n_own], d(conv.bn_h.weight), d(conv.bn_h.bias), h[:n_own], out=h_next[:n_own])
             else:
-                m_h, v_h = ops.batch_stats(v[:n_own])
-                mean_h, rstd_h, sc_h, sh_h = _bn_train(sh, conv.bn_h, m_h, v_h, n_own, sh.n_global, updates=1)
+                if _can_fuse_bn(sh, conv.bn_h):
+                    mean_h, rstd_h, sc_h, sh_h = _bn_train_fused(sh, conv.bn_h, ops.batch_moments(v[:n_own]), updates=1)
+                else:
+                    m_h, v_h = ops.batch_stats(v[:n_own])
+                    mean_h, rstd_h, sc_h, sh_h = _bn_train(sh, conv.bn_h, m_h, v_h, n_own, sh.n_global, updates=1)
                 ops.bn_relu_res(v[:n_own], sc_h, sh_h, h[:n_own], out=h_next[:n_own])
             mask = None
             if conv.dropout > 0.0:

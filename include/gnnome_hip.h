@@ -214,8 +214,8 @@ int gnnome_node_aggregate_raw_f32(const float* e, int hidden, int64_t num_nodes,
                                   const int32_t* out_dst, float* v_out, float* aux0, float* aux1, float* aux2,
                                   float* aux3, void* stream);
 
-/* s1[c] += sum_r x'[r,c];  s2[c] += sum_r x'[r,c]*y'[r,c]  with x' = x - center[c] (center NULL: 0) and y NULL -> x'
- * (sum of squares).  s1/s2 must be zeroed by the caller.  hidden in {16,32,64,128,256}.  Two calls give train-mode
+/* s1[c] = sum_r x'[r,c];  s2[c] = sum_r x'[r,c]*y'[r,c]  with x' = x - center[c] (center NULL: 0) and y NULL -> x'
+ * (sum of squares).  s1/s2 are overwritten (rows = 0: left untouched).  hidden in {16,32,64,128,256}.  Two calls give train-mode
  * BatchNorm its batch statistics (gated_gcn_full.py:106,119,132): the mean, then the centred second moment - the
  * one-pass E[x^2]-E[x]^2 form cancels badly on this path (|e| ~ 500, spread of a few units).  Also bias gradients.
  * The sum over workgroups is deterministic (partials parked in `workspace`, added up in workgroup order by a second
@@ -230,7 +230,7 @@ int gnnome_bn_relu_res_f32(const float* x, const float* scale, const float* shif
                            int hidden, float* out, void* stream);
 
 /* BatchNorm backward through the relu of out = relu(x*scale + shift) + res, m = (x*scale + shift > 0):
- *   stats: s1[c] += sum_r dy*m,  s2[c] += sum_r dy*m*(x - mean[c])   (s1/s2 zeroed by the caller)
+ *   stats: s1[c] = sum_r dy*m,  s2[c] = sum_r dy*m*(x - mean[c])   (overwritten)
  *   apply: dx = a[c] * (dy*m - c1[c] - (x - mean[c])*rstd[c]*c2[c]) */
 int gnnome_bn_bwd_stats_f32(const float* dy, const float* x, const float* scale, const float* shift,
                             const float* mean, int64_t rows, int hidden, float* s1, float* s2, void* workspace,
@@ -242,7 +242,7 @@ int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const float* scale,
 /* LayerNorm variant (normalization='layer', gated_gcn_full.py:40-42,106,119,132) of the two groups above:
  *   out = relu(LN(x) * gamma + beta) + res, LN over the `hidden` entries of each row (biased variance, eps 1e-5);
  *   backward: dx = rstd_row (g - mean_row(g) - xhat mean_row(g xhat)) with g = dy m gamma, m the relu mask;
- *   dbeta[c] += sum_r dy m, dgamma[c] += sum_r dy m xhat (deterministic; zeroed by the caller; workspace as colsum2). */
+ *   dbeta[c] = sum_r dy m, dgamma[c] = sum_r dy m xhat (deterministic; overwritten; workspace as colsum2). */
 int gnnome_ln_relu_res_f32(const float* x, const float* gamma, const float* beta, const float* res, int64_t rows, int hidden,
                            float* out, void* stream);
 int gnnome_ln_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, int64_t rows, int hidden, float* dx,
@@ -320,6 +320,19 @@ int gnnome_edge_features_f32(const float* overlap_length, const float* overlap_s
 int gnnome_edge_loss_f32(const float* logits, const float* logits_rev, const float* labels, int64_t num_edges,
                          const float* pos_weight, float alpha, float grad_scale, float* loss, float* dlogits,
                          float* dlogits_rev, int64_t* tfpn, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The per-channel arithmetic of a train-mode BatchNorm1d call in one launch (gated_gcn_full.py:106,119,132 with
+ * nn.BatchNorm1d's buffer semantics): from shifted column sums d1 = sum(x - center), d2 = sum((x - center)^2) over `rows`
+ * rows -> mean, rstd = 1/sqrt(biased var + eps), scale = gamma*rstd, shift = beta - mean*scale, and `updates` momentum
+ * updates of running_mean / running_var (unbiased variance) + num_batches_tracked += updates.  center, running_* and
+ * num_batches_tracked may be NULL. */
+int gnnome_bn_train_finish_f32(const float* d1, const float* d2, const float* center, int64_t rows, int hidden, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float momentum, float eps, int updates, float* mean, float* rstd, float* scale, float* shift,
+                               void* stream);
+/* center[:] = B1h[srt_src[0],:] + B2h[srt_dst[0],:] + e[0,:] W3^T: row 0 of the raw gate, the shift of its batch statistics. */
+int gnnome_gate_center_f32(const float* e, int64_t num_edges, int hidden, const float* B1h, const float* B2h, int ld_node,
+                           const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw, float* center, void* stream);
 
 /* ---- greedy decode of the edge scores into contig walks -----------------------------
  * What inference.py:70-165 (greedy_forwards, greedy_backwards_rc, run_greedy_both_ways) and :29-36 (get_contig_length)

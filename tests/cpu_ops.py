@@ -188,6 +188,37 @@ def batch_stats(x):
     return x.mean(0), x.var(0, unbiased=False)
 
 
+def batch_moments(x):
+    c = x[0]
+    return (x - c).sum(0), ((x - c) ** 2).sum(0), c, x.shape[0]
+
+
+def edge_gate_raw_moments(e, B1h, B2h, views, W3):
+    xe = edge_gate_raw(e, B1h, B2h, views, W3)
+    return xe, batch_moments(xe)
+
+
+def can_fuse_gate_moments(e, B1h, B2h):
+    return e.shape[0] > 0
+
+
+def bn_train_finish(moments, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, updates):
+    d1, d2, c, rows = moments
+    m1 = d1 / rows
+    mean, var = c + m1, (d2 / rows - m1 * m1).clamp_min(0.0)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    scale = weight * rstd
+    shift = bias - mean * scale
+    if running_mean is not None:
+        unbiased = var * (rows / max(rows - 1, 1))
+        for _ in range(updates):
+            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1 - momentum).add_(unbiased, alpha=momentum)
+    if num_batches_tracked is not None:
+        num_batches_tracked += updates
+    return mean, rstd, scale, shift
+
+
 def bn_relu_res(x, scale, shift, res, out=None):
     y = torch.relu(x * scale + shift) + res
     if out is None:
