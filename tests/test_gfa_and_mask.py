@@ -141,3 +141,61 @@ def test_cluster_partition_with_halo():
     loss = bce_loss(logits.squeeze(-1), gr["y"].to(dev())[sub.eid], gr["pos_weight"].to(dev()))
     loss.backward()
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def _layout_gfa(path, reads, seed):
+    """A genome laid out left to right: read r starts at r * step (+ jitter) and overlaps the next few reads; every link is
+    written once (the parser adds the reverse-complement mate); similarities ride on SI:f: tags.  No sequences (hifiasm
+    'noseq' style)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    start = np.cumsum(rng.integers(2000, 4000, size=reads))
+    length = rng.integers(9000, 15000, size=reads)
+    with open(path, "w") as f:
+        for r in range(reads):
+            f.write(f"S\tread{r}\t*\tLN:i:{length[r]}\n")
+        for r in range(reads):
+            for t in range(r + 1, reads):
+                ol = start[r] + length[r] - start[t]
+                if ol <= 500:
+                    break
+                if start[t] + length[t] <= start[r] + length[r]:
+                    continue   # contained read: no dovetail overlap
+                f.write(f"L\tread{r}\t+\tread{t}\t+\t{int(ol)}M\tSI:f:{1.0 - 0.002 * rng.random():.6f}\n")
+    return start, length
+
+
+@pytest.mark.gpu
+def test_pipeline_from_gfa_to_contigs(tmp_path, shipped_weights):
+    """inference.py:411-467 end to end on the device: GFA -> features -> SymGatedGCN (shipped weights) -> greedy decode.
+    With scores that favour the true layout edges (the role of decode_with_labels, hyperparameters.py:49) the decoder must
+    return the layout as ONE walk of consecutive reads; with the model's own scores the walks must be valid contigs."""
+    import gnnome_amd
+    from gnnome_amd import pipeline
+    reads = 400
+    path = tmp_path / "layout.gfa"
+    start, length = _layout_gfa(path, reads, seed=3)
+    m = gnnome_amd.SymGatedGCNModel(2, 2, 64, 16, 8, 64, "batch").eval()
+    m.load_state_dict(shipped_weights)
+    torch.manual_seed(1)
+    walks, scores, g = pipeline.assemble(str(path), m, len_threshold=20_000, nb_paths=20, device=dev())
+    assert scores.shape == (g["src"].numel(),) and torch.isfinite(scores).all() and len(walks) >= 1
+    pairs = set(zip(g["src"].tolist(), g["dst"].tolist()))
+    seen = set()
+    for w in walks:
+        assert all((a, b) in pairs for a, b in zip(w[:-1], w[1:]))
+        rd = {v >> 1 for v in w}
+        assert len(rd) == len(w) and not (rd & seen)
+        seen |= rd
+    # oracle scores: the shorter the hop along the layout the better (+8 for the next read, falling off), for both strands
+    src, dst = g["src"], g["dst"]
+    hop = torch.where(src % 2 == 0, (dst - src) // 2, (src - dst) // 2).float()
+    ideal = 10.0 - 2.0 * hop
+    torch.manual_seed(1)
+    walks2, _, _ = pipeline.assemble(g, None, len_threshold=20_000, nb_paths=20, device=dev(), scores=ideal)
+    best = max(walks2, key=len)
+    reads_in_order = [v >> 1 for v in best]
+    sign = 1 if reads_in_order[1] > reads_in_order[0] else -1
+    assert all((b - a) * sign > 0 for a, b in zip(reads_in_order[:-1], reads_in_order[1:]))       # monotone along the genome
+    assert (max(reads_in_order) - min(reads_in_order)) >= 0.9 * reads                             # the whole layout as one contig
+    assert len(best) >= 0.6 * reads                                    # (reads contained in a neighbour are jumped over)
