@@ -23,7 +23,16 @@ struct GateEnc {
     const float *W1, *b1, *W2, *b2;   // [16,2] [16] [H,16] [H]
 };
 
-// Arguments of the bf16x6 edge-tile kernel (edge_gate_bf.hip); mode 0 gate, 1 raw gate + statistics, 2 C += A W^T.
+// Mode 3 of the edge-tile kernel: the A operand is not read but COMPUTED by the load waves from two streams,
+// A = a[c] * (dy m - c1[c] - (x - mean[c]) rstd[c] c2[c]),  m = (x scale[c] + shift[c] > 0)   (BatchNorm backward through the relu),
+// with dy = the old rows of C and x = the rows at e_in; A is also written to `a_out`.  One pass does what
+// gnnome_bn_bwd_apply_f32 + gnnome_linear_acc_f32 did in two (train.py: dxe, then d e_in = d e' + dxe W3).
+struct GateBnBwd {
+    const float *a, *c1, *c2, *mean, *rstd, *scale, *shift;   // [H] each
+    float* a_out;                                              // [E,H]
+};
+
+// Arguments of the bf16x6 edge-tile kernel (edge_gate_bf.hip); mode 0 gate, 1 raw gate + statistics, 2 C += A W^T, 3 see GateBnBwd.
 struct GateBfArgs {
     const float* e_in;        // A operand rows [E,H] (mode 2: A); unused with enc
     float* e_out;             // result rows [E,H] (may alias e_in; mode 2: C)
@@ -43,6 +52,7 @@ struct GateBfArgs {
     long long* prof;          // measurement only: per-workgroup phase cycle counters [gridDim][8] (NULL in normal use)
     int xp;                   // experiment knob (key 4): producers' poll interval 0..3 = s_sleep 1/4/16/64
     GateEnc enc;              // mode 0 with the folded edge encoder
+    GateBnBwd bnb;            // mode 3
 };
 int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& args, hipStream_t s);
 // H = 256, affine norm, e_out != e_in: barrier-free streaming gate (edge_gate_stream.hip)

@@ -88,6 +88,7 @@ __device__ __forceinline__ bf16x8 as_bf(const uint4 v) { return __builtin_bit_ca
 // MODE 0: y = relu((acc + G) * scale + shift) + e      (the gate, gated_gcn_full.py:97,104-110)
 // MODE 1: y = acc + G, G = B1h[src] + B2h[dst]          (raw gate of the training step) + shifted column sums (scale = centre)
 // MODE 2: y = acc + G, G = the old rows of C (in B1h)   (C += A W^T: the backward's d e_in = d e' + dxe W3)
+// MODE 3: MODE 2 with A = BatchNorm-backward(old rows of C, rows at e_in) computed by the load waves and written to bnb.a_out
 template <int CB, int RB, int MODE, bool ENC>
 __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
     using P = GateBF<CB, RB>;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {   // rows past the end of the list read the last valid row (never stored)
                 const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
-                if (MODE != 2) {
+                if (MODE < 2) {
                     si[p] = a.srt_src[row];
                     di[p] = a.srt_dst[row];
                 }
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
                     raw1[p] = a.enc.e_raw[2 * (int64_t)ei[p] + 1];
                 }
                 if (a.abl & 1) {
-                } else if (MODE == 2) {
+                } else if (MODE >= 2) {
                     const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
                     g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * a.ldn + 4 * c4);   // the old rows of C
                 } else {
@@ -294,10 +295,30 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
         float* Gs = Gring + group * SLOT;
         for (int r = group; r < n; r += RING) {
             // the slot is free: this group stored its previous tile itself (below)
+            if (MODE == 3) {
+                // A = BatchNorm backward of (dy = g1, x = av) for this lane's four columns; written out as dxe on the way
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(a.bnb.a + 4 * c4), k1 = *reinterpret_cast<const f32x4*>(a.bnb.c1 + 4 * c4);
+                const f32x4 k2 = *reinterpret_cast<const f32x4*>(a.bnb.c2 + 4 * c4), km = *reinterpret_cast<const f32x4*>(a.bnb.mean + 4 * c4);
+                const f32x4 kr = *reinterpret_cast<const f32x4*>(a.bnb.rstd + 4 * c4), ks = *reinterpret_cast<const f32x4*>(a.bnb.scale + 4 * c4);
+                const f32x4 kh = *reinterpret_cast<const f32x4*>(a.bnb.shift + 4 * c4);
+                const int valid3 = tile_valid(r);
+                float* aout = a.bnb.a_out + (int64_t)tile_of(r) * TM * H;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    f32x4 t;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gm = (av[p][j] * ks[j] + kh[j] > 0.f) ? g1[p][j] : 0.f;
+                        t[j] = ka[j] * (gm - k1[j] - (av[p][j] - km[j]) * kr[j] * k2[j]);
+                    }
+                    av[p] = t;
+                    if (r0 + p * RSTEP < valid3) *reinterpret_cast<f32x4*>(aout + (off_row + (unsigned)(p * RSTEP * H))) = t;
+                }
+            }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 *reinterpret_cast<f32x4*>(As + (r0 + p * RSTEP) * LDK + 4 * c4) = av[p];
-                *reinterpret_cast<f32x4*>(Gs + (r0 + p * RSTEP) * LDK + 4 * c4) = MODE == 2 ? g1[p] : g1[p] + g2[p];
+                *reinterpret_cast<f32x4*>(Gs + (r0 + p * RSTEP) * LDK + 4 * c4) = MODE >= 2 ? g1[p] : g1[p] + g2[p];
             }
             flag_bump_bf(full0 + 4 * group, lane);
             if (r + RING < n) issue_early(r + RING);
@@ -306,7 +327,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
             const int valid = tile_valid(r);
             // (re-read per tile, L1-resident: eight registers fewer across the fetch phase)
             f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-            if (MODE != 2) sc4 = *reinterpret_cast<const f32x4*>(a.scale + 4 * c4);   // MODE 1: the columns' centres
+            if (MODE < 2) sc4 = *reinterpret_cast<const f32x4*>(a.scale + 4 * c4);   // MODE 1: the columns' centres
             if (MODE == 0) sh4 = *reinterpret_cast<const f32x4*>(a.shift + 4 * c4);
             float* out = a.e_out + (int64_t)tile_of(r) * TM * H;   // uniform; the lane's part is off_row + p * const
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -387,9 +408,11 @@ static int launch_bf(const GateBfArgs& args, hipStream_t s) {
 int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStream_t s) {
     if (hidden == 128) {
         if (mode == 0) return enc ? launch_bf<4, 1, 0, true>(a, s) : launch_bf<4, 1, 0, false>(a, s);
+        if (mode == 3) return launch_bf<4, 1, 3, false>(a, s);
         return mode == 1 ? launch_bf<4, 1, 1, false>(a, s) : launch_bf<4, 1, 2, false>(a, s);
     }
     if (mode == 0) return enc ? launch_bf<2, 2, 0, true>(a, s) : launch_bf<2, 2, 0, false>(a, s);
+    if (mode == 3) return launch_bf<2, 2, 3, false>(a, s);
     return mode == 1 ? launch_bf<2, 2, 1, false>(a, s) : launch_bf<2, 2, 2, false>(a, s);
 }
 
@@ -398,4 +421,22 @@ int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStrea
 extern "C" int gnnome_debug_gate_profile(void* counters) {
     gnnome::g_gate_prof = (long long*)counters;
     return GNNOME_OK;
+}
+
+// C[M,H] += BatchNormBackward(C, X) W^T and dxe = BatchNormBackward(C, X) written out: gnnome_bn_bwd_apply_f32 followed by
+// gnnome_linear_acc_f32 in ONE pass over the [E,H] tensors (the A tile never comes from HBM: the load waves compute it).
+extern "C" int gnnome_bn_bwd_dgrad_f32(float* C, const float* X, int64_t rows, int hidden, const float* scale, const float* shift,
+                                       const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
+                                       const float* W, int ldw, float* dxe, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(rows >= 0 && (hidden == 64 || hidden == 128), "bn_bwd_dgrad: hidden=%d not in {64,128}", hidden);
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(C && X && scale && shift && a && c1 && c2 && mean && rstd && W && dxe && dxe != C && ldw >= hidden && ldw % 4 == 0,
+               "bn_bwd_dgrad: bad arguments");
+    GN_REQUIRE(((uintptr_t)C % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)dxe % 16 == 0) && ((uintptr_t)W % 16 == 0),
+               "bn_bwd_dgrad: tensors must be 16-byte aligned");
+    GateBfArgs g = {};
+    g.e_in = X; g.e_out = C; g.E = rows; g.B1h = C; g.ldn = hidden; g.W3 = W; g.ldw = ldw;
+    g.bnb = GateBnBwd{a, c1, c2, mean, rstd, scale, shift, dxe};
+    return gate_bf_launch(hidden, 3, false, g, (hipStream_t)stream);
 }

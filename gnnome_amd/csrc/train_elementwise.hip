@@ -503,3 +503,67 @@ extern "C" int gnnome_gate_center_f32(const float* e, int64_t num_edges, int hid
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-edge gradient of both gated aggregations (gnnome_agg_edge_bwd_f32, train_gemm.hip) WITH the BatchNorm-backward
+// statistics of the result gathered in the same pass: de' = de + s(1-s)(...) is final for this layer's e' once this kernel
+// has added its term, and bn_e's backward needs  s1 = sum_p de' m,  s2 = sum_p de' m (xe - mean)  over exactly these rows
+// (m = relu mask rebuilt from the forward's expression).  One read of xe here replaces gnnome_bn_bwd_stats_f32's reads of de'
+// and xe.
+namespace gnnome {
+template <int H>
+__global__ __launch_bounds__(kEwThreads) void k_agg_edge_bwd_stats(const float* __restrict__ e, int64_t E, const float* __restrict__ Tf,
+                                                                   const float* __restrict__ Uf, const float* __restrict__ Tb,
+                                                                   const float* __restrict__ Ub, const float* __restrict__ A2h,
+                                                                   const float* __restrict__ A3h, int ldn,
+                                                                   const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst,
+                                                                   float* __restrict__ de, const float* __restrict__ xe,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   const float* __restrict__ mean, float* __restrict__ part) {
+    column_reduce<2>(E, H, part, [&](int64_t p, int c, f32x4 (&acc)[2]) {
+        const int64_t s_ = srt_src[p], d_ = srt_dst[p];
+        const f32x4 x = *reinterpret_cast<const f32x4*>(e + p * H + c);
+        const f32x4 tf = *reinterpret_cast<const f32x4*>(Tf + d_ * H + c), uf = *reinterpret_cast<const f32x4*>(Uf + d_ * H + c);
+        const f32x4 tb = *reinterpret_cast<const f32x4*>(Tb + s_ * H + c), ub = *reinterpret_cast<const f32x4*>(Ub + s_ * H + c);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(A2h + s_ * ldn + c), a3 = *reinterpret_cast<const f32x4*>(A3h + d_ * ldn + c);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xe + p * H + c);
+        f32x4 g = *reinterpret_cast<const f32x4*>(de + p * H + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sg = sigmoidf_(x[j]);
+            g[j] += sg * (1.f - sg) * (tf[j] * a2[j] - uf[j] + tb[j] * a3[j] - ub[j]);
+            const float gm = (xv[j] * scale[c + j] + shift[c + j] > 0.f) ? g[j] : 0.f;
+            acc[0][j] += gm;
+            acc[1][j] += gm * (xv[j] - mean[c + j]);
+        }
+        *reinterpret_cast<f32x4*>(de + p * H + c) = g;
+    });
+}
+}  // namespace gnnome
+
+extern "C" int gnnome_agg_edge_bwd_stats_f32(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                                             const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
+                                             const int32_t* srt_src, const int32_t* srt_dst, float* de, const float* xe,
+                                             const float* scale, const float* shift, const float* mean, float* s1, float* s2,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(num_edges >= 0, "agg_edge_bwd_stats: negative edge count");
+    if (num_edges == 0) return GNNOME_OK;
+    GN_REQUIRE(e && Tf && Uf && Tb && Ub && A2h && A3h && srt_src && srt_dst && de && xe && scale && shift && mean && s1 && s2 && ld_node % 4 == 0,
+               "agg_edge_bwd_stats: bad arguments");
+    GN_REQUIRE(workspace && workspace_bytes >= kColWorkspaceBytes && (uintptr_t)workspace % 16 == 0,
+               "agg_edge_bwd_stats: workspace too small or misaligned (gnnome_colsum_workspace_bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = col_grid(num_edges, hidden);
+    switch (hidden) {
+        case 64: hipLaunchKernelGGL(k_agg_edge_bwd_stats<64>, dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace); break;
+        case 128: hipLaunchKernelGGL(k_agg_edge_bwd_stats<128>, dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace); break;
+        case 256: hipLaunchKernelGGL(k_agg_edge_bwd_stats<256>, dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace); break;
+        default: set_error("agg_edge_bwd_stats: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
+    }
+    GN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, s, (const float*)workspace, (int)grid, hidden, s1, s2);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}

@@ -573,6 +573,34 @@ def agg_edge_bwd(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de):
     return de
 
 
+def can_fuse_bn_bwd_dgrad(de, W):
+    return de.shape[1] in (64, 128) and de.shape[0] > 0 and de.is_contiguous() and W.stride(0) % 4 == 0
+
+
+def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt):
+    """dxe = BatchNorm-backward(de, xe) (as bn_bwd_apply) and de += dxe @ Wt.T in ONE pass (gnnome_bn_bwd_dgrad_f32): the
+    edge-tile kernel's load waves compute the A tile instead of reading it.  Returns dxe; de is updated in place."""
+    de, xe = _dense(de, "bn_bwd_dgrad.de"), _dense(xe, "bn_bwd_dgrad.xe")
+    Wt, ldw = _rows(Wt, "bn_bwd_dgrad.W")
+    dxe = torch.empty_like(de)
+    _call("gnnome_bn_bwd_dgrad_f32", de.device, _ptr(de), _ptr(xe), de.shape[0], de.shape[1], _ptr(scale), _ptr(shift), _ptr(a), _ptr(c1),
+          _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))
+    return dxe
+
+
+def agg_edge_bwd_stats(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift, mean):
+    """agg_edge_bwd + the BatchNorm-backward statistics (s1, s2) of the updated de in one pass (see the header)."""
+    A2h, ldn = _rows(A2h, "agg_edge_bwd_stats.A2h")
+    A3h, _ = _rows(A3h, "agg_edge_bwd_stats.A3h")
+    H = e.shape[1]
+    s = (torch.empty if e.shape[0] > 0 else torch.zeros)((2, H), dtype=torch.float32, device=e.device)
+    ws = _col_workspace(e.device)
+    _call("gnnome_agg_edge_bwd_stats_f32", e.device, _ptr(_dense(e, "e")), e.shape[0], H, _ptr(Tf), _ptr(Uf), _ptr(Tb), _ptr(Ub), _ptr(A2h),
+          _ptr(A3h), ldn, _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(_dense(de, "de")), _ptr(_dense(xe, "xe")), _ptr(scale), _ptr(shift),
+          _ptr(mean), _ptr(s[0]), _ptr(s[1]), _ptr(ws), ws.numel())
+    return de, s[0], s[1]
+
+
 def encode_hidden(x, W1, b1, gather=None, rows=None):
     x = x.contiguous()
     rows = int(x.shape[0] if rows is None else rows)

@@ -105,16 +105,18 @@ def _can_fuse_bn(sh, bn):
     return sh.world == 1 and bn.momentum is not None and hasattr(sh.ops, "bn_train_finish")
 
 
-def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out):
+def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out, stats=None, apply=True):
     """out <- d(input of bn); returns this rank's share of (d gamma, d beta), for out = relu(x*scale + shift) + res with
     scale = gamma*rstd.  `rows` = rows of the whole graph.  dy may hold PARTIAL gradients of rows that are replicated
     on another rank (cut edges): the per-channel sums run over all local rows - summed over ranks they are the true
     totals - while the mean-subtraction terms, which must enter once per row of the whole graph, are applied to the
     first n_once rows only (the owned ones)."""
     ops = sh.ops
-    s1, s2 = ops.bn_bwd_stats(dy, x, scale, shift, mean)
+    s1, s2 = ops.bn_bwd_stats(dy, x, scale, shift, mean) if stats is None else stats   # (stats: gathered by the producer of dy)
     s2h = rstd * s2                                     # sum dy*m*xhat
     t1, t2 = sh.sum_ranks([s1, s2h])
+    if not apply:   # the caller fuses the apply pass into its consumer (ops.bn_bwd_dgrad): hand back the two mean terms
+        return s2h, s1, (t1 / rows).contiguous(), (t2 / rows).contiguous()
     ops.bn_bwd_apply(dy[:n_once], x[:n_once], scale, shift, scale, (t1 / rows).contiguous(), (t2 / rows).contiguous(), mean, rstd,
                      out=out[:n_once])
     if n_once < x.shape[0]:
@@ -262,16 +264,33 @@ class _TrainStep(torch.autograd.Function):
             Tf, Uf = ops.mul23(dv, s["rdf"], s["hf"])
             Tb, Ub = ops.mul23(dv, s["rdb"], s["hb"])
             sum_in, sum_out = ops.node_aggregate_raw(s["e_new"], None, Tb, Tf, views, 2, n_local)   # = dA3(role), dA2(role)
-            ops.agg_edge_bwd(s["e_new"], Tf, Uf, Tb, Ub, blk(s["P"], "A2"), blk(s["P"], "A3"), views, de)  # de += ...
+            stats_e = None
+            if s["sc_e"] is not None and hasattr(ops, "agg_edge_bwd_stats"):
+                # de += ... and bn_e's backward statistics of the result in the same pass over the edges
+                _, s1_e, s2_e = ops.agg_edge_bwd_stats(s["e_new"], Tf, Uf, Tb, Ub, blk(s["P"], "A2"), blk(s["P"], "A3"), views, de, s["xe"],
+                                                       s["sc_e"], s["sh_e"], s["mean_e"])
+                stats_e = (s1_e, s2_e)
+            else:
+                ops.agg_edge_bwd(s["e_new"], Tf, Uf, Tb, Ub, blk(s["P"], "A2"), blk(s["P"], "A3"), views, de)  # de += ...
             # e' = relu(bn_e(xe)) + e_in ;  xe = B1h[src] + B2h[dst] + e_in W3^T
-            dxe = torch.empty_like(de)
             if s["sc_e"] is None:
+                dxe = torch.empty_like(de)
                 _, g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = ops.ln_bwd(de, s["xe"], d(conv.bn_e.weight), d(conv.bn_e.bias), out=dxe)
             else:
-                g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
-                                                                       sh.e_global, e_own, dxe)
+                W3t = d(conv.B_3.weight).t().contiguous()
+                if e_own == e_local and hasattr(ops, "bn_bwd_dgrad") and ops.can_fuse_bn_bwd_dgrad(de, W3t):
+                    # BatchNorm backward and d e_in = d e' + dxe W3 in one pass over the edges (dxe computed by the load waves)
+                    g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"], c1, c2 = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
+                                                                                   sh.e_global, e_own, None, stats=stats_e, apply=False)
+                    dxe = ops.bn_bwd_dgrad(de, s["xe"], s["sc_e"], s["sh_e"], s["sc_e"], c1, c2, s["mean_e"], s["rstd_e"], W3t)
+                    W3t = None
+                else:
+                    dxe = torch.empty_like(de)
+                    g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
+                                                                           sh.e_global, e_own, dxe, stats=stats_e)
             g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"])
-            ops.linear(dxe, d(conv.B_3.weight).t().contiguous(), None, out=de, accumulate=True)   # d e_in = d e' + dxe W3
+            if s["sc_e"] is None or W3t is not None:
+                ops.linear(dxe, d(conv.B_3.weight).t().contiguous(), None, out=de, accumulate=True)   # d e_in = d e' + dxe W3
             dB1 = ops.segment_sum(dxe, views.out_ptr, views.out_pos, n_local)
             dB2 = ops.segment_sum(dxe, views.in_ptr, None, n_local)
             parts = [None] * 5

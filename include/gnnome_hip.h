@@ -321,6 +321,23 @@ int gnnome_edge_loss_f32(const float* logits, const float* logits_rev, const flo
                          const float* pos_weight, float alpha, float grad_scale, float* loss, float* dlogits,
                          float* dlogits_rev, int64_t* tfpn, void* workspace, size_t workspace_bytes, void* stream);
 
+/* gnnome_bn_bwd_apply_f32 followed by gnnome_linear_acc_f32 in one pass over the [rows,hidden] tensors (hidden in {64,128}):
+ *   dxe[r,:] = a (C[r,:] m - c1 - (X[r,:] - mean) rstd c2),  m = (X scale + shift > 0)        (written out)
+ *   C[r,:]  += dxe[r,:] * W^T                                                                  (in place)
+ * i.e. train.py's  dxe = bn_e backward(de, xe);  d e_in = d e' + dxe W3  with C = de, X = xe, W = W3^T. */
+int gnnome_bn_bwd_dgrad_f32(float* C, const float* X, int64_t rows, int hidden, const float* scale, const float* shift,
+                            const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
+                            const float* W, int ldw, float* dxe, void* stream);
+
+/* gnnome_agg_edge_bwd_f32 with the BatchNorm-backward statistics of its result gathered in the same pass:
+ *   de[p,:] += s(1-s)(...)   as above, then   s1[c] = sum_p de[p,c] m,  s2[c] = sum_p de[p,c] m (xe[p,c] - mean[c]),
+ *   m = (xe*scale + shift > 0): what gnnome_bn_bwd_stats_f32(de, xe, ...) would return, without its pass over de and xe. */
+int gnnome_agg_edge_bwd_stats_f32(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                                  const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
+                                  const int32_t* srt_src, const int32_t* srt_dst, float* de, const float* xe, const float* scale,
+                                  const float* shift, const float* mean, float* s1, float* s2, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* The per-channel arithmetic of a train-mode BatchNorm1d call in one launch (gated_gcn_full.py:106,119,132 with
  * nn.BatchNorm1d's buffer semantics): from shifted column sums d1 = sum(x - center), d2 = sum((x - center)^2) over `rows`
  * rows -> mean, rstd = 1/sqrt(biased var + eps), scale = gamma*rstd, shift = beta - mean*scale, and `updates` momentum

@@ -322,3 +322,19 @@ def encode_hidden(x, W1, b1, gather=None, rows=None):
     if gather is not None:
         x = x[gather.long()]
     return torch.relu(x @ W1.t() + b1)
+
+
+def agg_edge_bwd_stats(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift, mean):
+    agg_edge_bwd(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de)
+    s1, s2 = bn_bwd_stats(de, xe, scale, shift, mean)
+    return de, s1, s2
+
+
+def can_fuse_bn_bwd_dgrad(de, W):
+    return de.shape[0] > 0
+
+
+def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt):
+    dxe = bn_bwd_apply(de, xe, scale, shift, a, c1, c2, mean, rstd)
+    de.add_(dxe @ Wt.t())
+    return dxe

@@ -311,6 +311,33 @@ def test_training_step_is_bit_reproducible():
         assert torch.equal(runs[0][3][k], runs[1][3][k]), k
 
 
+@pytest.mark.parametrize("hidden,e", [(128, 50_001), (64, 7000), (128, 31)])
+def test_fused_backward_kernels_equal_their_unfused_pairs(hidden, e):
+    """gnnome_agg_edge_bwd_stats_f32 = agg_edge_bwd + bn_bwd_stats, gnnome_bn_bwd_dgrad_f32 = bn_bwd_apply + linear_acc: the
+    fused passes against the two-pass forms they replace (same kernels' arithmetic, so tight tolerances)."""
+    g = torch.Generator().manual_seed(hidden + e)
+    n, H = 500, hidden
+    src, dst = torch.randint(0, n, (e,), generator=g).int(), torch.randint(0, n, (e,), generator=g).int()
+    views = ops.GraphViews(src.to(dev()), dst.to(dev()), n)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev())  # noqa: E731
+    ee, xe, de0 = 2 * r(e, H), 3 * r(e, H), r(e, H)
+    Tf, Uf, Tb, Ub, P = r(n, H), r(n, H), r(n, H), r(n, H), r(n, 2 * H)
+    scale, shift, mean = (torch.rand(H, generator=g) + 0.5).to(dev()), r(H), r(H)
+    want_de = ops.agg_edge_bwd(ee, Tf, Uf, Tb, Ub, P[:, :H], P[:, H:], views, de0.clone())
+    w1, w2 = ops.bn_bwd_stats(want_de, xe, scale, shift, mean)
+    got_de, s1, s2 = ops.agg_edge_bwd_stats(ee, Tf, Uf, Tb, Ub, P[:, :H], P[:, H:], views, de0.clone(), xe, scale, shift, mean)
+    assert (got_de - want_de).abs().max().item() <= 2e-6 * max(1.0, want_de.abs().max().item())   # same formula; fma contraction may differ
+    assert (s1 - w1).abs().max().item() <= 1e-4 * max(1.0, w1.abs().max().item()) and (s2 - w2).abs().max().item() <= 1e-4 * max(1.0, w2.abs().max().item())
+    a, c1, c2, rstd = r(H), 0.1 * r(H), 0.1 * r(H), (torch.rand(H, generator=g) + 0.5).to(dev())
+    Wt = (torch.randn(H, H, generator=g) / H ** 0.5).to(dev())
+    want_dxe = ops.bn_bwd_apply(want_de, xe, scale, shift, a, c1, c2, mean, rstd)
+    want_c = ops.linear(want_dxe, Wt, None, out=want_de.clone(), accumulate=True)
+    c = want_de.clone()
+    got_dxe = ops.bn_bwd_dgrad(c, xe, scale, shift, a, c1, c2, mean, rstd, Wt)
+    assert (got_dxe - want_dxe).abs().max().item() <= 1e-5 * max(1.0, want_dxe.abs().max().item())
+    assert (c - want_c).abs().max().item() <= 2e-5 * max(1.0, want_c.abs().max().item())
+
+
 def test_training_step_full_size_properties():
     """BASELINE configs[2]'s shape (N = 1e5, E = 1e6, H = 128): a whole fwd + BCE + bwd step twice from the same state -
     same bits (logits, loss, all 142 gradients, BatchNorm buffers), everything finite, BatchNorm counters advanced as the
