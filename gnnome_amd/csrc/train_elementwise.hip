@@ -276,6 +276,49 @@ __global__ __launch_bounds__(256) void k_segment_sum(const float* __restrict__ X
     if (group == 0) *reinterpret_cast<f32x4*>(out + node * ld_out + c) = acc;
 }
 
+// Both segment sums of one [E,W] tensor in one launch: out_in[i,:] = sum over the in-edge rows of node i (a contiguous run of
+// sorted positions), out_out[i,:] = sum over its out-edge rows (reached through out_pos).  One wave per node, as the
+// aggregation kernel walks the same two lists: the out-edge pass finds most of its rows in L2, where the in-edge pass of
+// a neighbouring node has just put them - two separate launches stream X from HBM twice.
+template <int W>
+__global__ __launch_bounds__(256) void k_segment_sum2(const float* __restrict__ X, const int32_t* __restrict__ in_ptr,
+                                                      const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos,
+                                                      int64_t n_nodes, float* __restrict__ out_in, int ld_in, float* __restrict__ out_out,
+                                                      int ld_out, int total_blocks) {
+    constexpr int LPR = W / 4, G = 64 / LPR, U = 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t node = (int64_t)xcd_remap(blockIdx.x, total_blocks) * 4 + (threadIdx.x >> 6);
+    if (node >= n_nodes) return;
+    const int group = lane / LPR, c = (lane % LPR) * 4;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int32_t* ptr = side == 0 ? in_ptr : out_ptr;
+        const int b = ptr[node], e = ptr[node + 1];
+        for (int q0 = b; q0 < e; q0 += G * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * G + group;
+                const int64_t p = q < e ? (side == 0 ? q : out_pos[q]) : 0;
+                v[u] = q < e ? *reinterpret_cast<const f32x4*>(X + p * W + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[side] += v[u];
+        }
+    }
+#pragma unroll
+    for (int side = 0; side < 2; ++side)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = LPR; m < 64; m <<= 1) acc[side][j] += __shfl_xor(acc[side][j], m);
+    if (group == 0) {
+        *reinterpret_cast<f32x4*>(out_in + node * ld_in + c) = acc[0];
+        *reinterpret_cast<f32x4*>(out_out + node * ld_out + c) = acc[1];
+    }
+}
+
 static unsigned ew_grid(int64_t work_items) {
     int64_t b = (work_items + kEwThreads - 1) / kEwThreads;
     if (b < 1) b = 1;
@@ -564,6 +607,26 @@ extern "C" int gnnome_agg_edge_bwd_stats_f32(const float* e, int64_t num_edges, 
     }
     GN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, s, (const float*)workspace, (int)grid, hidden, s1, s2);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_segment_sum2_f32(const float* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
+                                       int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(num_nodes >= 0, "segment_sum2: negative node count");
+    if (num_nodes == 0) return GNNOME_OK;
+    GN_REQUIRE(in_ptr && out_ptr && out_in && out_out && ld_in >= width && ld_out >= width && ld_in % 4 == 0 && ld_out % 4 == 0,
+               "segment_sum2: bad arguments");
+    const unsigned blocks = (unsigned)((num_nodes + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    switch (width) {
+        case 64: hipLaunchKernelGGL(k_segment_sum2<64>, dim3(blocks), dim3(256), 0, s, X, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, (int)blocks); break;
+        case 128: hipLaunchKernelGGL(k_segment_sum2<128>, dim3(blocks), dim3(256), 0, s, X, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, (int)blocks); break;
+        case 256: hipLaunchKernelGGL(k_segment_sum2<256>, dim3(blocks), dim3(256), 0, s, X, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, (int)blocks); break;
+        case 32: hipLaunchKernelGGL(k_segment_sum2<32>, dim3(blocks), dim3(256), 0, s, X, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, (int)blocks); break;
+        default: set_error("segment_sum2: width=%d not in {32,64,128,256}", width); return GNNOME_EINVAL;
+    }
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

@@ -540,6 +540,21 @@ def segment_sum(X, ptr, pos, num_nodes, out=None):
     return out
 
 
+def segment_sum2(X, views, num_nodes, out_in=None, out_out=None):
+    """(sum over in-edge rows, sum over out-edge rows) of X[E,W] per node, one launch; outputs may be column blocks of a
+    wider table (row-strided)."""
+    X = _dense(X, "segment_sum2.X")
+    W = X.shape[1]
+    mk = lambda: torch.empty((num_nodes, W), dtype=torch.float32, device=X.device)  # noqa: E731
+    out_in = mk() if out_in is None else out_in
+    out_out = mk() if out_out is None else out_out
+    out_in, ld_in = _rows(out_in, "segment_sum2.out_in")
+    out_out, ld_out = _rows(out_out, "segment_sum2.out_out")
+    _call("gnnome_segment_sum2_f32", X.device, _ptr(X), W, _ptr(views.in_ptr), _ptr(views.out_ptr), _ptr(views.out_pos), num_nodes,
+          _ptr(out_in), ld_in, _ptr(out_out), ld_out)
+    return out_in, out_out
+
+
 def wgrad(A, B, out=None):
     """out[Ka,Kb] = A^T @ B over the rows (nn.Linear weight gradient dW = dY^T X)."""
     A, lda = _rows(A, "wgrad.A")

@@ -291,8 +291,11 @@ class _TrainStep(torch.autograd.Function):
             g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"])
             if s["sc_e"] is None or W3t is not None:
                 ops.linear(dxe, d(conv.B_3.weight).t().contiguous(), None, out=de, accumulate=True)   # d e_in = d e' + dxe W3
-            dB1 = ops.segment_sum(dxe, views.out_ptr, views.out_pos, n_local)
-            dB2 = ops.segment_sum(dxe, views.in_ptr, None, n_local)
+            if hasattr(ops, "segment_sum2"):   # both gathers' transposes in one launch (the out-edge pass then hits L2)
+                dB2, dB1 = ops.segment_sum2(dxe, views, n_local)
+            else:
+                dB1 = ops.segment_sum(dxe, views.out_ptr, views.out_pos, n_local)
+                dB2 = ops.segment_sum(dxe, views.in_ptr, None, n_local)
             parts = [None] * 5
             parts[r["A1"]], parts[r["A2"]], parts[r["A3"]], parts[r["B1"]], parts[r["B2"]] = dv, sum_out, sum_in, dB1, dB2
             for k, name in enumerate(("A_1", "A_2", "A_3", "B_1", "B_2")):

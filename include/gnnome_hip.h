@@ -258,6 +258,11 @@ int gnnome_relu_bwd_f32(const float* dy, const float* y, int64_t count, float* d
 int gnnome_segment_sum_f32(const float* X, int width, const int32_t* ptr, const int32_t* pos, int64_t num_nodes,
                            float* out, int ld_out, void* stream);
 
+/* Both segment sums of one tensor in one launch: out_in[i,:] = sum over node i's in-edge rows (ptr = in_ptr, contiguous),
+ * out_out[i,:] = sum over its out-edge rows (out_ptr / out_pos).  Same values as two gnnome_segment_sum_f32 calls. */
+int gnnome_segment_sum2_f32(const float* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
+                            int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream);
+
 /* C[Ka,Kb] = A[rows,Ka]^T * B[rows,Kb]: nn.Linear weight gradients on the bf16 matrix cores as the fp32-faithful
  * bf16x6 product (see gnnome_linear_f32; error of the size of an fp32 dot product's), chunked over rows with a
  * deterministic second-stage sum.  Ka, Kb % 4 == 0; A, B 16-byte aligned. */

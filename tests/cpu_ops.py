@@ -338,3 +338,9 @@ def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt):
     dxe = bn_bwd_apply(de, xe, scale, shift, a, c1, c2, mean, rstd)
     de.add_(dxe @ Wt.t())
     return dxe
+
+
+def segment_sum2(X, views, num_nodes, out_in=None, out_out=None):
+    a = segment_sum(X, views.in_ptr, None, num_nodes, out=out_in)
+    b = segment_sum(X, views.out_ptr, views.out_pos, num_nodes, out=out_out)
+    return a, b

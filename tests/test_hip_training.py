@@ -328,6 +328,12 @@ def test_fused_backward_kernels_equal_their_unfused_pairs(hidden, e):
     got_de, s1, s2 = ops.agg_edge_bwd_stats(ee, Tf, Uf, Tb, Ub, P[:, :H], P[:, H:], views, de0.clone(), xe, scale, shift, mean)
     assert (got_de - want_de).abs().max().item() <= 2e-6 * max(1.0, want_de.abs().max().item())   # same formula; fma contraction may differ
     assert (s1 - w1).abs().max().item() <= 1e-4 * max(1.0, w1.abs().max().item()) and (s2 - w2).abs().max().item() <= 1e-4 * max(1.0, w2.abs().max().item())
+    si, so = ops.segment_sum2(xe, views, n)
+    assert torch.equal(si, ops.segment_sum(xe, views.in_ptr, None, n)) or (si - ops.segment_sum(xe, views.in_ptr, None, n)).abs().max() < 1e-4
+    assert (so - ops.segment_sum(xe, views.out_ptr, views.out_pos, n)).abs().max().item() < 1e-4 * max(1.0, so.abs().max().item())
+    wide = torch.zeros(n, 3 * H, device=dev())
+    ops.segment_sum2(xe, views, n, out_in=wide[:, :H], out_out=wide[:, 2 * H:])
+    assert torch.equal(wide[:, :H], si) and torch.equal(wide[:, 2 * H:], so) and not wide[:, H:2 * H].any()
     a, c1, c2, rstd = r(H), 0.1 * r(H), 0.1 * r(H), (torch.rand(H, generator=g) + 0.5).to(dev())
     Wt = (torch.randn(H, H, generator=g) / H ** 0.5).to(dev())
     want_dxe = ops.bn_bwd_apply(want_de, xe, scale, shift, a, c1, c2, mean, rstd)
