@@ -233,12 +233,27 @@ static unsigned grid_for_items(int64_t n) {
 
 using namespace gnnome;
 
+// Row chunks of one wgrad call: enough workgroups (output tiles x chunks) to put two on every CU - the LDS footprint admits
+// two - but no chunk shorter than 256 rows (each chunk costs a [Ka,Kb] partial tile written and read back).  At 1M rows and
+// one output tile that is ~2000 rows per chunk; at 100k rows and five tiles (the [N,5H]^T [N,H] projection gradient) 1024,
+// where the old fixed 2048 left one 4-wave workgroup per CU.
+static int64_t wgrad_chunks(int64_t rows, int Ka, int Kb, int64_t* rows_per_chunk) {
+    const int64_t tiles = (int64_t)((Ka + kWgTile - 1) / kWgTile) * ((Kb + kWgTile - 1) / kWgTile);
+    int64_t chunks = (2 * kNumCUs + tiles - 1) / tiles;
+    const int64_t most = (rows + 255) / 256;
+    if (chunks > most) chunks = most;
+    if (chunks > 1024) chunks = 1024;
+    if (chunks < 1) chunks = 1;
+    int64_t rpc = (rows + chunks - 1) / chunks;
+    rpc = (rpc + kWgRows - 1) / kWgRows * kWgRows;
+    if (rpc < kWgRows) rpc = kWgRows;
+    if (rows_per_chunk) *rows_per_chunk = rpc;
+    return rows > 0 ? (rows + rpc - 1) / rpc : 1;
+}
+
 extern "C" int gnnome_wgrad_workspace_bytes(int64_t rows, int Ka, int Kb, size_t* bytes_host) {
     GN_REQUIRE(bytes_host && rows >= 0 && Ka > 0 && Kb > 0, "wgrad: bad arguments");
-    int64_t chunks = (rows + 2047) / 2048;  // >= 2048 rows per chunk: ~2 resident workgroups per CU at 1M rows
-    if (chunks < 1) chunks = 1;
-    if (chunks > 1024) chunks = 1024;
-    *bytes_host = (size_t)chunks * Ka * Kb * sizeof(float);
+    *bytes_host = (size_t)wgrad_chunks(rows, Ka, Kb, nullptr) * Ka * Kb * sizeof(float);
     return GNNOME_OK;
 }
 
@@ -253,11 +268,8 @@ extern "C" int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B,
     }
     GN_REQUIRE(A && B && workspace && lda >= Ka && ldb >= Kb && lda % 4 == 0 && ldb % 4 == 0, "wgrad: bad operands");
     GN_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "wgrad: A and B must be 16-byte aligned");
-    int64_t chunks = (rows + 2047) / 2048;
-    if (chunks > 1024) chunks = 1024;
-    int64_t rpc = (rows + chunks - 1) / chunks;
-    rpc = (rpc + kWgRows - 1) / kWgRows * kWgRows;
-    chunks = (rows + rpc - 1) / rpc;
+    int64_t rpc = 0;
+    const int64_t chunks = wgrad_chunks(rows, Ka, Kb, &rpc);
     const size_t need = (size_t)chunks * Ka * Kb * sizeof(float);
     if (workspace_bytes < need) {
         set_error("wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
