@@ -12,15 +12,26 @@ namespace gnnome {
 // 128x128 output tile and one contiguous chunk of rows and writes its partial tile; a second kernel adds the
 // partials in chunk order, so the result does not depend on scheduling (no float atomics).
 // ---------------------------------------------------------------------------------------------------
-constexpr int kWgTile = 128, kWgRows = 64, kWgLd = kWgTile + 4;
+constexpr int kWgTile = 128, kWgRows = 32;
+constexpr int kWgColBytes = 2 * kWgRows + 16;        // one column of one bf16 plane: 32 rows + 16 bytes of pad
+constexpr int kWgPlane = kWgTile * kWgColBytes;      // 10 KB; six planes (A and B, three each) = 60 KB: two workgroups per CU
 
 // One workgroup = one 128x128 output tile (a whole [H,H] weight at H = 128) x one chunk of rows, so every row of
 // A and B is read from HBM exactly once; wave (wi, wj) owns a 64x64 quadrant as 2x2 accumulators.
-__global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__ A, int lda, int Ka, const float* __restrict__ B,
-                                                       int ldb, int Kb, int64_t R, int64_t rows_per_chunk,
-                                                       float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float As[kWgRows * kWgLd];
-    __shared__ __attribute__((aligned(16))) float Bs[kWgRows * kWgLd];
+//
+// The MFMA k dimension is the ROW index, so a lane's operand is eight consecutive rows of ONE column.  The threads that
+// stage a 32-row slab split it (each element once, not once per wave that uses it) and store it TRANSPOSED as three bf16
+// planes [column slot][row]: a fragment is then one ds_read_b128 per plane.  A staging thread holds four columns
+// 4 c4 .. 4 c4 + 3 of four consecutive rows (a 16-byte global load per row) and writes 8 bytes per column and plane;
+// column 4 c4 + j lives in slot 32 j + c4, which spreads the 32 lanes of a write over the banks (20 c4 mod 64) and makes
+// MFMA row/column index m of fragment f the output index 4 m + f.  The next slab's global loads are issued before the
+// MFMAs of the current one.
+__global__ __launch_bounds__(256, 2) void k_wgrad_partial(const float* __restrict__ A, int lda, int Ka, const float* __restrict__ B,
+                                                          int ldb, int Kb, int64_t R, int64_t rows_per_chunk,
+                                                          float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[6 * kWgPlane];
+    unsigned char* Ap = lds;
+    unsigned char* Bp = lds + 3 * kWgPlane;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i0 = blockIdx.x * kWgTile, j0 = blockIdx.y * kWgTile;
     const int64_t r_begin = (int64_t)blockIdx.z * rows_per_chunk, r_end = min(R, r_begin + rows_per_chunk);
@@ -33,43 +44,56 @@ __global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int c4 = tid & 31, rr = tid >> 5;  // 32 float4 per 128-wide row, 8 rows per pass
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
+    const int c4 = tid & 31, rr = tid >> 5;  // 32 float4 per 128-wide row; rows 4 rr .. 4 rr + 3 of the slab
+    const bool a_in = i0 + 4 * c4 < Ka, b_in = j0 + 4 * c4 < Kb;   // rows and columns outside the operands contribute zeros
+    const float* a_col = A + i0 + 4 * c4;
+    const float* b_col = B + j0 + 4 * c4;
+    f32x4 av[4], bv[4];
+    auto fetch = [&](int64_t r0) {
 #pragma unroll
-        for (int it = 0; it < kWgRows / 8; ++it) {
-            const int lr = rr + 8 * it;
-            const int64_t row = r0 + lr;
-            f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = av;
-            if (row < r_end) {  // rows and columns outside the operands contribute zeros
-                if (i0 + 4 * c4 < Ka) av = *reinterpret_cast<const f32x4*>(A + row * lda + i0 + 4 * c4);
-                if (j0 + 4 * c4 < Kb) bv = *reinterpret_cast<const f32x4*>(B + row * ldb + j0 + 4 * c4);
+        for (int t = 0; t < 4; ++t) {
+            const int64_t row = r0 + 4 * rr + t;
+            av[t] = bv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < r_end) {
+                if (a_in) av[t] = *reinterpret_cast<const f32x4*>(a_col + row * lda);
+                if (b_in) bv[t] = *reinterpret_cast<const f32x4*>(b_col + row * ldb);
             }
-            *reinterpret_cast<f32x4*>(As + lr * kWgLd + 4 * c4) = av;
-            *reinterpret_cast<f32x4*>(Bs + lr * kWgLd + 4 * c4) = bv;
         }
+    };
+    auto stage = [&](unsigned char* planes, const f32x4 (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint2 p1, p2, p3;
+            tile_split4(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]}, p1, p2, p3);
+            unsigned char* d = planes + (32 * j + c4) * kWgColBytes + 8 * rr;
+            *reinterpret_cast<uint2*>(d) = p1;
+            *reinterpret_cast<uint2*>(d + kWgPlane) = p2;
+            *reinterpret_cast<uint2*>(d + 2 * kWgPlane) = p3;
+        }
+    };
+    auto bf = [](const uint4 v) { return __builtin_bit_cast(tile_bf16x8, v); };
+    // fragment f of wave half w: slots 64 w + 32 f + (lane & 31), rows 16 s + 8 (lane >> 5) .. + 7
+    const unsigned char* ap = Ap + (64 * wi + (lane & 31)) * kWgColBytes + 16 * (lane >> 5);
+    const unsigned char* bp = Bp + (64 * wj + (lane & 31)) * kWgColBytes + 16 * (lane >> 5);
+    fetch(r_begin);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
+        stage(Ap, av);
+        stage(Bp, bv);
         __syncthreads();
-        // bf16x6 (gemm_tile.h): for v_mfma_f32_32x32x16_bf16 lane l supplies A^T[i = l&31][k = rows 16s + 8(l>>5) .. +7] and
-        // B[k][j = l&31] - eight ROWS of one column, read as eight conflict-free dwords and split in registers
-        const float* ap = As + 8 * (lane >> 5) * kWgLd + 64 * wi + (lane & 31);
-        const float* bp = Bs + 8 * (lane >> 5) * kWgLd + 64 * wj + (lane & 31);
-        auto bf = [](const uint4 v) { return __builtin_bit_cast(tile_bf16x8, v); };
-        auto frag = [&](const float* p, uint4& x1, uint4& x2, uint4& x3) {
-            const f32x4 lo = {p[0], p[kWgLd], p[2 * kWgLd], p[3 * kWgLd]};
-            const f32x4 hi = {p[4 * kWgLd], p[5 * kWgLd], p[6 * kWgLd], p[7 * kWgLd]};
-            uint2 l1, l2, l3, h1, h2, h3;
-            tile_split4(lo, l1, l2, l3);
-            tile_split4(hi, h1, h2, h3);
-            x1 = make_uint4(l1.x, l1.y, h1.x, h1.y);
-            x2 = make_uint4(l2.x, l2.y, h2.x, h2.y);
-            x3 = make_uint4(l3.x, l3.y, h3.x, h3.y);
-        };
-#pragma unroll 2
+        if (r0 + kWgRows < r_end) fetch(r0 + kWgRows);
+#pragma unroll
         for (int s = 0; s < kWgRows / 16; ++s) {
             uint4 a1[2], a2[2], a3[2], b1[2], b2[2], b3[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                frag(ap + 16 * s * kWgLd + 32 * h, a1[h], a2[h], a3[h]);
-                frag(bp + 16 * s * kWgLd + 32 * h, b1[h], b2[h], b3[h]);
+                const unsigned char* pa = ap + 32 * h * kWgColBytes + 32 * s;
+                const unsigned char* pb = bp + 32 * h * kWgColBytes + 32 * s;
+                a1[h] = *reinterpret_cast<const uint4*>(pa);
+                a2[h] = *reinterpret_cast<const uint4*>(pa + kWgPlane);
+                a3[h] = *reinterpret_cast<const uint4*>(pa + 2 * kWgPlane);
+                b1[h] = *reinterpret_cast<const uint4*>(pb);
+                b2[h] = *reinterpret_cast<const uint4*>(pb + kWgPlane);
+                b3[h] = *reinterpret_cast<const uint4*>(pb + 2 * kWgPlane);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -94,7 +118,7 @@ __global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = 64 * wi + 32 * a + cd_row(r, lane), j = 64 * wj + 32 * b + (lane & 31);
+                const int i = 4 * cd_row(r, lane) + 2 * wi + a, j = 4 * (lane & 31) + 2 * wj + b;
                 if (i0 + i < Ka && j0 + j < Kb) out[(int64_t)i * Kb + j] = acc[a][b][r];
             }
 }
