@@ -49,6 +49,8 @@ SIGNATURES = {
     "gnnome_segment_sum2_f32": [_p, _i, _p, _p, _p, _l, _p, _i, _p, _i, _p],
     "gnnome_wgrad_workspace_bytes": [_l, _i, _i, ctypes.POINTER(_sz)],
     "gnnome_wgrad_f32": [_p, _i, _i, _p, _i, _i, _l, _p, _i, _p, _sz, _p],
+    "gnnome_wgrad_blocks_f32": [_p, _i, _i, _i, _p, _i, _i, _l, _p, _i, _p, _p, _sz, _p],
+    "gnnome_linear_blocks_f32": [_p, _i, _i, _l, _i, _p, _i, _i, _p, _i, _i, _p],
     "gnnome_score_tail_bwd_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_agg_edge_bwd_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "gnnome_encode_hidden_f32": [_p, _l, _i, _p, _p, _p, _i, _p, _p],

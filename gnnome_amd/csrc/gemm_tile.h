@@ -155,4 +155,45 @@ __device__ __forceinline__ void tile_gemm(f32x16 (&acc)[NB], const float* __rest
     }
 }
 
+// The same with A given as column blocks of equal width in separate buffers (K = blocks x width, width % kKC == 0): the K chunk
+// kc comes from block kc / width.  Used by the backward's dh += [dA1 | dA2 | dA3 | dB1 | dB2] * Wcat without concatenating.
+constexpr int kABlocks = 8;
+struct ABlocks {
+    const float* blk[kABlocks];
+    int width;
+};
+
+template <int NB>
+__device__ __forceinline__ void tile_gemm_blocks(f32x16 (&acc)[NB], const ABlocks& ab, int64_t row0, int64_t M, int lda,
+                                                 const float* __restrict__ W, int wrow0, int Nout, int ldw, int K, float* As,
+                                                 float* Ws, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    ChunkRegs<kTileM> ra;
+    ChunkRegs<32 * NB> rw;
+    const float* w_tile = W + (int64_t)wrow0 * ldw;
+    const int a_valid = (int)min((int64_t)kTileM, M - row0);
+    const int w_valid = min(32 * NB, Nout - wrow0);
+    auto load_a = [&](int kc) {
+        const int which = kc / ab.width;
+        const float* base = ab.blk[0];
+#pragma unroll
+        for (int k = 1; k < kABlocks; ++k)
+            if (which == k) base = ab.blk[k];
+        ra.load(base + row0 * lda, a_valid, lda, kc - which * ab.width, tid);
+    };
+    load_a(0);
+    rw.load(w_tile, w_valid, ldw, 0, tid);
+    for (int kc = 0; kc < K; kc += kKC) {
+        ra.store(As, tid);
+        rw.store_planes(Ws, tid);
+        __syncthreads();
+        if (kc + kKC < K) {
+            load_a(kc + kKC);
+            rw.load(w_tile, w_valid, ldw, kc + kKC, tid);
+        }
+        mma_chunk<NB>(acc, As, Ws, wave, lane);
+        __syncthreads();
+    }
+}
+
 }  // namespace gnnome

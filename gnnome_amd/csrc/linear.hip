@@ -497,7 +497,64 @@ static int launch_linear(const float* A, int64_t M, int K, int lda, const float*
     return GNNOME_OK;
 }
 
+// k_linear with A as column blocks (tile_gemm_blocks), 128 output columns per tile, C (+)= A W^T
+__global__ __launch_bounds__(kGemmThreads) void k_linear_blocks(ABlocks ab, int64_t M, int K, int lda, const float* __restrict__ W,
+                                                                int ldw, int Nout, float* __restrict__ C, int ldc, int n_tiles,
+                                                                int total_tiles, int accumulate) {
+    constexpr int NB = 4;
+    __shared__ __attribute__((aligned(16))) float lds[tile_lds_floats<NB>()];
+    float* As = lds;
+    float* Ws = lds + kTileM * kLdk;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tile = xcd_remap(blockIdx.x, total_tiles);
+    const int64_t row0 = (int64_t)(tile / n_tiles) * kTileM;
+    const int col0 = (tile % n_tiles) * 32 * NB;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    tile_gemm_blocks<NB>(acc, ab, row0, M, lda, W, col0, Nout, ldw, K, As, Ws, tid);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = col0 + 32 * nb + (lane & 31);
+        if (col < Nout) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + 32 * wave + cd_row(r, lane);
+                if (row < M) C[row * ldc + col] = accumulate ? C[row * ldc + col] + acc[nb][r] : acc[nb][r];
+            }
+        }
+    }
+}
+
 }  // namespace gnnome
+
+// C[M,Nout] (+)= [A_0 | A_1 | ...] W^T with the column blocks of A in separate buffers (all [M, block_width], row stride lda)
+extern "C" int gnnome_linear_blocks_f32(const float* const* A_blocks, int num_blocks, int block_width, int64_t M, int lda, const float* W,
+                                        int ldw, int Nout, float* C, int ldc, int accumulate, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(M >= 0 && Nout > 0, "linear_blocks: bad shape M=%lld Nout=%d", (long long)M, Nout);
+    if (M == 0) return GNNOME_OK;
+    GN_REQUIRE(A_blocks && num_blocks >= 1 && num_blocks <= kABlocks && block_width > 0 && block_width % kKC == 0,
+               "linear_blocks: 1..%d blocks of a width that is a multiple of %d", kABlocks, kKC);
+    const int K = num_blocks * block_width;
+    GN_REQUIRE(W && C && lda >= block_width && ldw >= K && ldc >= Nout && lda % 4 == 0 && ldw % 4 == 0 && (uintptr_t)W % 16 == 0,
+               "linear_blocks: bad operands");
+    ABlocks ab = {};
+    for (int k = 0; k < num_blocks; ++k) {
+        GN_REQUIRE(A_blocks[k] && (uintptr_t)A_blocks[k] % 16 == 0, "linear_blocks: block %d null or not 16-byte aligned", k);
+        ab.blk[k] = A_blocks[k];
+    }
+    ab.width = block_width;
+    const int n_tiles = (Nout + 127) / 128;
+    const int64_t total = (M + kTileM - 1) / kTileM * n_tiles;
+    GN_REQUIRE(total < (1ll << 31), "linear_blocks: too many tiles");
+    hipLaunchKernelGGL(k_linear_blocks, dim3((unsigned)total), dim3(kGemmThreads), 0, (hipStream_t)stream, ab, M, K, lda, W, ldw, Nout, C,
+                       ldc, n_tiles, (int)total, accumulate);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
 
 static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias, int Nout,
                        float* C, int ldc, void* stream, int accumulate) {

@@ -12,7 +12,7 @@ namespace gnnome {
 // 128x128 output tile and one contiguous chunk of rows and writes its partial tile; a second kernel adds the
 // partials in chunk order, so the result does not depend on scheduling (no float atomics).
 // ---------------------------------------------------------------------------------------------------
-constexpr int kWgTile = 128, kWgRows = 32;
+constexpr int kWgTile = 128, kWgRows = 32, kWgBlocks = 8;
 constexpr int kWgColBytes = 2 * kWgRows + 16;        // one column of one bf16 plane: 32 rows + 16 bytes of pad
 constexpr int kWgPlane = kWgTile * kWgColBytes;      // 10 KB; six planes (A and B, three each) = 60 KB: two workgroups per CU
 
@@ -26,9 +26,19 @@ constexpr int kWgPlane = kWgTile * kWgColBytes;      // 10 KB; six planes (A and
 // column 4 c4 + j lives in slot 32 j + c4, which spreads the 32 lanes of a write over the banks (20 c4 mod 64) and makes
 // MFMA row/column index m of fragment f the output index 4 m + f.  The next slab's global loads are issued before the
 // MFMAs of the current one.
-__global__ __launch_bounds__(256, 2) void k_wgrad_partial(const float* __restrict__ A, int lda, int Ka, const float* __restrict__ B,
+//
+// A may be given as up to kWgBlocks column blocks of equal width living in separate buffers (the five [N,H] gradients of a
+// layer's node projections, never concatenated): column c is column c % width of block c / width.  With colsum_part set, the
+// workgroups of the first tile column also leave the column sums of their rows of A (the bias gradients) - the slab is in
+// their registers anyway.
+struct WgradA {
+    const float* blk[kWgBlocks];
+    int width;   // >= Ka for a single buffer
+};
+
+__global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, int Ka, const float* __restrict__ B,
                                                           int ldb, int Kb, int64_t R, int64_t rows_per_chunk,
-                                                          float* __restrict__ partial) {
+                                                          float* __restrict__ partial, float* __restrict__ colsum_part) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[6 * kWgPlane];
     unsigned char* Ap = lds;
     unsigned char* Bp = lds + 3 * kWgPlane;
@@ -46,8 +56,17 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(const float* __restric
 
     const int c4 = tid & 31, rr = tid >> 5;  // 32 float4 per 128-wide row; rows 4 rr .. 4 rr + 3 of the slab
     const bool a_in = i0 + 4 * c4 < Ka, b_in = j0 + 4 * c4 < Kb;   // rows and columns outside the operands contribute zeros
-    const float* a_col = A + i0 + 4 * c4;
+    const float* a_col = a_op.blk[0];
+    {
+        const int ca = a_in ? i0 + 4 * c4 : 0, which = ca / a_op.width;
+#pragma unroll
+        for (int k = 1; k < kWgBlocks; ++k)
+            if (which == k) a_col = a_op.blk[k];   // a select chain: no dynamic indexing of the kernel arguments
+        a_col += ca - which * a_op.width;
+    }
     const float* b_col = B + j0 + 4 * c4;
+    const bool sums = colsum_part != nullptr && blockIdx.y == 0;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     f32x4 av[4], bv[4];
     auto fetch = [&](int64_t r0) {
 #pragma unroll
@@ -79,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(const float* __restric
     for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
         stage(Ap, av);
         stage(Bp, bv);
+        if (sums) cs += (av[0] + av[1]) + (av[2] + av[3]);
         __syncthreads();
         if (r0 + kWgRows < r_end) fetch(r0 + kWgRows);
 #pragma unroll
@@ -121,15 +141,34 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(const float* __restric
                 const int i = 4 * cd_row(r, lane) + 2 * wi + a, j = 4 * (lane & 31) + 2 * wj + b;
                 if (i0 + i < Ka && j0 + j < Kb) out[(int64_t)i * Kb + j] = acc[a][b][r];
             }
+    if (sums) {   // the eight row groups of a column, added in a fixed order (the planes are no longer needed: the loop ended on a barrier)
+        float* red = reinterpret_cast<float*>(lds);
+        *reinterpret_cast<f32x4*>(red + rr * kWgTile + 4 * c4) = cs;
+        __syncthreads();
+        if (tid < kWgTile && i0 + tid < Ka) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * kWgTile + tid];
+            colsum_part[(int64_t)blockIdx.z * Ka + i0 + tid] = t;
+        }
+    }
 }
 
 // C = sum over chunks of the partial tiles, in a fixed order: workgroup = 64 consecutive elements, wave w adds the
 // chunks c = w, w+4, ... and the four wave sums are combined in wave order.
+// Workgroups past the last element of C do the same for the column sums of A (colsum_part[chunk][Ka] -> colsum[Ka]).
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int64_t elems, int chunks,
-                                                      float* __restrict__ C, int ldc, int Kb) {
+                                                      float* __restrict__ C, int ldc, int Kb, int c_blocks,
+                                                      const float* __restrict__ colsum_part, int Ka, float* __restrict__ colsum) {
     __shared__ float part[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    if ((int)blockIdx.x >= c_blocks) {
+        partial = colsum_part;
+        elems = Ka;
+        C = colsum;
+        ldc = Kb = Ka;
+    }
+    const int64_t i = (int64_t)(blockIdx.x >= (unsigned)c_blocks ? blockIdx.x - c_blocks : blockIdx.x) * 64 + lane;
     float s = 0.f;
     if (i < elems)
         for (int c = wave; c < chunks; c += 4) s += partial[(int64_t)c * elems + i];
@@ -277,36 +316,63 @@ static int64_t wgrad_chunks(int64_t rows, int Ka, int Kb, int64_t* rows_per_chun
 
 extern "C" int gnnome_wgrad_workspace_bytes(int64_t rows, int Ka, int Kb, size_t* bytes_host) {
     GN_REQUIRE(bytes_host && rows >= 0 && Ka > 0 && Kb > 0, "wgrad: bad arguments");
-    *bytes_host = (size_t)wgrad_chunks(rows, Ka, Kb, nullptr) * Ka * Kb * sizeof(float);
+    *bytes_host = (size_t)wgrad_chunks(rows, Ka, Kb, nullptr) * ((size_t)Ka * Kb + Ka) * sizeof(float);   // partial tiles + partial column sums
     return GNNOME_OK;
 }
 
-extern "C" int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C,
-                                int ldc, void* workspace, size_t workspace_bytes, void* stream) {
+static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C, int ldc,
+                      float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
     GN_REQUIRE(rows >= 0 && Ka > 0 && Kb > 0 && Ka % 4 == 0 && Kb % 4 == 0, "wgrad: Ka=%d Kb=%d must be positive multiples of 4", Ka, Kb);
     GN_REQUIRE(C && ldc >= Kb, "wgrad: bad output");
     hipStream_t s = (hipStream_t)stream;
     if (rows == 0) {
         for (int i = 0; i < Ka; ++i) GN_HIP(hipMemsetAsync(C + (int64_t)i * ldc, 0, Kb * sizeof(float), s));
+        if (colsum) GN_HIP(hipMemsetAsync(colsum, 0, Ka * sizeof(float), s));
         return GNNOME_OK;
     }
-    GN_REQUIRE(A && B && workspace && lda >= Ka && ldb >= Kb && lda % 4 == 0 && ldb % 4 == 0, "wgrad: bad operands");
-    GN_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "wgrad: A and B must be 16-byte aligned");
+    GN_REQUIRE(B && workspace && ldb >= Kb && lda % 4 == 0 && ldb % 4 == 0, "wgrad: bad operands");
+    GN_REQUIRE((uintptr_t)B % 16 == 0, "wgrad: A and B must be 16-byte aligned");
     int64_t rpc = 0;
     const int64_t chunks = wgrad_chunks(rows, Ka, Kb, &rpc);
-    const size_t need = (size_t)chunks * Ka * Kb * sizeof(float);
+    const size_t need = (size_t)chunks * ((size_t)Ka * Kb + Ka) * sizeof(float);
     if (workspace_bytes < need) {
         set_error("wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
         return GNNOME_EWORKSPACE;
     }
+    float* partial = (float*)workspace;
+    float* colsum_part = colsum ? partial + (size_t)chunks * Ka * Kb : nullptr;
     const dim3 grid((Ka + kWgTile - 1) / kWgTile, (Kb + kWgTile - 1) / kWgTile, (unsigned)chunks);
-    hipLaunchKernelGGL(k_wgrad_partial, grid, dim3(256), 0, s, A, lda, Ka, B, ldb, Kb, rows, rpc, (float*)workspace);
+    hipLaunchKernelGGL(k_wgrad_partial, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
     GN_LAUNCH_CHECK();
     const int64_t elems = (int64_t)Ka * Kb;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, s, (const float*)workspace, elems,
-                       (int)chunks, C, ldc, Kb);
+    const int c_blocks = (int)((elems + 63) / 64), s_blocks = colsum ? (Ka + 63) / 64 : 0;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(c_blocks + s_blocks)), dim3(256), 0, s, (const float*)partial, elems, (int)chunks, C,
+                       ldc, Kb, c_blocks, (const float*)colsum_part, Ka, colsum);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
+}
+
+extern "C" int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C,
+                                int ldc, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(rows == 0 || (A && lda >= Ka && (uintptr_t)A % 16 == 0), "wgrad: bad operands");
+    WgradA a_op = {};
+    a_op.blk[0] = A;
+    a_op.width = Ka > 0 ? Ka : 1;
+    return wgrad_impl(a_op, lda, Ka, B, ldb, Kb, rows, C, ldc, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gnnome_wgrad_blocks_f32(const float* const* A_blocks, int num_blocks, int block_width, int lda, const float* B, int ldb,
+                                       int Kb, int64_t rows, float* C, int ldc, float* colsum, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    GN_REQUIRE(A_blocks && num_blocks >= 1 && num_blocks <= kWgBlocks && block_width > 0 && block_width % 4 == 0 && lda >= block_width,
+               "wgrad_blocks: 1..%d blocks of a width that is a multiple of 4", kWgBlocks);
+    WgradA a_op = {};
+    for (int k = 0; k < num_blocks; ++k) {
+        GN_REQUIRE(rows == 0 || (A_blocks[k] && (uintptr_t)A_blocks[k] % 16 == 0), "wgrad_blocks: block %d null or not 16-byte aligned", k);
+        a_op.blk[k] = A_blocks[k];
+    }
+    a_op.width = block_width;
+    return wgrad_impl(a_op, lda, num_blocks * block_width, B, ldb, Kb, rows, C, ldc, colsum, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gnnome_score_tail_bwd_f32(const float* z1, const float* dscore, const int32_t* srt_eid, int64_t num_edges,

@@ -570,6 +570,52 @@ def wgrad(A, B, out=None):
     return out
 
 
+def _block_table(blocks, name):
+    """A list of [rows, width] tensors with one common row stride -> (host array of device pointers, rows, width, lda)."""
+    rows, width = blocks[0].shape
+    lda = None
+    for k, b in enumerate(blocks):
+        b, ld = _rows(b, f"{name}[{k}]")
+        if tuple(b.shape) != (rows, width) or b.device != blocks[0].device or (lda is not None and ld != lda):
+            raise ValueError(f"{name}: the column blocks must share shape, device and row stride")
+        lda = ld
+    table = (ctypes.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
+    return table, rows, width, lda
+
+
+def wgrad_blocks(blocks, B, colsum=True):
+    """(C, s): C[len(blocks)*width, Kb] = [blocks[0] | blocks[1] | ...]^T @ B without concatenating, and the column sums s of
+    the blocks (the bias gradients) from the same pass (None with colsum=False)."""
+    table, rows, width, lda = _block_table(blocks, "wgrad_blocks.A")
+    B, ldb = _rows(B, "wgrad_blocks.B")
+    Ka, Kb, dev = len(blocks) * width, B.shape[1], B.device
+    out = torch.empty((Ka, Kb), dtype=torch.float32, device=dev)
+    sums = torch.empty(Ka, dtype=torch.float32, device=dev) if colsum else None
+    need = ctypes.c_size_t(0)
+    _lib.check(_lib.load().gnnome_wgrad_workspace_bytes(rows, Ka, Kb, ctypes.byref(need)), "wgrad_workspace_bytes")
+    ws = torch.empty(max(int(need.value), 4), dtype=torch.uint8, device=dev)
+    _call("gnnome_wgrad_blocks_f32", dev, table, len(blocks), width, lda, _ptr(B), ldb, Kb, rows, _ptr(out), Kb, _ptr(sums), _ptr(ws),
+          ws.numel())
+    return out, sums
+
+
+def linear_blocks(blocks, W, out, accumulate=False):
+    """out[M,Nout] (+)= [blocks[0] | blocks[1] | ...] @ W.T without concatenating (W[Nout, len(blocks)*width])."""
+    table, M, width, lda = _block_table(blocks, "linear_blocks.A")
+    W, ldw = _rows(W, "linear_blocks.W")
+    out, ldc = _rows(out, "linear_blocks.out")
+    assert W.shape[1] == len(blocks) * width and out.shape[0] == M
+    _call("gnnome_linear_blocks_f32", out.device, table, len(blocks), width, M, lda, _ptr(W), ldw, W.shape[0], _ptr(out), ldc,
+          1 if accumulate else 0)
+    return out
+
+
+def can_use_blocks(blocks):
+    b0 = blocks[0]
+    return (len(blocks) <= 8 and b0.dim() == 2 and b0.shape[1] % 32 == 0 and
+            all(b.data_ptr() % 16 == 0 and b.shape == b0.shape and b.stride() == b0.stride() and b.stride(1) == 1 for b in blocks))
+
+
 def score_tail_bwd(z1, dscore, views, W2, b2, W3):
     E, hs = z1.shape
     dz1 = torch.empty_like(z1)

@@ -298,15 +298,25 @@ class _TrainStep(torch.autograd.Function):
                 dB2 = ops.segment_sum(dxe, views.in_ptr, None, n_local)
             parts = [None] * 5
             parts[r["A1"]], parts[r["A2"]], parts[r["A3"]], parts[r["B1"]], parts[r["B2"]] = dv, sum_out, sum_in, dB1, dB2
-            for k, name in enumerate(("A_1", "A_2", "A_3", "B_1", "B_2")):
-                g[pfx + name + ".bias"] = ops.colsum2(parts[k])[0]
+            names = ("A_1", "A_2", "A_3", "B_1", "B_2")
+            WcatT = s["Wcat"].t().contiguous()
+            if hasattr(ops, "wgrad_blocks") and ops.can_use_blocks(parts):
+                # the five [N,H] gradients stay where their kernels left them: weight gradients, bias gradients (column sums of
+                # the same slabs) and dh += dP Wcat read them as column blocks
+                gWcat, gbcat = ops.wgrad_blocks(parts, s["h"])                # [5H, H], [5H]
+                for k, name in enumerate(names):
+                    g[pfx + name + ".bias"] = gbcat[k * H:(k + 1) * H]
+                dh = ops.linear_blocks(parts, WcatT, dh_in, accumulate=True)
+            else:
+                for k, name in enumerate(names):
+                    g[pfx + name + ".bias"] = ops.colsum2(parts[k])[0]
+                dP = torch.cat(parts, 1)
+                gWcat = ops.wgrad(dP, s["h"])                                 # [5H, H]
+                dh = ops.linear(dP, WcatT, None, out=dh_in, accumulate=True)
             # every edge has exactly one destination: sum_p dxe[p] = sum_i dB2[i], no second pass over [E,H]
             g[pfx + "B_3.bias"] = g[pfx + ("B_1" if views.transposed else "B_2") + ".bias"].clone()
-            dP = torch.cat(parts, 1)
-            gWcat = ops.wgrad(dP, s["h"])                                     # [5H, H]
-            for k, name in enumerate(("A_1", "A_2", "A_3", "B_1", "B_2")):
+            for k, name in enumerate(names):
                 g[pfx + name + ".weight"] = gWcat[k * H:(k + 1) * H]
-            dh = ops.linear(dP, s["Wcat"].t().contiguous(), None, out=dh_in, accumulate=True)
 
         # ---- encoders (models/full_graph.py:26-27)
         def encoder_bwd(dout, inp, gather, rows, l1, l2, pfx1, pfx2):

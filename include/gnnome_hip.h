@@ -270,6 +270,20 @@ int gnnome_wgrad_workspace_bytes(int64_t rows, int Ka, int Kb, size_t* bytes_hos
 int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C, int ldc,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with A given as num_blocks (1..8) column blocks of equal width in separate buffers - A_blocks is a HOST array of
+ * device pointers, each [rows, block_width] with row stride lda - so that the five gradients of a layer's node projections
+ * (dA1h | dA2h | dA3h | dB1h | dB2h, gated_gcn_full.py:89-95) need not be concatenated: C[num_blocks*block_width, Kb].
+ * colsum (may be NULL): [num_blocks*block_width] column sums of A over the rows = the bias gradients, from the same pass.
+ * Workspace: gnnome_wgrad_workspace_bytes(rows, num_blocks*block_width, Kb). */
+int gnnome_wgrad_blocks_f32(const float* const* A_blocks, int num_blocks, int block_width, int lda, const float* B, int ldb,
+                            int Kb, int64_t rows, float* C, int ldc, float* colsum, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
+/* C[M,Nout] (accumulate != 0: +=) [A_0 | A_1 | ...] * W[Nout, num_blocks*block_width]^T with the column blocks of A in separate
+ * buffers as above (block_width % 32 == 0): the backward's dh += dP * Wcat (gnnome_linear_acc_f32 on the concatenation). */
+int gnnome_linear_blocks_f32(const float* const* A_blocks, int num_blocks, int block_width, int64_t M, int lda, const float* W,
+                             int ldw, int Nout, float* C, int ldc, int accumulate, void* stream);
+
 /* Backward of the scorer tail (score_predictor.py:15-16) from the saved relu(z1) and d(score) (edge-id order,
  * read through srt_eid): dz1[E,hs], dz2[E,32], u[E,32] = dscore*z2.  hs in {32,64}. */
 int gnnome_score_tail_bwd_f32(const float* z1, const float* dscore, const int32_t* srt_eid, int64_t num_edges,

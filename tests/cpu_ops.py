@@ -301,6 +301,24 @@ def wgrad(A, B, out=None):
     return out
 
 
+def wgrad_blocks(blocks, B, colsum=True):
+    A = torch.cat(list(blocks), 1)
+    return A.t() @ B, (A.sum(0) if colsum else None)
+
+
+def linear_blocks(blocks, W, out, accumulate=False):
+    res = torch.cat(list(blocks), 1) @ W.t()
+    if accumulate:
+        out.add_(res)
+    else:
+        out.copy_(res)
+    return out
+
+
+def can_use_blocks(blocks):
+    return True
+
+
 def score_tail_bwd(z1, dscore, views, W2, b2, W3):
     E = z1.shape[0]
     dl = dscore[views.srt_eid[:E].long()]

@@ -76,6 +76,29 @@ def test_wgrad(rows, ka, kb):
     close(ops.wgrad(wide[:, 64:], B.to(dev())), wide[:, 64:].double().cpu().t() @ B.double(), tol=2e-5, scale=rows ** 0.5 * 4)
 
 
+@pytest.mark.parametrize("rows,width,nblocks,kb", [(5000, 128, 5, 128), (777, 64, 5, 64), (3001, 256, 5, 256), (1, 32, 3, 32), (4099, 64, 8, 128)])
+def test_wgrad_and_linear_over_column_blocks(rows, width, nblocks, kb):
+    """gnnome_wgrad_blocks_f32 / gnnome_linear_blocks_f32: the concatenation-free forms equal the calls on torch.cat of the blocks
+    (same kernels, same chunking: bit for bit), and the column sums are the bias gradients."""
+    g = torch.Generator().manual_seed(rows + width)
+    blocks = [torch.randn(rows, width, generator=g).to(dev()) for _ in range(nblocks)]
+    B = torch.randn(rows, kb, generator=g).to(dev())
+    assert ops.can_use_blocks(blocks)
+    C, sums = ops.wgrad_blocks(blocks, B)
+    cat = torch.cat(blocks, 1)
+    assert torch.equal(C, ops.wgrad(cat, B))
+    close(sums, cat.double().cpu().sum(0), tol=2e-5, scale=rows ** 0.5 * 4)
+    assert torch.equal(sums, ops.wgrad_blocks(blocks, B)[1])            # deterministic
+    assert ops.wgrad_blocks(blocks, B, colsum=False)[1] is None
+    W = torch.randn(kb, nblocks * width, generator=g).to(dev())
+    base = torch.randn(rows, kb, generator=g).to(dev())
+    want = cat.double().cpu() @ W.double().cpu().t()
+    close(ops.linear_blocks(blocks, W, torch.empty_like(base)), want, tol=2e-5, scale=(nblocks * width) ** 0.5 * 4)
+    close(ops.linear_blocks(blocks, W, base.clone(), accumulate=True), want + base.double().cpu(), tol=2e-5, scale=(nblocks * width) ** 0.5 * 4)
+    with pytest.raises(ValueError):
+        ops.wgrad_blocks([blocks[0], blocks[1][:, :width // 2]], B)
+
+
 def _views(n, e, seed):
     g = torch.Generator().manual_seed(seed)
     src = torch.randint(0, n - 2, (e,), generator=g).int()
