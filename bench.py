@@ -249,7 +249,7 @@ def _single_gpu_forward(gnnome_amd, ops, make_graph, random_state_dict, workload
             "steps": steps, "hbm_roofline_frac_whole_fwd": algorithmic_bytes(n, e, hidden) / (ms * 1e-3) / HBM_PEAK}
 
 
-def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry, dropout):
+def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry, dropout, storage="fp32"):
     """configs[2]'s shape: fwd + loss + bwd + Adam on the whole graph, fp32, the step replayed from a hipGraph (a training
     loop over one graph repeats the same launch sequence; ~450 library launches + a few hundred small torch ops cost
     30-40 ms of host time per step when issued eagerly)."""
@@ -258,6 +258,7 @@ def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry
     from gnnome_amd.synth import random_state_dict
     model.load_state_dict(random_state_dict(hidden, seed=1))
     model.to(dev)
+    model.activation_storage = storage   # "bf16": xe / dxe stored as bfloat16 between the kernels (arithmetic stays fp32)
     views = ops.GraphViews(g["src"].to(dev), g["dst"].to(dev), n)
     x, ef, y, pw = ops.degree_features(views), g["e"].to(dev), g["y"].to(dev), g["pos_weight"].to(dev)
     # torch.optim.Adam as train.py:259 builds it, in its fused single-kernel form (fused / capturable are implementation
@@ -303,8 +304,8 @@ def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry
     return {"metric": "edges/sec full-graph training step", "value": e / (ms * 1e-3), "unit": "edges/s", "ms_per_step": ms, "steps": steps,
             "step": ("train.py:159-170 symmetry loss: two train-mode forwards (graph and reversed graph) + BCE both ways + |org - rev|" if symmetry
                      else "train.py:138-145 + :328-330: train-mode forward (batch-statistic BatchNorm) + BCEWithLogits(pos_weight)")
-                    + f" + backward + Adam, fp32, dropout {dropout or 0}, whole step replayed from one hipGraph",
-            "eager_ms_per_step": eager_ms, "dtype": "f32",
+                    + f" + backward + Adam, fp32 arithmetic, activation storage {storage}, dropout {dropout or 0}, whole step replayed from one hipGraph",
+            "eager_ms_per_step": eager_ms, "dtype": "f32", "activation_storage": storage, "loss": float(loss),
             "hbm_roofline_frac_3xBfwd": passes * 3 * b_fwd / (ms * 1e-3) / HBM_PEAK, "mfma_f32_frac_3xFfwd": passes * 3 * f_fwd / (ms * 1e-3) / MFMA_F32_PEAK}
 
 
@@ -317,6 +318,7 @@ def main():
     ap.add_argument("--kind", default="banded", choices=["banded", "uniform"])
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: one forward (BASELINE configs[1]); train: the training step as the headline value (configs[2], fp32)")
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"], help="train: model.activation_storage (bf16 = xe / dxe stored as bfloat16)")
     ap.add_argument("--symmetry", action="store_true", help="train: the reference's default step (symmetry loss: two forwards, dropout 0.2)")
     ap.add_argument("--hipgraph", action="store_true", help="replay the forward from a captured hipGraph (single GPU, infer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -400,7 +402,8 @@ def main():
                 "note": "first call = weight preparation + allocator growth + one forward"}
 
         if args.mode == "train":
-            rec = _train_record(gnnome_amd, ops, g, n, e, hidden, dev, args.steps, args.warmup, args.symmetry, 0.2 if args.symmetry else None)
+            rec = _train_record(gnnome_amd, ops, g, n, e, hidden, dev, args.steps, args.warmup, args.symmetry, 0.2 if args.symmetry else None,
+                                storage=args.storage)
             rec.update({"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                         "data": "synthetic", "config": {"workload": f"{args.workload}: {args.kind} synthetic assembly graph N={n} E={e}, SymGatedGCNModel "
                                                                     f"hidden={hidden} L=8 hs=64, {rec.pop('step')}, random-init weights seed 1",
@@ -579,6 +582,8 @@ def main():
             if not args.no_extras and args.workload == "c2":
                 res["target_10m"] = _single_gpu_forward(gnnome_amd, ops, make_graph, random_state_dict, "10m", args.kind, dev, 20, 3)
                 res["train"] = _train_record(gnnome_amd, ops, g, n, e, hidden, dev, 20, 3, False, None)
+                t16 = _train_record(gnnome_amd, ops, g, n, e, hidden, dev, 20, 3, False, None, storage="bf16")
+                res["train"]["bf16_storage"] = {k: t16[k] for k in ("value", "ms_per_step", "eager_ms_per_step", "loss", "activation_storage")}
             if not args.no_cpu_baseline:
                 # in a child process (own thread pool, hard time limit): the baseline must never stall the bench line
                 res["cpu_baseline"], err_cpu = _run_cpu_child(args, 900 if args.cpu_baseline_full else 200)

@@ -34,10 +34,12 @@ SIGNATURES = {
     "gnnome_edge_gate_raw_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p],
     "gnnome_edge_gate_raw_stats_rows": [_i, ctypes.POINTER(_i)],
     "gnnome_edge_gate_raw_stats_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
+    "gnnome_edge_gate_raw_stats_x16": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
     "gnnome_node_aggregate_raw_f32": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_colsum_workspace_bytes": [ctypes.POINTER(_sz)],
     "gnnome_colsum2_f32": [_p, _p, _l, _i, _p, _p, _p, _p, _sz, _p],
     "gnnome_bn_relu_res_f32": [_p, _p, _p, _p, _l, _i, _p, _p],
+    "gnnome_bn_relu_res_x16": [_p, _p, _p, _p, _l, _i, _p, _p],
     "gnnome_bn_bwd_stats_f32": [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _sz, _p],
     "gnnome_bn_bwd_apply_f32": [_p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_ln_relu_res_f32": [_p, _p, _p, _p, _l, _i, _p, _p],
@@ -47,8 +49,10 @@ SIGNATURES = {
     "gnnome_relu_bwd_f32": [_p, _p, _l, _p, _p],
     "gnnome_segment_sum_f32": [_p, _i, _p, _p, _l, _p, _i, _p],
     "gnnome_segment_sum2_f32": [_p, _i, _p, _p, _p, _l, _p, _i, _p, _i, _p],
+    "gnnome_segment_sum2_x16": [_p, _i, _p, _p, _p, _l, _p, _i, _p, _i, _p],
     "gnnome_wgrad_workspace_bytes": [_l, _i, _i, ctypes.POINTER(_sz)],
     "gnnome_wgrad_f32": [_p, _i, _i, _p, _i, _i, _l, _p, _i, _p, _sz, _p],
+    "gnnome_wgrad_x16": [_p, _i, _i, _p, _i, _i, _l, _p, _i, _p, _sz, _p],
     "gnnome_wgrad_blocks_f32": [_p, _i, _i, _i, _p, _i, _i, _l, _p, _i, _p, _p, _sz, _p],
     "gnnome_linear_blocks_f32": [_p, _i, _i, _l, _i, _p, _i, _i, _p, _i, _i, _p],
     "gnnome_score_tail_bwd_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
@@ -60,7 +64,9 @@ SIGNATURES = {
     "gnnome_degree_features_f32": [_p, _p, _l, _i, _p, _p, _sz, _p],
     "gnnome_edge_features_f32": [_p, _p, _l, _p, _p, _sz, _p],
     "gnnome_bn_bwd_dgrad_f32": [_p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "gnnome_bn_bwd_dgrad_x16": [_p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_agg_edge_bwd_stats_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gnnome_agg_edge_bwd_stats_x16": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_bn_train_finish_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _i, _p, _p, _p, _p, _p],
     "gnnome_gate_center_f32": [_p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p],
     "gnnome_greedy_walks_workspace_bytes": [_l, _i, ctypes.POINTER(_sz)],
@@ -69,7 +75,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

@@ -54,7 +54,7 @@ struct GateBfArgs {
     GateEnc enc;              // mode 0 with the folded edge encoder
     GateBnBwd bnb;            // mode 3
 };
-int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& args, hipStream_t s);
+int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& args, hipStream_t s, bool x16 = false);
 // H = 256, affine norm, e_out != e_in: barrier-free streaming gate (edge_gate_stream.hip)
 int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn, const int32_t* ss,
                        const int32_t* sd, const float* W3, int ldw, const float* scale, const float* shift, hipStream_t s);
@@ -94,6 +94,34 @@ constexpr float kNormEps = 1e-5f;  // torch BatchNorm1d / LayerNorm default eps
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// bf16 STORAGE of training activations (the "x16" entry points): round to nearest even on the way out, exact on the way in.
+// Arithmetic stays fp32; only the bytes of the pre-normalisation gate output xe and of its gradient dxe in HBM are halved.
+__device__ __forceinline__ unsigned bf16_bits(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint2 pack_bf16x4(const f32x4 v) {
+    return make_uint2(bf16_bits(v[0]) | (bf16_bits(v[1]) << 16), bf16_bits(v[2]) | (bf16_bits(v[3]) << 16));
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(const uint2 p) {
+    return f32x4{__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xFFFF0000u), __uint_as_float(p.y << 16),
+                 __uint_as_float(p.y & 0xFFFF0000u)};
+}
+// a row piece of four values at element offset `off` of a tensor stored as fp32 (X16 = false) or bf16 (true)
+template <bool X16>
+__device__ __forceinline__ f32x4 load4_as(const void* base, int64_t off) {
+    if (X16) return unpack_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + off));
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
+}
+template <bool X16>
+__device__ __forceinline__ void store4_as(void* base, int64_t off, const f32x4 v) {
+    if (X16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + off) = pack_bf16x4(v);
+    else
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
+}
+
 
 // Give each XCD (private 4 MiB L2) a contiguous range of work items so that neighbouring tiles -
 // which share destination rows and, in layout-ordered assembly graphs, nearby source rows - hit

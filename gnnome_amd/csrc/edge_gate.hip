@@ -658,27 +658,39 @@ extern "C" int gnnome_edge_gate_raw_stats_rows(int hidden, int* rows_host) {
     return GNNOME_OK;
 }
 
-extern "C" int gnnome_edge_gate_raw_stats_f32(const float* e_in, float* x_out, int64_t num_edges, int hidden, const float* B1h,
-                                              const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
-                                              const float* W3, int ldw, const float* center, float* stats_partial, void* stream) {
+static int raw_stats_impl(const float* e_in, void* x_out, int64_t num_edges, int hidden, const float* B1h,
+                          const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
+                          const float* W3, int ldw, const float* center, float* stats_partial, void* stream, bool x16) {
     using namespace gnnome;
     GN_REQUIRE(num_edges > 0, "edge_gate_raw_stats: needs at least one edge");
-    GN_REQUIRE(e_in && x_out && x_out != e_in && B1h && B2h && srt_src && srt_dst && W3 && center && stats_partial,
+    GN_REQUIRE(e_in && x_out && x_out != (const void*)e_in && B1h && B2h && srt_src && srt_dst && W3 && center && stats_partial,
                "edge_gate_raw_stats: bad pointers");
     GN_REQUIRE(hidden == 64 || hidden == 128, "edge_gate_raw_stats: hidden=%d not in {64,128}", hidden);
     GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ldw >= hidden && ldw % 4 == 0, "edge_gate_raw_stats: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0) && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0),
                "edge_gate_raw_stats: 16-byte alignment required");
     hipStream_t s = (hipStream_t)stream;
-    if (tuning(kTuneGateVariant) == 0) {
+    if (tuning(kTuneGateVariant) == 0 || x16) {
         GateBfArgs a = {};
-        a.e_in = e_in; a.e_out = x_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
+        a.e_in = e_in; a.e_out = (float*)x_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
         a.srt_dst = srt_dst; a.W3 = W3; a.ldw = ldw; a.scale = center; a.stats = stats_partial;
-        return gate_bf_launch(hidden, 1, false, a, s);
+        return gate_bf_launch(hidden, 1, false, a, s, x16);
     }
     if (hidden == 128)
-        return launch_ws_raw_stats<4, 1>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, s);
-    return launch_ws_raw_stats<2, 2>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, s);
+        return launch_ws_raw_stats<4, 1>(e_in, (float*)x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, s);
+    return launch_ws_raw_stats<2, 2>(e_in, (float*)x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, s);
+}
+
+extern "C" int gnnome_edge_gate_raw_stats_f32(const float* e_in, float* x_out, int64_t num_edges, int hidden, const float* B1h,
+                                              const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
+                                              const float* W3, int ldw, const float* center, float* stats_partial, void* stream) {
+    return raw_stats_impl(e_in, x_out, num_edges, hidden, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, stream, false);
+}
+
+extern "C" int gnnome_edge_gate_raw_stats_x16(const float* e_in, uint16_t* x_out, int64_t num_edges, int hidden, const float* B1h,
+                                              const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
+                                              const float* W3, int ldw, const float* center, float* stats_partial, void* stream) {
+    return raw_stats_impl(e_in, x_out, num_edges, hidden, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, stream, true);
 }
 
 extern "C" int gnnome_edge_gate_encode_f32(const float* e_raw, const int32_t* srt_eid, const float* encW1, const float* encb1,

@@ -89,7 +89,9 @@ __device__ __forceinline__ bf16x8 as_bf(const uint4 v) { return __builtin_bit_ca
 // MODE 1: y = acc + G, G = B1h[src] + B2h[dst]          (raw gate of the training step) + shifted column sums (scale = centre)
 // MODE 2: y = acc + G, G = the old rows of C (in B1h)   (C += A W^T: the backward's d e_in = d e' + dxe W3)
 // MODE 3: MODE 2 with A = BatchNorm-backward(old rows of C, rows at e_in) computed by the load waves and written to bnb.a_out
-template <int CB, int RB, int MODE, bool ENC>
+// X16 (modes 1 and 3): the xe rows (mode 1: the output; mode 3: the rows at e_in) and the dxe rows (mode 3: bnb.a_out) are bf16 in
+// HBM - see common.h; mode 1's statistics are those of the ROUNDED values, the ones every later kernel reads.
+template <int CB, int RB, int MODE, bool ENC, bool X16 = false>
 __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
     using P = GateBF<CB, RB>;
     constexpr int H = P::H, TM = P::TM, NP = P::NP, LDK = P::LDK, RING = P::RING, KS = H / 16, SLOT = P::kSlotFloats;
@@ -233,7 +235,12 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
-                    av[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + 4 * c4);
+                    if (X16 && MODE == 3) {
+                        const uint2 pk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.e_in) + row * H + 4 * c4);
+                        av[p] = unpack_bf16x4(pk);
+                    } else {
+                        av[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + 4 * c4);
+                    }
                 }
             }
         };
@@ -312,7 +319,13 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
                         t[j] = ka[j] * (gm - k1[j] - (av[p][j] - km[j]) * kr[j] * k2[j]);
                     }
                     av[p] = t;
-                    if (r0 + p * RSTEP < valid3) *reinterpret_cast<f32x4*>(aout + (off_row + (unsigned)(p * RSTEP * H))) = t;
+                    if (r0 + p * RSTEP < valid3) {
+                        if (X16)
+                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.bnb.a_out) + (int64_t)tile_of(r) * TM * H +
+                                                      (off_row + (unsigned)(p * RSTEP * H))) = pack_bf16x4(t);
+                        else
+                            *reinterpret_cast<f32x4*>(aout + (off_row + (unsigned)(p * RSTEP * H))) = t;
+                    }
                 }
             }
 #pragma unroll
@@ -347,13 +360,22 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
                 } else {
                     y = x;
                 }
+                uint2 pk = {0u, 0u};
+                if (X16 && MODE == 1) {
+                    pk = pack_bf16x4(y);
+                    y = unpack_bf16x4(pk);
+                }
                 if (row < valid) {
                     if (MODE == 1) {
-                        const f32x4 d = x - sc4;
+                        const f32x4 d = y - sc4;
                         s1 += d;
                         s2 += d * d;
                     }
-                    if (!(a.abl & 2)) *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
+                    if (X16 && MODE == 1)
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.e_out) + (int64_t)tile_of(r) * TM * H +
+                                                  (off_row + (unsigned)(p * RSTEP * H))) = pk;
+                    else if (!(a.abl & 2))
+                        *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
                 }
                 if (a.abl & 2) asm volatile("" ::"v"(y[0] + y[1] + y[2] + y[3]));
             }
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
 
 static long long* g_gate_prof = nullptr;
 
-template <int CB, int RB, int MODE, bool ENC>
+template <int CB, int RB, int MODE, bool ENC, bool X16 = false>
 static int launch_bf(const GateBfArgs& args, hipStream_t s) {
     using P = GateBF<CB, RB>;
     GateBfArgs a = args;
@@ -400,12 +422,18 @@ static int launch_bf(const GateBfArgs& args, hipStream_t s) {
     a.xp = tuning(kTuneGateExperiment);
     a.prof = g_gate_prof;
     if (MODE == 1) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * kNumCUs * P::RING * P::LWAVES * 2 * P::H, s));   // idle waves leave zeros
-    hipLaunchKernelGGL((k_edge_gate_bf<CB, RB, MODE, ENC>), dim3(persistent_grid()), dim3(P::NT), 0, s, a);
+    hipLaunchKernelGGL((k_edge_gate_bf<CB, RB, MODE, ENC, X16>), dim3(persistent_grid()), dim3(P::NT), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
 
-int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStream_t s) {
+int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStream_t s, bool x16) {
+    if (x16) {   // bf16 storage of xe / dxe: modes 1 and 3 only
+        if (mode == 1) return hidden == 128 ? launch_bf<4, 1, 1, false, true>(a, s) : launch_bf<2, 2, 1, false, true>(a, s);
+        if (mode == 3) return hidden == 128 ? launch_bf<4, 1, 3, false, true>(a, s) : launch_bf<2, 2, 3, false, true>(a, s);
+        set_error("edge-tile kernel: bf16 storage exists for modes 1 and 3 only");
+        return GNNOME_EINVAL;
+    }
     if (hidden == 128) {
         if (mode == 0) return enc ? launch_bf<4, 1, 0, true>(a, s) : launch_bf<4, 1, 0, false>(a, s);
         if (mode == 3) return launch_bf<4, 1, 3, false>(a, s);
@@ -425,18 +453,30 @@ extern "C" int gnnome_debug_gate_profile(void* counters) {
 
 // C[M,H] += BatchNormBackward(C, X) W^T and dxe = BatchNormBackward(C, X) written out: gnnome_bn_bwd_apply_f32 followed by
 // gnnome_linear_acc_f32 in ONE pass over the [E,H] tensors (the A tile never comes from HBM: the load waves compute it).
-extern "C" int gnnome_bn_bwd_dgrad_f32(float* C, const float* X, int64_t rows, int hidden, const float* scale, const float* shift,
-                                       const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
-                                       const float* W, int ldw, float* dxe, void* stream) {
+static int bn_bwd_dgrad_impl(float* C, const void* X, int64_t rows, int hidden, const float* scale, const float* shift,
+                             const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
+                             const float* W, int ldw, void* dxe, void* stream, bool x16) {
     using namespace gnnome;
     GN_REQUIRE(rows >= 0 && (hidden == 64 || hidden == 128), "bn_bwd_dgrad: hidden=%d not in {64,128}", hidden);
     if (rows == 0) return GNNOME_OK;
-    GN_REQUIRE(C && X && scale && shift && a && c1 && c2 && mean && rstd && W && dxe && dxe != C && ldw >= hidden && ldw % 4 == 0,
+    GN_REQUIRE(C && X && scale && shift && a && c1 && c2 && mean && rstd && W && dxe && dxe != (void*)C && ldw >= hidden && ldw % 4 == 0,
                "bn_bwd_dgrad: bad arguments");
     GN_REQUIRE(((uintptr_t)C % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)dxe % 16 == 0) && ((uintptr_t)W % 16 == 0),
                "bn_bwd_dgrad: tensors must be 16-byte aligned");
     GateBfArgs g = {};
-    g.e_in = X; g.e_out = C; g.E = rows; g.B1h = C; g.ldn = hidden; g.W3 = W; g.ldw = ldw;
-    g.bnb = GateBnBwd{a, c1, c2, mean, rstd, scale, shift, dxe};
-    return gate_bf_launch(hidden, 3, false, g, (hipStream_t)stream);
+    g.e_in = (const float*)X; g.e_out = C; g.E = rows; g.B1h = C; g.ldn = hidden; g.W3 = W; g.ldw = ldw;
+    g.bnb = GateBnBwd{a, c1, c2, mean, rstd, scale, shift, (float*)dxe};
+    return gate_bf_launch(hidden, 3, false, g, (hipStream_t)stream, x16);
+}
+
+extern "C" int gnnome_bn_bwd_dgrad_f32(float* C, const float* X, int64_t rows, int hidden, const float* scale, const float* shift,
+                                       const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
+                                       const float* W, int ldw, float* dxe, void* stream) {
+    return bn_bwd_dgrad_impl(C, X, rows, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, false);
+}
+
+extern "C" int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows, int hidden, const float* scale, const float* shift,
+                                       const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
+                                       const float* W, int ldw, uint16_t* dxe, void* stream) {
+    return bn_bwd_dgrad_impl(C, X, rows, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, true);
 }

@@ -122,14 +122,15 @@ __global__ __launch_bounds__(kEwThreads) void k_bn_bwd_apply(const float* __rest
 }
 
 // out = relu(x * scale + shift) + res
-__global__ __launch_bounds__(kEwThreads) void k_bn_relu_res(const float* __restrict__ x, const float* __restrict__ scale,
+template <bool X16>
+__global__ __launch_bounds__(kEwThreads) void k_bn_relu_res(const void* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const float* __restrict__ res,
                                                             int64_t rows, int H, float* __restrict__ out) {
     const int64_t total = rows * (H / 4);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % (H / 4)) * 4;
         const int64_t off = (i / (H / 4)) * H + c;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+        const f32x4 xv = load4_as<X16>(x, off);
         const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
         f32x4 o;
 #pragma unroll
@@ -280,8 +281,8 @@ __global__ __launch_bounds__(256) void k_segment_sum(const float* __restrict__ X
 // sorted positions), out_out[i,:] = sum over its out-edge rows (reached through out_pos).  One wave per node, as the
 // aggregation kernel walks the same two lists: the out-edge pass finds most of its rows in L2, where the in-edge pass of
 // a neighbouring node has just put them - two separate launches stream X from HBM twice.
-template <int W>
-__global__ __launch_bounds__(256) void k_segment_sum2(const float* __restrict__ X, const int32_t* __restrict__ in_ptr,
+template <int W, bool X16>
+__global__ __launch_bounds__(256) void k_segment_sum2(const void* __restrict__ X, const int32_t* __restrict__ in_ptr,
                                                       const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos,
                                                       int64_t n_nodes, float* __restrict__ out_in, int ld_in, float* __restrict__ out_out,
                                                       int ld_out, int total_blocks) {
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void k_segment_sum2(const float* __restrict__ 
             for (int u = 0; u < U; ++u) {
                 const int q = q0 + u * G + group;
                 const int64_t p = q < e ? (side == 0 ? q : out_pos[q]) : 0;
-                v[u] = q < e ? *reinterpret_cast<const f32x4*>(X + p * W + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                v[u] = q < e ? load4_as<X16>(X, p * W + c) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) acc[side] += v[u];
@@ -391,15 +392,28 @@ extern "C" int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const fl
     return GNNOME_OK;
 }
 
-extern "C" int gnnome_bn_relu_res_f32(const float* x, const float* scale, const float* shift, const float* res, int64_t rows,
-                                      int hidden, float* out, void* stream) {
+static int bn_relu_res_impl(const void* x, bool x16, const float* scale, const float* shift, const float* res, int64_t rows, int hidden,
+                            float* out, void* stream) {
     GN_REQUIRE(rows >= 0 && hidden > 0 && hidden % 4 == 0, "bn_relu_res: bad shape");
     if (rows == 0) return GNNOME_OK;
     GN_REQUIRE(x && scale && shift && res && out, "bn_relu_res: null pointer");
-    hipLaunchKernelGGL(k_bn_relu_res, dim3(ew_grid(rows * (hidden / 4))), dim3(kEwThreads), 0, (hipStream_t)stream, x, scale, shift,
-                       res, rows, hidden, out);
+    const dim3 grid(ew_grid(rows * (hidden / 4)));
+    if (x16)
+        hipLaunchKernelGGL(k_bn_relu_res<true>, grid, dim3(kEwThreads), 0, (hipStream_t)stream, x, scale, shift, res, rows, hidden, out);
+    else
+        hipLaunchKernelGGL(k_bn_relu_res<false>, grid, dim3(kEwThreads), 0, (hipStream_t)stream, x, scale, shift, res, rows, hidden, out);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
+}
+
+extern "C" int gnnome_bn_relu_res_f32(const float* x, const float* scale, const float* shift, const float* res, int64_t rows,
+                                      int hidden, float* out, void* stream) {
+    return bn_relu_res_impl(x, false, scale, shift, res, rows, hidden, out, stream);
+}
+
+extern "C" int gnnome_bn_relu_res_x16(const uint16_t* x, const float* scale, const float* shift, const float* res, int64_t rows,
+                                      int hidden, float* out, void* stream) {
+    return bn_relu_res_impl(x, true, scale, shift, res, rows, hidden, out, stream);
 }
 
 extern "C" int gnnome_ln_relu_res_f32(const float* x, const float* gamma, const float* beta, const float* res, int64_t rows,
@@ -555,13 +569,13 @@ extern "C" int gnnome_gate_center_f32(const float* e, int64_t num_edges, int hid
 // (m = relu mask rebuilt from the forward's expression).  One read of xe here replaces gnnome_bn_bwd_stats_f32's reads of de'
 // and xe.
 namespace gnnome {
-template <int H>
+template <int H, bool X16>
 __global__ __launch_bounds__(kEwThreads) void k_agg_edge_bwd_stats(const float* __restrict__ e, int64_t E, const float* __restrict__ Tf,
                                                                    const float* __restrict__ Uf, const float* __restrict__ Tb,
                                                                    const float* __restrict__ Ub, const float* __restrict__ A2h,
                                                                    const float* __restrict__ A3h, int ldn,
                                                                    const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst,
-                                                                   float* __restrict__ de, const float* __restrict__ xe,
+                                                                   float* __restrict__ de, const void* __restrict__ xe,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ mean, float* __restrict__ part) {
     column_reduce<2>(E, H, part, [&](int64_t p, int c, f32x4 (&acc)[2]) {
@@ -570,7 +584,7 @@ __global__ __launch_bounds__(kEwThreads) void k_agg_edge_bwd_stats(const float* 
         const f32x4 tf = *reinterpret_cast<const f32x4*>(Tf + d_ * H + c), uf = *reinterpret_cast<const f32x4*>(Uf + d_ * H + c);
         const f32x4 tb = *reinterpret_cast<const f32x4*>(Tb + s_ * H + c), ub = *reinterpret_cast<const f32x4*>(Ub + s_ * H + c);
         const f32x4 a2 = *reinterpret_cast<const f32x4*>(A2h + s_ * ldn + c), a3 = *reinterpret_cast<const f32x4*>(A3h + d_ * ldn + c);
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xe + p * H + c);
+        const f32x4 xv = load4_as<X16>(xe, p * H + c);
         f32x4 g = *reinterpret_cast<const f32x4*>(de + p * H + c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -585,11 +599,11 @@ __global__ __launch_bounds__(kEwThreads) void k_agg_edge_bwd_stats(const float* 
 }
 }  // namespace gnnome
 
-extern "C" int gnnome_agg_edge_bwd_stats_f32(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
-                                             const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
-                                             const int32_t* srt_src, const int32_t* srt_dst, float* de, const float* xe,
-                                             const float* scale, const float* shift, const float* mean, float* s1, float* s2,
-                                             void* workspace, size_t workspace_bytes, void* stream) {
+static int agg_edge_bwd_stats_impl(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                                   const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
+                                   const int32_t* srt_src, const int32_t* srt_dst, float* de, const void* xe, bool x16,
+                                   const float* scale, const float* shift, const float* mean, float* s1, float* s2,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
     using namespace gnnome;
     GN_REQUIRE(num_edges >= 0, "agg_edge_bwd_stats: negative edge count");
     if (num_edges == 0) return GNNOME_OK;
@@ -599,20 +613,42 @@ extern "C" int gnnome_agg_edge_bwd_stats_f32(const float* e, int64_t num_edges, 
                "agg_edge_bwd_stats: workspace too small or misaligned (gnnome_colsum_workspace_bytes)");
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = col_grid(num_edges, hidden);
+#define GN_AEBS(HH, XX)                                                                                                              \
+    hipLaunchKernelGGL((k_agg_edge_bwd_stats<HH, XX>), dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, \
+                       srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace)
     switch (hidden) {
-        case 64: hipLaunchKernelGGL(k_agg_edge_bwd_stats<64>, dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace); break;
-        case 128: hipLaunchKernelGGL(k_agg_edge_bwd_stats<128>, dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace); break;
-        case 256: hipLaunchKernelGGL(k_agg_edge_bwd_stats<256>, dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace); break;
+        case 64: if (x16) GN_AEBS(64, true); else GN_AEBS(64, false); break;
+        case 128: if (x16) GN_AEBS(128, true); else GN_AEBS(128, false); break;
+        case 256: if (x16) GN_AEBS(256, true); else GN_AEBS(256, false); break;
         default: set_error("agg_edge_bwd_stats: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
+#undef GN_AEBS
     GN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, s, (const float*)workspace, (int)grid, hidden, s1, s2);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
 
-extern "C" int gnnome_segment_sum2_f32(const float* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
-                                       int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream) {
+extern "C" int gnnome_agg_edge_bwd_stats_f32(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                                             const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
+                                             const int32_t* srt_src, const int32_t* srt_dst, float* de, const float* xe,
+                                             const float* scale, const float* shift, const float* mean, float* s1, float* s2,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+    return agg_edge_bwd_stats_impl(e, num_edges, hidden, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de, xe, false, scale, shift,
+                                   mean, s1, s2, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gnnome_agg_edge_bwd_stats_x16(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                                             const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
+                                             const int32_t* srt_src, const int32_t* srt_dst, float* de, const uint16_t* xe,
+                                             const float* scale, const float* shift, const float* mean, float* s1, float* s2,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+    return agg_edge_bwd_stats_impl(e, num_edges, hidden, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, srt_src, srt_dst, de, xe, true, scale, shift,
+                                   mean, s1, s2, workspace, workspace_bytes, stream);
+}
+
+static int segment_sum2_impl(const void* X, bool x16, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
+                             int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream) {
     using namespace gnnome;
     GN_REQUIRE(num_nodes >= 0, "segment_sum2: negative node count");
     if (num_nodes == 0) return GNNOME_OK;
@@ -620,13 +656,27 @@ extern "C" int gnnome_segment_sum2_f32(const float* X, int width, const int32_t*
                "segment_sum2: bad arguments");
     const unsigned blocks = (unsigned)((num_nodes + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
+#define GN_SS2(WW, XX)                                                                                                                    \
+    hipLaunchKernelGGL((k_segment_sum2<WW, XX>), dim3(blocks), dim3(256), 0, s, X, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, \
+                       ld_out, (int)blocks)
     switch (width) {
-        case 64: hipLaunchKernelGGL(k_segment_sum2<64>, dim3(blocks), dim3(256), 0, s, X, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, (int)blocks); break;
-        case 128: hipLaunchKernelGGL(k_segment_sum2<128>, dim3(blocks), dim3(256), 0, s, X, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, (int)blocks); break;
-        case 256: hipLaunchKernelGGL(k_segment_sum2<256>, dim3(blocks), dim3(256), 0, s, X, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, (int)blocks); break;
-        case 32: hipLaunchKernelGGL(k_segment_sum2<32>, dim3(blocks), dim3(256), 0, s, X, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, (int)blocks); break;
+        case 64: if (x16) GN_SS2(64, true); else GN_SS2(64, false); break;
+        case 128: if (x16) GN_SS2(128, true); else GN_SS2(128, false); break;
+        case 256: if (x16) GN_SS2(256, true); else GN_SS2(256, false); break;
+        case 32: if (x16) GN_SS2(32, true); else GN_SS2(32, false); break;
         default: set_error("segment_sum2: width=%d not in {32,64,128,256}", width); return GNNOME_EINVAL;
     }
+#undef GN_SS2
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
+}
+
+extern "C" int gnnome_segment_sum2_f32(const float* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
+                                       int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream) {
+    return segment_sum2_impl(X, false, width, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, stream);
+}
+
+extern "C" int gnnome_segment_sum2_x16(const uint16_t* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
+                                       int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream) {
+    return segment_sum2_impl(X, true, width, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, stream);
 }

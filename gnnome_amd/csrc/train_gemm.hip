@@ -36,6 +36,7 @@ struct WgradA {
     int width;   // >= Ka for a single buffer
 };
 
+template <bool X16>   // X16: A is stored as bf16 (the dxe rows of the bf16-storage training step)
 __global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, int Ka, const float* __restrict__ B,
                                                           int ldb, int Kb, int64_t R, int64_t rows_per_chunk,
                                                           float* __restrict__ partial, float* __restrict__ colsum_part) {
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, 
             if (which == k) a_col = a_op.blk[k];   // a select chain: no dynamic indexing of the kernel arguments
         a_col += ca - which * a_op.width;
     }
+    const void* a_base16 = a_op.blk[0];                       // X16: one buffer of bf16, element offsets
+    const int64_t a_off16 = a_in ? i0 + 4 * c4 : 0;
     const float* b_col = B + j0 + 4 * c4;
     const bool sums = colsum_part != nullptr && blockIdx.y == 0;
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, 
             const int64_t row = r0 + 4 * rr + t;
             av[t] = bv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row < r_end) {
-                if (a_in) av[t] = *reinterpret_cast<const f32x4*>(a_col + row * lda);
+                if (a_in) av[t] = X16 ? load4_as<true>(a_base16, a_off16 + row * lda) : *reinterpret_cast<const f32x4*>(a_col + row * lda);
                 if (b_in) bv[t] = *reinterpret_cast<const f32x4*>(b_col + row * ldb);
             }
         }
@@ -321,7 +324,7 @@ extern "C" int gnnome_wgrad_workspace_bytes(int64_t rows, int Ka, int Kb, size_t
 }
 
 static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C, int ldc,
-                      float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+                      float* colsum, void* workspace, size_t workspace_bytes, void* stream, bool x16 = false) {
     GN_REQUIRE(rows >= 0 && Ka > 0 && Kb > 0 && Ka % 4 == 0 && Kb % 4 == 0, "wgrad: Ka=%d Kb=%d must be positive multiples of 4", Ka, Kb);
     GN_REQUIRE(C && ldc >= Kb, "wgrad: bad output");
     hipStream_t s = (hipStream_t)stream;
@@ -342,7 +345,10 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
     float* partial = (float*)workspace;
     float* colsum_part = colsum ? partial + (size_t)chunks * Ka * Kb : nullptr;
     const dim3 grid((Ka + kWgTile - 1) / kWgTile, (Kb + kWgTile - 1) / kWgTile, (unsigned)chunks);
-    hipLaunchKernelGGL(k_wgrad_partial, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
+    if (x16)
+        hipLaunchKernelGGL(k_wgrad_partial<true>, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
+    else
+        hipLaunchKernelGGL(k_wgrad_partial<false>, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
     GN_LAUNCH_CHECK();
     const int64_t elems = (int64_t)Ka * Kb;
     const int c_blocks = (int)((elems + 63) / 64), s_blocks = colsum ? (Ka + 63) / 64 : 0;
@@ -359,6 +365,16 @@ extern "C" int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B,
     a_op.blk[0] = A;
     a_op.width = Ka > 0 ? Ka : 1;
     return wgrad_impl(a_op, lda, Ka, B, ldb, Kb, rows, C, ldc, nullptr, workspace, workspace_bytes, stream);
+}
+
+// A stored as bf16 ([rows, Ka], row stride lda ELEMENTS, 8-byte aligned rows): the weight gradient of B_3 from the bf16 dxe
+extern "C" int gnnome_wgrad_x16(const uint16_t* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C,
+                                int ldc, void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(rows == 0 || (A && lda >= Ka && (uintptr_t)A % 8 == 0), "wgrad_x16: bad operands");
+    WgradA a_op = {};
+    a_op.blk[0] = reinterpret_cast<const float*>(A);
+    a_op.width = Ka > 0 ? Ka : 1;
+    return wgrad_impl(a_op, lda, Ka, B, ldb, Kb, rows, C, ldc, nullptr, workspace, workspace_bytes, stream, true);
 }
 
 extern "C" int gnnome_wgrad_blocks_f32(const float* const* A_blocks, int num_blocks, int block_width, int lda, const float* B, int ldb,

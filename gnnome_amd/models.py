@@ -16,6 +16,8 @@ weights/weights.pt, same call.  Differences, all deliberate:
     matrix-core kernels and kernels that evaluate the layer's dense products in the reference's own ORDER (bit for bit
     what torch's CPU nn.Linear computes); "auto" uses the latter for layers whose eval-BatchNorm gain magnifies fp32
     reorder noise (engine.REFERENCE_ORDER_GAIN; the shipped checkpoint's layer 0).  Eval mode only.
+  * `model.activation_storage` ("fp32" | "bf16", default "fp32"; train mode only): "bf16" keeps the pre-normalisation gate output
+    and its gradient in HBM as bfloat16 between the kernels of the training step (gnnome_amd/train.py; arithmetic stays fp32).
 """
 import torch.nn as nn
 
@@ -25,6 +27,7 @@ from .layers import ScorePredictor, SymGatedGCN_processor
 
 class SymGatedGCNModel(nn.Module):
     arithmetic = "auto"
+    activation_storage = "fp32"
 
     def __init__(self, node_features, edge_features, hidden_features, hidden_ne_features, num_layers,
                  hidden_edge_scores, normalization, dropout=None):

@@ -43,6 +43,14 @@ def _f32(t, name):
     return t
 
 
+def _act(t, name):
+    """A contiguous CUDA activation tensor in either storage type of the training step: float32, or bfloat16 (the xe / dxe
+    rows of `activation_storage="bf16"`, read and written by the *_x16 entry points) -> (tensor, is_bf16)."""
+    if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_cuda or not t.is_contiguous():
+        raise TypeError(f"{name}: expected a contiguous CUDA float32 or bfloat16 tensor, got {t.dtype} on {t.device}")
+    return t, t.dtype == torch.bfloat16
+
+
 def _i32(t, name):
     if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
         raise TypeError(f"{name}: expected a contiguous CUDA int32 tensor, got {t.dtype} on {t.device}")
@@ -429,11 +437,13 @@ def batch_moments(x):
     return d1, d2, c, x.shape[0]
 
 
-def edge_gate_raw_moments(e, B1h, B2h, views, W3):
+def edge_gate_raw_moments(e, B1h, B2h, views, W3, storage=torch.float32):
     """-> (xe, (d1, d2, center, E)): the raw gate and the shifted column sums of its rows, ONE pass over [E,H] (the kernel
-    leaves per-workgroup partial sums, colsum2 adds them up in a fixed order); H in {64,128}, all E rows."""
+    leaves per-workgroup partial sums, colsum2 adds them up in a fixed order); H in {64,128}, all E rows.
+    storage=torch.bfloat16: xe is rounded to bf16 on the way out and the sums are those of the rounded values."""
     H, E = e.shape[1], e.shape[0]
     e = _dense(e, "edge_gate_raw_moments.e")
+    x16 = storage == torch.bfloat16
     B1h, ldn = _rows(B1h, "edge_gate_raw_moments.B1h")
     B2h, _ = _rows(B2h, "edge_gate_raw_moments.B2h")
     W3, ldw = _rows(W3, "edge_gate_raw_moments.W3")
@@ -443,9 +453,9 @@ def edge_gate_raw_moments(e, B1h, B2h, views, W3):
     rows = ctypes.c_int(0)
     _lib.check(_lib.load().gnnome_edge_gate_raw_stats_rows(H, ctypes.byref(rows)), "edge_gate_raw_stats_rows")
     partial = torch.empty((rows.value, 2 * H), dtype=torch.float32, device=e.device)
-    out = torch.empty_like(e)
-    _call("gnnome_edge_gate_raw_stats_f32", e.device, _ptr(e), _ptr(out), E, H, _ptr(B1h), _ptr(B2h), ldn, _ptr(views.srt_src),
-          _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(center), _ptr(partial))
+    out = torch.empty_like(e, dtype=torch.bfloat16 if x16 else torch.float32)
+    _call("gnnome_edge_gate_raw_stats_x16" if x16 else "gnnome_edge_gate_raw_stats_f32", e.device, _ptr(e), _ptr(out), E, H, _ptr(B1h),
+          _ptr(B2h), ldn, _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(center), _ptr(partial))
     sums = colsum2(partial)[0]
     return out, (sums[:H], sums[H:], center, E)
 
@@ -468,9 +478,10 @@ def bn_train_finish(moments, weight, bias, running_mean, running_var, num_batche
 
 
 def bn_relu_res(x, scale, shift, res, out=None):
-    x, res = _dense(x, "bn_relu_res.x"), _dense(res, "bn_relu_res.res")
-    out = torch.empty_like(x) if out is None else _dense(out, "bn_relu_res.out")
-    _call("gnnome_bn_relu_res_f32", x.device, _ptr(x), _ptr(scale), _ptr(shift), _ptr(res), x.shape[0], x.shape[1], _ptr(out))
+    (x, x16), res = _act(x, "bn_relu_res.x"), _dense(res, "bn_relu_res.res")
+    out = torch.empty_like(res) if out is None else _dense(out, "bn_relu_res.out")
+    _call("gnnome_bn_relu_res_x16" if x16 else "gnnome_bn_relu_res_f32", x.device, _ptr(x), _ptr(scale), _ptr(shift), _ptr(res), x.shape[0],
+          x.shape[1], _ptr(out))
     return out
 
 
@@ -543,21 +554,23 @@ def segment_sum(X, ptr, pos, num_nodes, out=None):
 def segment_sum2(X, views, num_nodes, out_in=None, out_out=None):
     """(sum over in-edge rows, sum over out-edge rows) of X[E,W] per node, one launch; outputs may be column blocks of a
     wider table (row-strided)."""
-    X = _dense(X, "segment_sum2.X")
+    X, x16 = _act(X, "segment_sum2.X")
     W = X.shape[1]
     mk = lambda: torch.empty((num_nodes, W), dtype=torch.float32, device=X.device)  # noqa: E731
     out_in = mk() if out_in is None else out_in
     out_out = mk() if out_out is None else out_out
     out_in, ld_in = _rows(out_in, "segment_sum2.out_in")
     out_out, ld_out = _rows(out_out, "segment_sum2.out_out")
-    _call("gnnome_segment_sum2_f32", X.device, _ptr(X), W, _ptr(views.in_ptr), _ptr(views.out_ptr), _ptr(views.out_pos), num_nodes,
+    _call("gnnome_segment_sum2_x16" if x16 else "gnnome_segment_sum2_f32", X.device, _ptr(X), W, _ptr(views.in_ptr), _ptr(views.out_ptr), _ptr(views.out_pos), num_nodes,
           _ptr(out_in), ld_in, _ptr(out_out), ld_out)
     return out_in, out_out
 
 
 def wgrad(A, B, out=None):
-    """out[Ka,Kb] = A^T @ B over the rows (nn.Linear weight gradient dW = dY^T X)."""
-    A, lda = _rows(A, "wgrad.A")
+    """out[Ka,Kb] = A^T @ B over the rows (nn.Linear weight gradient dW = dY^T X).  A may be a contiguous bfloat16 tensor
+    (the dxe rows of the bf16-storage training step)."""
+    x16 = A.dtype == torch.bfloat16
+    A, lda = (_act(A, "wgrad.A")[0], A.shape[1]) if x16 else _rows(A, "wgrad.A")
     B, ldb = _rows(B, "wgrad.B")
     rows, Ka, Kb = A.shape[0], A.shape[1], B.shape[1]
     if out is None:
@@ -566,7 +579,8 @@ def wgrad(A, B, out=None):
     need = ctypes.c_size_t(0)
     _lib.check(_lib.load().gnnome_wgrad_workspace_bytes(rows, Ka, Kb, ctypes.byref(need)), "wgrad_workspace_bytes")
     ws = torch.empty(max(int(need.value), 4), dtype=torch.uint8, device=A.device)
-    _call("gnnome_wgrad_f32", A.device, _ptr(A), lda, Ka, _ptr(B), ldb, Kb, rows, _ptr(out), ldc, _ptr(ws), ws.numel())
+    _call("gnnome_wgrad_x16" if x16 else "gnnome_wgrad_f32", A.device, _ptr(A), lda, Ka, _ptr(B), ldb, Kb, rows, _ptr(out), ldc, _ptr(ws),
+          ws.numel())
     return out
 
 
@@ -641,10 +655,10 @@ def can_fuse_bn_bwd_dgrad(de, W):
 def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt):
     """dxe = BatchNorm-backward(de, xe) (as bn_bwd_apply) and de += dxe @ Wt.T in ONE pass (gnnome_bn_bwd_dgrad_f32): the
     edge-tile kernel's load waves compute the A tile instead of reading it.  Returns dxe; de is updated in place."""
-    de, xe = _dense(de, "bn_bwd_dgrad.de"), _dense(xe, "bn_bwd_dgrad.xe")
+    de, (xe, x16) = _dense(de, "bn_bwd_dgrad.de"), _act(xe, "bn_bwd_dgrad.xe")
     Wt, ldw = _rows(Wt, "bn_bwd_dgrad.W")
-    dxe = torch.empty_like(de)
-    _call("gnnome_bn_bwd_dgrad_f32", de.device, _ptr(de), _ptr(xe), de.shape[0], de.shape[1], _ptr(scale), _ptr(shift), _ptr(a), _ptr(c1),
+    dxe = torch.empty_like(xe)     # dxe is stored the way xe is
+    _call("gnnome_bn_bwd_dgrad_x16" if x16 else "gnnome_bn_bwd_dgrad_f32", de.device, _ptr(de), _ptr(xe), de.shape[0], de.shape[1], _ptr(scale), _ptr(shift), _ptr(a), _ptr(c1),
           _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))
     return dxe
 
@@ -656,8 +670,10 @@ def agg_edge_bwd_stats(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift,
     H = e.shape[1]
     s = (torch.empty if e.shape[0] > 0 else torch.zeros)((2, H), dtype=torch.float32, device=e.device)
     ws = _col_workspace(e.device)
-    _call("gnnome_agg_edge_bwd_stats_f32", e.device, _ptr(_dense(e, "e")), e.shape[0], H, _ptr(Tf), _ptr(Uf), _ptr(Tb), _ptr(Ub), _ptr(A2h),
-          _ptr(A3h), ldn, _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(_dense(de, "de")), _ptr(_dense(xe, "xe")), _ptr(scale), _ptr(shift),
+    xe, x16 = _act(xe, "agg_edge_bwd_stats.xe")
+    _call("gnnome_agg_edge_bwd_stats_x16" if x16 else "gnnome_agg_edge_bwd_stats_f32", e.device, _ptr(_dense(e, "e")), e.shape[0], H, _ptr(Tf),
+          _ptr(Uf), _ptr(Tb), _ptr(Ub), _ptr(A2h), _ptr(A3h), ldn, _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(_dense(de, "de")), _ptr(xe),
+          _ptr(scale), _ptr(shift),
           _ptr(mean), _ptr(s[0]), _ptr(s[1]), _ptr(ws), ws.numel())
     return de, s[0], s[1]
 

@@ -125,6 +125,24 @@ def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out, stats=None, 
     return s2h, s1
 
 
+ACTIVATION_STORAGE = ("fp32", "bf16")
+
+
+def _storage_dtype(model):
+    """`model.activation_storage`: "fp32" (the reference's arithmetic, the default) or "bf16" - the pre-normalisation gate output
+    xe and its gradient dxe are kept in HBM as bfloat16 between the kernels of the training step (BASELINE configs[2]; a sixth of
+    the step's traffic).  All arithmetic, every statistic and the residual streams e / e' / de / h stay fp32."""
+    kind = getattr(model, "activation_storage", "fp32")
+    if kind not in ACTIVATION_STORAGE:
+        raise ValueError(f"activation_storage={kind!r} not in {ACTIVATION_STORAGE}")
+    return torch.bfloat16 if kind == "bf16" else torch.float32
+
+
+def _no_bf16_storage():
+    return ValueError('activation_storage="bf16" is built for the fused single-rank BatchNorm step at hidden_features 64 / 128 '
+                      "(normalization='batch', momentum set, one process); use \"fp32\" here")
+
+
 class _TrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, sh, x, e_raw, names, *params):
@@ -136,6 +154,7 @@ class _TrainStep(torch.autograd.Function):
         blk = lambda P, k: P[:, r[k] * H:(r[k] + 1) * H]  # noqa: E731
         d = lambda t: t.detach().contiguous()  # noqa: E731
         new = lambda rows, cols: torch.empty((rows, cols), dtype=torch.float32, device=x.device)  # noqa: E731
+        storage = _storage_dtype(model)
 
         h = ops.encode(x, d(model.linear1_node.weight), d(model.linear1_node.bias), d(model.linear2_node.weight), d(model.linear2_node.bias))
         e = ops.encode(e_raw, d(model.linear1_edge.weight), d(model.linear1_edge.bias), d(model.linear2_edge.weight),
@@ -151,13 +170,17 @@ class _TrainStep(torch.autograd.Function):
             if n_local > n_own:
                 ops.linear(h[n_own:], Wcat, bcat, out=P[n_own:])
             mean_e = rstd_e = sc_e = sh_e = mean_h = rstd_h = sc_h = sh_h = None
+            if layer_norm and storage != torch.float32:
+                raise _no_bf16_storage()
             if layer_norm:   # per-row statistics: nothing crosses rows (or ranks), and there are no running buffers
                 xe = ops.edge_gate_raw(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight))
                 e_new = ops.ln_relu_res(xe, d(conv.bn_e.weight), d(conv.bn_e.bias), e)
             else:
                 if _can_fuse_bn(sh, conv.bn_e) and ops.can_fuse_gate_moments(e, blk(P, "B1"), blk(P, "B2")):
-                    xe, mom = ops.edge_gate_raw_moments(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight))
+                    xe, mom = ops.edge_gate_raw_moments(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight), storage=storage)
                     mean_e, rstd_e, sc_e, sh_e = _bn_train_fused(sh, conv.bn_e, mom, updates=2)
+                elif storage != torch.float32:
+                    raise _no_bf16_storage()
                 else:
                     xe, m_e, v_e = ops.edge_gate_raw_stats(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight), rows_stats=e_own)
                     mean_e, rstd_e, sc_e, sh_e = _bn_train(sh, conv.bn_e, m_e, v_e, e_own, sh.e_global, updates=2)
@@ -284,6 +307,8 @@ class _TrainStep(torch.autograd.Function):
                                                                                    sh.e_global, e_own, None, stats=stats_e, apply=False)
                     dxe = ops.bn_bwd_dgrad(de, s["xe"], s["sc_e"], s["sh_e"], s["sc_e"], c1, c2, s["mean_e"], s["rstd_e"], W3t)
                     W3t = None
+                elif s["xe"].dtype != torch.float32:
+                    raise _no_bf16_storage()
                 else:
                     dxe = torch.empty_like(de)
                     g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],

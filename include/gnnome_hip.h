@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 4
+#define GNNOME_ABI_VERSION 5
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -394,6 +394,31 @@ int gnnome_greedy_walks(const int32_t* succ_ptr, const int32_t* succ_nbr, const 
  * succs[ss] & preds[dd] and their mates (inference.py:313-318, :334). */
 int gnnome_mark_walk_visited(const int32_t* succ_ptr, const int32_t* succ_nbr, const int32_t* walk, int64_t walk_len,
                              uint8_t* visited, void* stream);
+
+/* ---- bf16 STORAGE of two training activations (activation_storage = "bf16", BASELINE configs[2]) ------------------------------
+ * The reference trains in fp32 throughout; as an OPTION the pre-normalisation gate output xe[E,H] (written once, read three
+ * times per layer) and its gradient dxe[E,H] (written once, read twice) can live in HBM as bfloat16 - rounded to nearest even
+ * when written, widened exactly when read; every sum, product and statistic is still fp32, and the residual streams e, e', de,
+ * h stay fp32 (|e| reaches several hundred with per-layer updates of order one: bf16 there would drop the updates).  Each entry
+ * is its _f32 namesake with the marked tensor as uint16_t (bf16 bits), contiguous, 8-byte aligned:
+ *   raw_stats: x_out (the statistics are those of the ROUNDED values);  bn_relu_res: x;  agg_edge_bwd_stats: xe;
+ *   bn_bwd_dgrad: X and dxe (C += dxe W^T uses the unrounded dxe);  segment_sum2: X;  wgrad: A (lda in elements). */
+int gnnome_edge_gate_raw_stats_x16(const float* e_in, uint16_t* x_out, int64_t num_edges, int hidden, const float* B1h, const float* B2h,
+                                   int ld_node, const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw,
+                                   const float* center, float* stats_partial, void* stream);
+int gnnome_bn_relu_res_x16(const uint16_t* x, const float* scale, const float* shift, const float* res, int64_t rows, int hidden,
+                           float* out, void* stream);
+int gnnome_agg_edge_bwd_stats_x16(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf, const float* Tb,
+                                  const float* Ub, const float* A2h, const float* A3h, int ld_node, const int32_t* srt_src,
+                                  const int32_t* srt_dst, float* de, const uint16_t* xe, const float* scale, const float* shift,
+                                  const float* mean, float* s1, float* s2, void* workspace, size_t workspace_bytes, void* stream);
+int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows, int hidden, const float* scale, const float* shift, const float* a,
+                            const float* c1, const float* c2, const float* mean, const float* rstd, const float* W, int ldw,
+                            uint16_t* dxe, void* stream);
+int gnnome_segment_sum2_x16(const uint16_t* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
+                            int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream);
+int gnnome_wgrad_x16(const uint16_t* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C, int ldc,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

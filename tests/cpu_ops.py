@@ -193,9 +193,9 @@ def batch_moments(x):
     return (x - c).sum(0), ((x - c) ** 2).sum(0), c, x.shape[0]
 
 
-def edge_gate_raw_moments(e, B1h, B2h, views, W3):
-    xe = edge_gate_raw(e, B1h, B2h, views, W3)
-    return xe, batch_moments(xe)
+def edge_gate_raw_moments(e, B1h, B2h, views, W3, storage=torch.float32):
+    xe = edge_gate_raw(e, B1h, B2h, views, W3).to(storage)     # bf16 storage: rounded to nearest even, statistics of the rounded rows
+    return xe, batch_moments(xe.float())
 
 
 def can_fuse_gate_moments(e, B1h, B2h):
@@ -220,7 +220,7 @@ def bn_train_finish(moments, weight, bias, running_mean, running_var, num_batche
 
 
 def bn_relu_res(x, scale, shift, res, out=None):
-    y = torch.relu(x * scale + shift) + res
+    y = torch.relu(x.float() * scale + shift) + res
     if out is None:
         return y
     out.copy_(y)
@@ -294,7 +294,7 @@ def segment_sum(X, ptr, pos, num_nodes, out=None):
 
 
 def wgrad(A, B, out=None):
-    res = A.t() @ B
+    res = A.float().t() @ B
     if out is None:
         return res
     out.copy_(res)
@@ -344,7 +344,7 @@ def encode_hidden(x, W1, b1, gather=None, rows=None):
 
 def agg_edge_bwd_stats(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift, mean):
     agg_edge_bwd(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de)
-    s1, s2 = bn_bwd_stats(de, xe, scale, shift, mean)
+    s1, s2 = bn_bwd_stats(de, xe.float(), scale, shift, mean)
     return de, s1, s2
 
 
@@ -353,12 +353,13 @@ def can_fuse_bn_bwd_dgrad(de, W):
 
 
 def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt):
-    dxe = bn_bwd_apply(de, xe, scale, shift, a, c1, c2, mean, rstd)
+    dxe = bn_bwd_apply(de, xe.float(), scale, shift, a, c1, c2, mean, rstd)
     de.add_(dxe @ Wt.t())
-    return dxe
+    return dxe.to(xe.dtype)     # stored the way xe is; the product above used the unrounded values
 
 
 def segment_sum2(X, views, num_nodes, out_in=None, out_out=None):
+    X = X.float()
     a = segment_sum(X, views.in_ptr, None, num_nodes, out=out_in)
     b = segment_sum(X, views.out_ptr, views.out_pos, num_nodes, out=out_out)
     return a, b

@@ -367,6 +367,93 @@ def test_fused_backward_kernels_equal_their_unfused_pairs(hidden, e):
     assert (c - want_c).abs().max().item() <= 2e-5 * max(1.0, want_c.abs().max().item())
 
 
+@pytest.mark.parametrize("hidden,e", [(128, 50_001), (64, 7000), (128, 31)])
+def test_bf16_storage_kernels_equal_the_fp32_kernels_on_rounded_tensors(hidden, e):
+    """The *_x16 entry points (xe / dxe stored as bfloat16): each equals its _f32 namesake fed the SAME values widened to fp32
+    (reads are exact), and what they write is the fp32 result rounded to nearest even."""
+    g = torch.Generator().manual_seed(hidden * 3 + e)
+    n, H = 500, hidden
+    src, dst = torch.randint(0, n, (e,), generator=g).int(), torch.randint(0, n, (e,), generator=g).int()
+    views = ops.GraphViews(src.to(dev()), dst.to(dev()), n)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev())  # noqa: E731
+    bf = torch.bfloat16
+    # raw gate: bf16 output = RNE of the fp32 output; moments = those of the rounded rows
+    ee, P, W3 = 2 * r(e, H), r(n, 2 * H), (torch.randn(H, H, generator=g) / H ** 0.5).to(dev())
+    x32, _ = ops.edge_gate_raw_moments(ee, P[:, :H], P[:, H:], views, W3)
+    x16, (d1, d2, c, rows) = ops.edge_gate_raw_moments(ee, P[:, :H], P[:, H:], views, W3, storage=bf)
+    assert x16.dtype == bf and torch.equal(x16, x32.to(bf)) and rows == e
+    xr = x16.double().cpu()
+    close(d1, (xr - c.double().cpu()).sum(0), tol=1e-6, scale=e * 8)      # fp32 sums of e terms of size ~8
+    close(d2, ((xr - c.double().cpu()) ** 2).sum(0), tol=1e-6, scale=e * 64)
+    # consumers: identical to the fp32 kernels on the widened tensor
+    scale, shift, mean = (torch.rand(H, generator=g) + 0.5).to(dev()), r(H), r(H)
+    assert torch.equal(ops.bn_relu_res(x16, scale, shift, ee), ops.bn_relu_res(x16.float(), scale, shift, ee))
+    Tf, Uf, Tb, Ub, de0 = r(n, H), r(n, H), r(n, H), r(n, H), r(e, H)
+    a_ = ops.agg_edge_bwd_stats(ee, Tf, Uf, Tb, Ub, P[:, :H], P[:, H:], views, de0.clone(), x16, scale, shift, mean)
+    b_ = ops.agg_edge_bwd_stats(ee, Tf, Uf, Tb, Ub, P[:, :H], P[:, H:], views, de0.clone(), x16.float(), scale, shift, mean)
+    assert all(torch.equal(u, v) for u, v in zip(a_, b_))
+    a, c1, c2, rstd = r(H), 0.1 * r(H), 0.1 * r(H), (torch.rand(H, generator=g) + 0.5).to(dev())
+    ca, cb = a_[0].clone(), a_[0].clone()
+    dx16 = ops.bn_bwd_dgrad(ca, x16, scale, shift, a, c1, c2, mean, rstd, W3)
+    dx32 = ops.bn_bwd_dgrad(cb, x16.float(), scale, shift, a, c1, c2, mean, rstd, W3)
+    assert dx16.dtype == bf and torch.equal(dx16, dx32.to(bf)) and torch.equal(ca, cb)     # the product used the unrounded dxe
+    si, so = ops.segment_sum2(dx16, views, n)
+    ti, to = ops.segment_sum2(dx16.float(), views, n)
+    assert torch.equal(si, ti) and torch.equal(so, to)
+    assert torch.equal(ops.wgrad(dx16, ee), ops.wgrad(dx16.float(), ee))
+
+
+def test_bf16_activation_storage_training_step():
+    """activation_storage="bf16" (BASELINE configs[2]): same step with xe / dxe stored as bfloat16.  Pinned two ways: the HIP step
+    against the checker backend making the same roundings, and its deviation from the fp32 step - loss, logits and the 142
+    gradients - inside the bounds DESIGN.md quotes."""
+    import cpu_ops
+    from gnnome_amd import train as train_mod
+    n, e, hidden = 3000, 30000, 128
+    gr = make_graph(n, e, seed=11)
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(hidden, seed=5)
+
+    def step(storage, backend=None):
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch", dropout=0.0)
+        m.load_state_dict(sd)
+        m.activation_storage = storage
+        if backend is None:
+            m = m.to(dev()).train()
+            logits = m((gr["src"], gr["dst"], n), x.to(dev()), gr["e"].to(dev()))
+            loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), gr["y"].to(dev()), pos_weight=gr["pos_weight"].to(dev()))
+        else:
+            m.train()
+            logits = train_mod.train_forward_on(m, train_mod.WholeGraph(cpu_ops.CpuViews(gr["src"], gr["dst"], n), backend), x, gr["e"])
+            loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), gr["y"], pos_weight=gr["pos_weight"])
+        loss.backward()
+        return loss.item(), logits.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+
+    l32, z32, g32 = step("fp32")
+    l16, z16, g16 = step("bf16")
+    lck, zck, gck = step("bf16", backend=cpu_ops)
+    # GPU vs checker, both rounding xe / dxe to bf16: elements that sit within an fp32 rounding of a bf16 tie round differently,
+    # so this is a tolerance test (an order tighter than the distance to fp32 below)
+    assert abs(l16 - lck) <= 2e-5 * abs(lck)
+    gmax = max(w.abs().max().item() for w in gck.values())
+    for k, w in gck.items():   # (the biases in front of a train-mode BatchNorm have a true gradient of zero: rounding noise on both sides)
+        err = (g16[k] - w).abs().max().item()
+        assert err <= 5e-2 * w.abs().max().item() + 1e-4 * gmax, f"{k}: {err:.2e} vs {w.abs().max().item():.2e}"
+    num = sum(((g16[k] - gck[k]).double() ** 2).sum().item() for k in gck) ** 0.5
+    den = sum((gck[k].double() ** 2).sum().item() for k in gck) ** 0.5
+    print(f"bf16 storage, HIP vs checker: gradient rel L2 {num / den:.2e}")
+    assert num / den < 5e-3
+    # deviation of bf16 storage from the fp32 step
+    dl = abs(l16 - l32) / abs(l32)
+    dp = (torch.sigmoid(z16) - torch.sigmoid(z32)).abs().max().item()
+    num = sum(((g16[k] - g32[k]).double() ** 2).sum().item() for k in g32) ** 0.5
+    den = sum((g32[k].double() ** 2).sum().item() for k in g32) ** 0.5
+    print(f"bf16 storage vs fp32: loss rel {dl:.2e}, max |dp| {dp:.2e}, gradient rel L2 {num / den:.2e}")
+    assert dl < 2e-3 and dp < 2e-2 and num / den < 5e-2
+    with pytest.raises(ValueError):
+        step("fp8")
+
+
 def test_training_step_full_size_properties():
     """BASELINE configs[2]'s shape (N = 1e5, E = 1e6, H = 128): a whole fwd + BCE + bwd step twice from the same state -
     same bits (logits, loss, all 142 gradients, BatchNorm buffers), everything finite, BatchNorm counters advanced as the

@@ -95,3 +95,38 @@ def test_dropout_training_step_matches_oracle_autograd_with_the_same_masks(monke
     monkeypatch.undo()
     mk = gtrain.dropout_mask(2000, 64, 0.2, torch.device("cpu"))
     assert set(mk.unique().tolist()) == {0.0, 1.25} and abs(mk.mean().item() - 1.0) < 0.02
+
+
+def test_bf16_activation_storage_on_checker_backend_stays_close_to_the_reference_golden_g3():
+    """model.activation_storage = "bf16" (xe and dxe rounded to bfloat16 between the kernels, arithmetic fp32): the host logic of
+    the option, and its distance from the REFERENCE's fp32 step on golden G3 (2000 edges: little averaging) - loss within 1e-4,
+    probabilities within 2e-3, the whole gradient within 3 % in L2 (measured 1.2 %; single tensors up to 14 % of their own
+    scale; the fp32 step holds 1e-3), BatchNorm buffers within 1e-3.  The option refuses what it is not built for."""
+    import pytest
+    g = load_golden("g3_train_h64.pt")
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 8, 64, "batch", dropout=0.0)
+    m.load_state_dict(random_state_dict(64, seed=g["seed"]))
+    m.train()
+    m.activation_storage = "bf16"
+    views = cpu_ops.CpuViews(g["src"], g["dst"], g["num_nodes"])
+    logits = train_forward_on(m, WholeGraph(views, cpu_ops), g["x"], g["e"])
+    loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), g["y"], pos_weight=g["pos_weight"])
+    loss.backward()
+    assert (torch.sigmoid(logits.detach()) - torch.sigmoid(g["logits"])).abs().max().item() < 2e-3
+    assert abs(loss.item() - g["loss"].item()) < 1e-4 * abs(g["loss"].item())
+    got = {k: p.grad for k, p in m.named_parameters()}
+    check_grads(got, g["grads"], rtol=0.25, floor=3e-5)
+    num = sum(((got[k] - w).double() ** 2).sum().item() for k, w in g["grads"].items()) ** 0.5
+    den = sum((w.double() ** 2).sum().item() for w in g["grads"].values()) ** 0.5
+    assert num / den < 3e-2, f"relative L2 distance of the gradient from the reference's {num / den:.2e}"
+    bufs = dict(m.named_buffers())
+    for k, want in g["buffers_after"].items():
+        assert torch.allclose(bufs[k].float(), want.float(), atol=1e-3, rtol=1e-3), k
+    # LayerNorm has no bf16-storage path; an unknown storage name is rejected
+    ln = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 2, 64, "layer", dropout=0.0).train()
+    ln.activation_storage = "bf16"
+    with pytest.raises(ValueError):
+        train_forward_on(ln, WholeGraph(views, cpu_ops), g["x"], g["e"])
+    m.activation_storage = "fp16"
+    with pytest.raises(ValueError):
+        train_forward_on(m, WholeGraph(views, cpu_ops), g["x"], g["e"])

@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 TAG=${1:-prof_train}; O=gpurun_out/$TAG; mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o r -- python bench.py --mode train --steps 10 --warmup 3 --no-cpu-baseline > $O/bench.json 2> $O/err.log
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o r -- python bench.py --mode train --steps 10 --warmup 3 --no-cpu-baseline $PROF_ARGS > $O/bench.json 2> $O/err.log
 DB=$(find $O/prof -name "*.db" | head -1)
 python tools/rocpd_summary.py "$DB" > $O/kernel_stats.md 2>&1
 rm -rf $O/prof
