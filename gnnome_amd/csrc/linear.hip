@@ -429,6 +429,127 @@ __global__ __launch_bounds__(64 * NW) void k_linear_bf2(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// A-stationary form for wide outputs (the node projection [N,H] -> [N,5H]).  The streaming kernel above keeps a W chunk per
+// workgroup and re-reads - and re-splits - the A rows for every 64-column chunk (ten times at Nout = 5H, in 32-byte pieces that
+// thrash L1).  Here a wave loads its 32 rows x K ONCE, splits them ONCE into registers (3 K / 16 x 4 VGPRs) and walks over ALL
+// column chunks; the W chunks (L2-resident, Nout x K x 4 bytes) stream through one LDS buffer, split by the threads that
+// stage them, the next chunk's rows fetched into registers while the MFMAs of the current one run.  Two barriers per chunk.
+// ---------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256, 2) void k_linear_as(const float* __restrict__ A, int64_t M, int lda, const float* __restrict__ W,
+                                                      int ldw, const float* __restrict__ bias, int Nout, float* __restrict__ C, int ldc,
+                                                      int accumulate) {
+    using P = LinBF2<K, 4>;
+    constexpr int PLD = P::PLD, PB = P::kPlaneBytes, KS = K / 16, NP = P::kWPieces;
+    __shared__ __attribute__((aligned(16))) unsigned char Wp[3 * PB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 31, half = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * P::TM + 32 * wave;
+    const bool live = row0 < M;   // a wave past the end still stages W and meets the barriers
+    auto bf = [](const uint4 v) { return __builtin_bit_cast(lin_bf16x8, v); };
+
+    uint4 a1[KS], a2[KS], a3[KS];
+    {
+        const int64_t arow = min(row0 + cl, M - 1);   // rows past the end read the last row (never stored)
+        const float* ap = A + arow * lda + 8 * half;
+        f32x4 x[KS][2];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            x[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * q);
+            x[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * q + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < KS; ++q) lin_split8(x[q][0], x[q][1], a1[q], a2[q], a3[q]);
+    }
+    f32x4 wr[NP][2];
+    auto fetch_w = [&](int chunk) {   // eight consecutive k of one W row per piece
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int f = tid + 256 * it, row = f / (K / 8), c8 = f % (K / 8);
+            const float* src = W + (int64_t)(chunk * P::NC + row) * ldw + 8 * c8;
+            wr[it][0] = *reinterpret_cast<const f32x4*>(src);
+            wr[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+    };
+    const int n_chunks = Nout / P::NC;
+    const unsigned char* wp = Wp + cl * PLD + 16 * half;
+    fetch_w(0);
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        if (chunk > 0) __syncthreads();   // every wave is done with the previous chunk's planes
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int f = tid + 256 * it, row = f / (K / 8), c8 = f % (K / 8);
+            uint4 p1, p2, p3;
+            lin_split8(wr[it][0], wr[it][1], p1, p2, p3);
+            unsigned char* dst = Wp + row * PLD + 16 * c8;
+            *reinterpret_cast<uint4*>(dst) = p1;
+            *reinterpret_cast<uint4*>(dst + PB) = p2;
+            *reinterpret_cast<uint4*>(dst + 2 * PB) = p3;
+        }
+        __syncthreads();
+        if (chunk + 1 < n_chunks) fetch_w(chunk + 1);
+        if (!live) continue;
+        const int col0 = chunk * P::NC;
+        const float b0 = bias != nullptr ? bias[col0 + cl] : 0.f, b1 = bias != nullptr ? bias[col0 + 32 + cl] : 0.f;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = b0;
+            acc1[r] = b1;
+        }
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const unsigned char* w = wp + 32 * q;
+            const uint4 u1 = *reinterpret_cast<const uint4*>(w), u2 = *reinterpret_cast<const uint4*>(w + PB),
+                        u3 = *reinterpret_cast<const uint4*>(w + 2 * PB);
+            const uint4 v1 = *reinterpret_cast<const uint4*>(w + 32 * PLD), v2 = *reinterpret_cast<const uint4*>(w + 32 * PLD + PB),
+                        v3 = *reinterpret_cast<const uint4*>(w + 32 * PLD + 2 * PB);
+            // smallest terms first; the two column blocks alternate, so consecutive MFMAs never wait on each other
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a3[q]), bf(u1), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a3[q]), bf(v1), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[q]), bf(u3), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[q]), bf(v3), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2[q]), bf(u2), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2[q]), bf(v2), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2[q]), bf(u1), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2[q]), bf(v1), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[q]), bf(u2), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[q]), bf(v2), acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[q]), bf(u1), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[q]), bf(v1), acc1, 0, 0, 0);
+        }
+        float* out = C + row0 * ldc + col0 + cl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = cd_row(r, lane);
+            if (row0 + lr < M) {
+                float* o = out + (int64_t)lr * ldc;
+                if (accumulate) {
+                    o[0] += acc0[r];
+                    o[32] += acc1[r];
+                } else {
+                    o[0] = acc0[r];
+                    o[32] = acc1[r];
+                }
+            }
+        }
+    }
+}
+
+constexpr int64_t kAStationaryRows = 400000;   // ~6 row blocks of 128 per workgroup slot (2 per CU)
+
+template <int K>
+static int launch_linear_as(const float* A, int64_t M, int lda, const float* W, int ldw, const float* bias, int Nout, float* C,
+                            int ldc, hipStream_t s, int accumulate) {
+    const int64_t blocks = (M + 127) / 128;
+    GN_REQUIRE(blocks < (1ll << 31), "linear: too many tiles");
+    hipLaunchKernelGGL(k_linear_as<K>, dim3((unsigned)blocks), dim3(256), 0, s, A, M, lda, W, ldw, bias, Nout, C, ldc, accumulate);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
 template <int K, int NW = 4, int WGS_PER_CU = 3>
 static int launch_linear_bf2(const float* A, int64_t M, int lda, const float* W, int ldw, const float* bias, int Nout, float* C,
                              int ldc, hipStream_t s, int accumulate) {
@@ -570,11 +691,21 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
     if (tuning(kTuneLinearVariant) == 0 && accumulate && bias == nullptr && K == Nout && (K == 64 || K == 128) && lda == K &&
         ldc == K && aligned_out && M >= 32768)   // edge-sized square residual GEMM: the wave-specialised edge-tile kernel
         return ws_linear_acc(A, M, K, W, ldw, C, s);
+    if (tuning(kTuneLinearVariant) == 0 && ldw % 4 == 0 && Nout % 64 == 0 && Nout >= 256 && M >= kAStationaryRows) {
+        // many row blocks and a wide output: A loaded and split once per row block (measured at Nout = 5H = 640: 1.08 against
+        // 1.24 ms at M = 1M; at M = 100k - three row blocks per CU - the streaming kernel below wins, 0.120 against 0.133 ms)
+        if (K == 128) return launch_linear_as<128>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+        if (K == 64) return launch_linear_as<64>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+    }
     if (tuning(kTuneLinearVariant) == 0 && ldw % 4 == 0 && Nout % 64 == 0) {   // the shipped default: bf16x6, barrier-free streaming
         if (K == 128) return launch_linear_bf2<128>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
         if (K == 64) return launch_linear_bf2<64>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
         // (K = 256: 101 KB of W planes leave one 8-wave workgroup per CU, too few waves to hide the fragment fetches:
         //  1.06 ms against 0.91 ms for the tile kernel at N = 250k, Nout = 1280 - measured, so K = 256 falls through)
+    }
+    if (tuning(kTuneLinearVariant) == 6 && ldw % 4 == 0 && Nout % 64 == 0) {   // 6: A-stationary (see k_linear_as)
+        if (K == 128) return launch_linear_as<128>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+        if (K == 64) return launch_linear_as<64>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
     }
     if (tuning(kTuneLinearVariant) == 4 && ldw % 4 == 0 && Nout % 64 == 0) {   // 4: the default kernel as 8-wave workgroups, two per CU
         if (K == 128) return launch_linear_bf2<128, 8, 2>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);

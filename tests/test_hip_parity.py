@@ -119,6 +119,33 @@ def test_linear(m, k, nout):
         ops.set_tuning(2, 0)
 
 
+@pytest.mark.parametrize("m,k,nout", [(400_001, 128, 640), (400_000, 64, 320), (1000, 128, 640), (129, 64, 256)])
+def test_linear_a_stationary_kernel(m, k, nout):
+    """k_linear_as (large M and a wide output: the node projection of a >= 400k-node graph; tuning variant 6 forces it at any
+    size): the same bf16x6 products in the same order as the streaming kernel - bit-identical - and the strided-output,
+    accumulate and ragged-last-block cases."""
+    g = torch.Generator().manual_seed(m + k)
+    A, W, b = torch.randn(m, k, generator=g).to(dev()), torch.randn(nout, k, generator=g).to(dev()), torch.randn(nout, generator=g).to(dev())
+    try:
+        ops.set_tuning(2, 6)
+        got = ops.linear(A, W, b)
+        wide = torch.zeros(m, nout + 64, device=dev())
+        ops.linear(A, W, None, out=wide[:, 64:])
+        base = torch.randn(m, nout, generator=g).to(dev())
+        acc = ops.linear(A, W, b, out=base.clone(), accumulate=True)
+        ops.set_tuning(2, 5 if k == 128 else 4)     # the streaming kernel at any size
+        ref = ops.linear(A, W, b)
+        ref_nb = ops.linear(A, W, None)
+    finally:
+        ops.set_tuning(2, 0)
+    assert torch.equal(got, ref) and torch.equal(wide[:, 64:], ref_nb) and not wide[:, :64].any()
+    assert torch.equal(ops.linear(A, W, b), ref)      # the default route (A-stationary from 400k rows) agrees either way
+    rows = torch.randint(0, m, (2000,), generator=g)
+    want = A[rows].double().cpu() @ W.double().cpu().t() + b.double().cpu()
+    _assert_close(got[rows], want, scale=float(k) ** 0.5 * 4)
+    _assert_close(acc[rows], want + base[rows].double().cpu(), scale=float(k) ** 0.5 * 4)
+
+
 def test_linear_strided_views():
     g = torch.Generator().manual_seed(9)
     hidden, hs, n = 128, 64, 700
