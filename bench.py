@@ -583,7 +583,7 @@ def main():
                 res["target_10m"] = _single_gpu_forward(gnnome_amd, ops, make_graph, random_state_dict, "10m", args.kind, dev, 20, 3)
                 res["train"] = _train_record(gnnome_amd, ops, g, n, e, hidden, dev, 20, 3, False, None)
                 t16 = _train_record(gnnome_amd, ops, g, n, e, hidden, dev, 20, 3, False, None, storage="bf16")
-                res["train"]["bf16_storage"] = {k: t16[k] for k in ("value", "ms_per_step", "eager_ms_per_step", "loss", "activation_storage")}
+                res["train"]["bf16_storage"] = {k: t16[k] for k in ("value", "ms_per_step", "loss", "activation_storage")}
             if not args.no_cpu_baseline:
                 # in a child process (own thread pool, hard time limit): the baseline must never stall the bench line
                 res["cpu_baseline"], err_cpu = _run_cpu_child(args, 900 if args.cpu_baseline_full else 200)
