@@ -607,7 +607,7 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
     const bool rows16 = ld_node % 4 == 0 && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0);
     const bool persistent_ok = norm_kind == GNNOME_NORM_AFFINE && (hidden == 64 || hidden == 128);
     if (persistent_ok && variant != 1) {
-        if (variant == 0 && rows16) {   // the shipped default: bf16x6 edge-tile kernel (edge_gate_bf.hip)
+        if ((variant == 0 || variant == 7 || variant == 8) && rows16) {   // the shipped default: bf16x6 edge-tile kernel (edge_gate_bf.hip); 7: its plane form
             GateBfArgs a = {};
             a.e_in = e_in; a.e_out = e_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
             a.srt_dst = srt_dst; a.W3 = W3; a.ldw = ldw; a.scale = norm_scale; a.shift = norm_shift;
@@ -708,7 +708,7 @@ extern "C" int gnnome_edge_gate_encode_f32(const float* e_raw, const int32_t* sr
                "edge_gate_encode: alignment");
     const GateEnc enc = {e_raw, srt_eid, encW1, encb1, encW2, encb2};
     hipStream_t s = (hipStream_t)stream;
-    if (tuning(kTuneGateVariant) == 0) {
+    if (tuning(kTuneGateVariant) == 0 || tuning(kTuneGateVariant) == 7 || tuning(kTuneGateVariant) == 8) {
         GateBfArgs a = {};
         a.e_out = e_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src; a.srt_dst = srt_dst;
         a.W3 = W3; a.ldw = ldw; a.scale = norm_scale; a.shift = norm_shift; a.enc = enc;

@@ -411,6 +411,271 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
 
 static long long* g_gate_prof = nullptr;
 
+// ---------------------------------------------------------------------------------------------------
+// Third generation, H = 128, mode 0 (the inference gate): the A operand is split ONCE per tile, by the load waves.
+// In k_edge_gate_bf the four compute waves each own 32 of the 128 output columns of the same 32 rows, so each of them reads
+// the whole fp32 A tile and splits it - 352 VALU operations per tile per wave, four times over, interleaved with 48 MFMAs
+// (2160 cycles in the loop against 1536 of MFMA).  Here the load waves, whose vector ALUs are idle most of the tile, store the
+// tile as three bf16 PLANES ([row][k], 272-byte rows) and the compute loop is 3 ds_read_b128 + 6 MFMAs per K = 16 step, no VALU.
+//   * LDS: a slot is the 26 KB of planes; once all four compute waves have read them (a second counter, `rd`) the slot is
+//     reused for x = e W3^T (fp32 [32][132], 17 KB) - four slots in 104 KB, so the ring keeps its four load groups (the
+//     round-1 attempt with planes AND a G tile per slot only had room for three and starved the compute waves);
+//   * G = B1h[src] + B2h[dst] and the e rows (for the residual) never enter LDS: the lanes that fetched them keep them in
+//     registers until their own epilogue (32 + 32 VGPRs), and the accumulators start from zero.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split4_planes(const f32x4 x, uint2& p1, uint2& p2, uint2& p3) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = __float_as_uint(x[j]) & 0xFFFF0000u;
+        const float r = x[j] - __uint_as_float(h[j]);        // exact
+        m[j] = __float_as_uint(r) & 0xFFFF0000u;
+        l[j] = __float_as_uint(r - __uint_as_float(m[j]));   // exact, a bf16
+    }
+    p1 = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+    p2 = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+    p3 = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+}
+
+template <bool ENC>
+__global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
+    constexpr int H = 128, TM = 32, RING = 4, KS = H / 16, LDK = H + 4, PLD = 2 * H + 16, PLANE = TM * PLD, SLOTB = 3 * PLANE;
+    constexpr int NP = 8, RSTEP = 4, NT = 768;
+    static_assert(TM * LDK * 4 <= SLOTB, "the x tile reuses the planes' slot");
+    constexpr int kEncFloats = ENC ? 16 * H + H + 48 : 4;
+    __shared__ __attribute__((aligned(16))) unsigned char ring[RING * SLOTB];
+    __shared__ __attribute__((aligned(16))) float encw[kEncFloats];
+    __shared__ unsigned flags[4 * RING];   // full[RING], rd[RING], done[RING], drained[RING]
+    __shared__ __attribute__((aligned(16))) float norm_lds[2 * H];   // scale | shift: the epilogue reads them per tile (no global load there)
+    float* w2t = encw;                     // ENC only
+    float* b2s = w2t + 16 * H;
+    float* w1s = b2s + H;
+    float* b1s = w1s + 32;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned full0 = lds_addr_bf(&flags[0]), rd0 = lds_addr_bf(&flags[RING]), done0 = lds_addr_bf(&flags[2 * RING]),
+                   drained0 = lds_addr_bf(&flags[3 * RING]);
+    const int per_xcd = gridDim.x / kXcds;
+    const int first = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
+    const int stride = (int)gridDim.x;
+    const int n = first < a.num_tiles ? (a.num_tiles - first + stride - 1) / stride : 0;
+    if (n <= 0) return;
+    auto tile_of = [&](int r) { return first + r * stride; };
+    auto tile_valid = [&](int r) { return (int)min((int64_t)TM, a.E - (int64_t)tile_of(r) * TM); };
+    if (ENC) {
+        for (int i = tid; i < 16 * H; i += NT) w2t[i] = a.enc.W2[(i % H) * 16 + (i / H)];
+        for (int i = tid; i < H; i += NT) b2s[i] = a.enc.b2[i];
+        if (tid < 32) w1s[tid] = a.enc.W1[tid];
+        if (tid < 16) b1s[tid] = a.enc.b1[tid];
+    }
+    if (tid < 4 * RING) flags[tid] = 0;
+    if (tid >= 64 && tid < 64 + 2 * H) norm_lds[tid - 64] = tid - 64 < H ? a.scale[tid - 64] : a.shift[tid - 64 - H];
+    __syncthreads();
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ compute wave: 32 rows x 32 columns
+        const int cl = lane & 31, half = lane >> 5, col = 32 * wave + cl;
+        uint4 w1[KS], w2[KS], w3[KS];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const float* wp = a.W3 + (int64_t)col * a.ldw + 16 * q + 8 * half;
+            split3(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4), w1[q], w2[q], w3[q]);
+        }
+        auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
+        const int lane_x = 4 * half * LDK + col;   // accumulator element r sits in tile row 4 half + crow(r)
+        long long t_wait = 0, t_rd = 0, t_loop = 0, t_x = 0, t0 = 0, t1 = 0;
+        const long long c_begin = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+        const long long r_begin = a.prof ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+        for (int i = 0; i < n; ++i) {
+            const int slot = i % RING;
+            const unsigned use = (unsigned)(i / RING) + 1u;
+            if (a.prof) t0 = __builtin_readcyclecounter();
+            flag_wait_bf(full0 + 4 * slot, 2u * use, 0);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_wait += t1 - t0; t0 = t1; }
+            const unsigned char* ap = ring + slot * SLOTB + cl * PLD + 16 * half;   // + 32 q, + PLANE * plane
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            uint4 c1 = *reinterpret_cast<const uint4*>(ap), c2 = *reinterpret_cast<const uint4*>(ap + PLANE),
+                  c3 = *reinterpret_cast<const uint4*>(ap + 2 * PLANE);
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                const int qn = q + 1 < KS ? q + 1 : q;
+                const uint4 n1 = *reinterpret_cast<const uint4*>(ap + 32 * qn), n2 = *reinterpret_cast<const uint4*>(ap + 32 * qn + PLANE),
+                            n3 = *reinterpret_cast<const uint4*>(ap + 32 * qn + 2 * PLANE);
+                // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c3), as_bf(w1[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w3[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c2), as_bf(w2[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c2), as_bf(w1[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w2[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w1[q]), acc, 0, 0, 0);
+                c1 = n1;
+                c2 = n2;
+                c3 = n3;
+            }
+            if (a.prof) { asm volatile("" ::"v"(acc[0])); t1 = __builtin_readcyclecounter(); t_loop += t1 - t0; t0 = t1; }
+            // every compute wave has read the planes -> the slot becomes the x tile
+            flag_bump_bf(rd0 + 4 * slot, lane);
+            flag_wait_bf(rd0 + 4 * slot, 4u * use, 0);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_rd += t1 - t0; t0 = t1; }
+            float* X = reinterpret_cast<float*>(ring + slot * SLOTB) + lane_x;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[crow(r) * LDK] = acc[r];
+            flag_bump_bf(done0 + 4 * slot, lane);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_x += t1 - t0; }
+        }
+        if (a.prof && wave == 0 && lane == 0) {   // same record as k_edge_gate_bf; slot 1 = waiting for the other compute waves
+            long long* o = a.prof + (int64_t)blockIdx.x * 8;
+            o[0] = t_wait; o[1] = t_rd; o[2] = t_loop; o[3] = t_x; o[4] = n;
+            o[5] = (long long)__builtin_readcyclecounter() - c_begin;
+            o[6] = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
+        }
+    } else {
+        // ------------------------------------------------------------------ load / store wave
+        const int group = (wave - 4) / 2;
+        const int gl = ((wave - 4) % 2) * 64 + lane;   // lane index inside the group, 0..127
+        const int r0 = gl / (H / 4), c4 = gl % (H / 4);
+        f32x4 av[NP], g1[NP], g2[NP], ek[NP], gk[NP];
+        float raw0[NP], raw1[NP];
+        int si[NP], di[NP], ei[NP];
+        const unsigned off_row = (unsigned)(r0 * H + 4 * c4);
+        auto issue_early = [&](int r) {
+            const int64_t row0 = (int64_t)tile_of(r) * TM;
+            const int valid = tile_valid(r);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {   // rows past the end of the list read the last valid row (never stored)
+                const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
+                si[p] = a.srt_src[row];
+                di[p] = a.srt_dst[row];
+                if (ENC) ei[p] = a.enc.srt_eid[row];
+            }
+        };
+        // (the e rows are NOT fetched with the indices: 32 registers fewer are held across the wait for the compute waves - this
+        //  role also keeps e and G of the tile in flight; see the epilogue)
+        auto fetch_e = [&](int r) {
+            const int64_t row0 = (int64_t)tile_of(r) * TM;
+            const int valid = tile_valid(r);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
+                av[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + 4 * c4);
+            }
+        };
+        auto issue_late = [&](int) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (ENC) {
+                    raw0[p] = a.enc.e_raw[2 * (int64_t)ei[p]];
+                    raw1[p] = a.enc.e_raw[2 * (int64_t)ei[p] + 1];
+                }
+                g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + (int64_t)si[p] * a.ldn + 4 * c4);
+                g2[p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)di[p] * a.ldn + 4 * c4);
+            }
+        };
+        auto encode_pending = [&]() {   // in the reference's order (see k_edge_gate_bf)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) av[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w2t + j * H + 4 * c4);
+                const float wa = w1s[2 * j], wb = w1s[2 * j + 1], bj = b1s[j];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float t = fmaxf(__builtin_fmaf(raw1[p], wb, raw0[p] * wa) + bj, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) av[p][i] = __builtin_fmaf(t, w[i], av[p][i]);
+                }
+            }
+            const f32x4 b2v = *reinterpret_cast<const f32x4*>(b2s + 4 * c4);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) av[p] += b2v;
+        };
+        if (group < n) {
+            issue_early(group);
+            if (!ENC) fetch_e(group);
+            issue_late(group);
+            if (ENC) encode_pending();
+        }
+        unsigned char* S = ring + group * SLOTB;
+        const float* Xs = reinterpret_cast<const float*>(S);
+        long long t_top = 0, t_split = 0, t_done = 0, t_epi = 0, t0 = 0, t1 = 0;
+        for (int r = group; r < n; r += RING) {
+            const unsigned use = (unsigned)(r / RING) + 1u;
+            if (a.prof) { t0 = __builtin_readcyclecounter(); asm volatile("" ::"v"(av[0][0]), "v"(g1[NP - 1][0]), "v"(g2[NP - 1][0])); t1 = __builtin_readcyclecounter(); t_top += t1 - t0; t0 = t1; }
+            // The slot is free once BOTH waves of the group have read the previous x tile out of it: the planes of a row do not
+            // lie where its x row lay, so one wave's plane stores would land on x rows the other wave has yet to read.
+            flag_wait_bf(drained0 + 4 * group, 2u * (use - 1u), 0);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                uint2 p1, p2, p3;
+                split4_planes(av[p], p1, p2, p3);
+                unsigned char* d = S + (r0 + p * RSTEP) * PLD + 8 * c4;
+                *reinterpret_cast<uint2*>(d) = p1;
+                *reinterpret_cast<uint2*>(d + PLANE) = p2;
+                *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+                ek[p] = av[p];
+                gk[p] = g1[p] + g2[p];
+                // G is summed HERE, not where it is used: sunk into the epilogue, the sum would drag the wait for the gathers
+                // behind that epilogue's own stores (one in-order counter for loads and stores) and stall on their completion
+                asm volatile("" : "+v"(gk[p]));
+            }
+            flag_bump_bf(full0 + 4 * group, lane);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_split += t1 - t0; t0 = t1; }
+            if (r + RING < n) issue_early(r + RING);
+            flag_wait_bf(done0 + 4 * group, 4u * use, a.xp & 3);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_done += t1 - t0; t0 = t1; }
+            const int valid = tile_valid(r);
+            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4), sh4 = *reinterpret_cast<const f32x4*>(norm_lds + H + 4 * c4);
+            float* out = a.e_out + (int64_t)tile_of(r) * TM * H;
+            // four x pieces are read together, BEFORE the row-validity branches: one LDS round trip (~400 cycles with the compute
+            // waves reading planes flat out) per four pieces instead of one per piece
+#pragma unroll
+            for (int pb = 0; pb < NP; pb += 4) {
+                f32x4 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(Xs + (r0 + (pb + u) * RSTEP) * LDK + 4 * c4);
+                asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = pb + u, row = r0 + p * RSTEP;
+                    f32x4 y;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + gk[p][j]) * sc4[j] + sh4[j], 0.f) + ek[p][j];
+                    if (row < valid) *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
+                }
+            }
+            flag_bump_bf(drained0 + 4 * group, lane);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_epi += t1 - t0; }
+            if (r + RING < n) {   // (woven into the epilogue piece by piece, the e-row fetch made the epilogue 1200 cycles longer and
+                                  //  arrived no earlier: loads and stores share one in-order counter)
+                if (!ENC) fetch_e(r + RING);
+                issue_late(r + RING);
+                if (ENC) encode_pending();
+            }
+        }
+        if (a.prof && wave == 4 && lane == 0) {   // the first load wave's phases, after the 256 compute-wave records
+            long long* o = a.prof + (int64_t)(256 + blockIdx.x) * 8;
+            o[0] = t_top; o[1] = t_split; o[2] = t_done; o[3] = t_epi; o[4] = (n + RING - 1) / RING;
+        }
+    }
+}
+
+template <bool ENC>
+static int launch_pl(const GateBfArgs& args, hipStream_t s) {
+    GateBfArgs a = args;
+    const int64_t tiles = (a.E + 31) / 32;
+    GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
+    a.num_tiles = (int)tiles;
+    a.xp = tuning(kTuneGateExperiment);
+    a.prof = g_gate_prof;
+    hipLaunchKernelGGL((k_edge_gate_pl<ENC>), dim3(persistent_grid()), dim3(768), 0, s, a);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+
 template <int CB, int RB, int MODE, bool ENC, bool X16 = false>
 static int launch_bf(const GateBfArgs& args, hipStream_t s) {
     using P = GateBF<CB, RB>;
@@ -435,6 +700,9 @@ int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStrea
         return GNNOME_EINVAL;
     }
     if (hidden == 128) {
+        // mode 0: the plane form (k_edge_gate_pl) is the default without the folded encoder; variant 7 forces it for the encoder
+        // launch too (its 24 extra registers spill there), variant 8 forces the second-generation kernel
+        if (mode == 0 && tuning(kTuneGateVariant) != 8 && (!enc || tuning(kTuneGateVariant) == 7)) return enc ? launch_pl<true>(a, s) : launch_pl<false>(a, s);
         if (mode == 0) return enc ? launch_bf<4, 1, 0, true>(a, s) : launch_bf<4, 1, 0, false>(a, s);
         if (mode == 3) return launch_bf<4, 1, 3, false>(a, s);
         return mode == 1 ? launch_bf<4, 1, 1, false>(a, s) : launch_bf<4, 1, 2, false>(a, s);

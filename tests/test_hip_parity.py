@@ -193,7 +193,7 @@ def test_edge_gate(hidden, norm, e_base):
         assert torch.equal(out, e_dev)
     # every kernel variant behind the entry point (gnnome_set_tuning key 0) must meet the same contract
     try:
-        for variant in (1, 5, 6):
+        for variant in (1, 5, 6, 7, 8):   # 8 = the second-generation bf16x6 kernel at H = 128 (the default there is its plane form)
             ops.set_tuning(0, variant)
             e_var = d["e"].clone()
             ops.edge_gate(e_var, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], norm, d["scale"], d["shift"])
@@ -315,8 +315,9 @@ def test_edge_gate_with_folded_encoder(hidden, e_count):
     got = ops.edge_gate_encode(e_raw.to(dev()), enc_d, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], d["scale"], d["shift"])
     _assert_close(got, want, scale=20.0)
     alts = []
-    try:  # the exact-fp32-MFMA generation of the kernel, slot hand-over by LDS counters (5) or workgroup barriers (6)
-        for variant in (5, 6):
+    try:  # the exact-fp32-MFMA generation of the kernel, slot hand-over by LDS counters (5) or workgroup barriers (6);
+          # 7 = the plane form with the folded encoder (not the default for this launch: it spills)
+        for variant in (5, 6, 7):
             ops.set_tuning(0, variant)
             alts.append(ops.edge_gate_encode(e_raw.to(dev()), enc_d, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], d["scale"],
                                              d["shift"]))
@@ -324,6 +325,7 @@ def test_edge_gate_with_folded_encoder(hidden, e_count):
         ops.set_tuning(0, 0)
     assert torch.equal(alts[0], alts[1])          # same arithmetic, same bits
     _assert_close(alts[0], want, scale=20.0)
+    _assert_close(alts[2], want, scale=20.0)
 
 
 def test_gather_rows():
@@ -529,6 +531,37 @@ def test_full_size_properties(n, e, hidden):
     perm = torch.randperm(e, generator=torch.Generator().manual_seed(3)).to(dev())
     d = m((graph[0][perm], graph[1][perm], n), x, ef[perm])
     assert _prob_diff(a[perm], d) < PROB_TOL
+
+
+@pytest.mark.parametrize("kind", ["banded", "uniform"])
+def test_gate_plane_form_at_full_size_against_the_second_generation(kind):
+    """k_edge_gate_pl hands an LDS slot over four times per tile (planes -> all compute waves read -> x tile -> both store waves
+    drained); a missing hand-over shows up as a handful of wrong rows per MILLION edges (seen while it was written: 5 rows, rows
+    28-31 of their tiles), which no small test catches.  1M edges, H = 128, five launches: every launch equals the
+    second-generation kernel (variant 8) to fp32 reordering, in place and out of place, and repeats bit for bit."""
+    n, e, H = 100_000, 1_000_000, 128
+    gr = make_graph(n, e, seed=4, kind=kind)
+    gv = ops.GraphViews(gr["src"].to(dev()), gr["dst"].to(dev()), n)
+    g = torch.Generator(device=dev()).manual_seed(1)
+    ee = torch.randn(e, H, device=dev(), generator=g)
+    P = torch.randn(n, 2 * H, device=dev(), generator=g)
+    W3 = torch.randn(H, H, device=dev(), generator=g) / H ** 0.5
+    sc, sh = torch.rand(H, device=dev(), generator=g) * 0.1, torch.randn(H, device=dev(), generator=g)
+    try:
+        ops.set_tuning(0, 8)
+        ref = ops.edge_gate(ee, P[:, :H], P[:, H:], gv, W3, 0, sc, sh, out=torch.empty_like(ee))
+    finally:
+        ops.set_tuning(0, 0)
+    scale = ref.abs().max().item()
+    first = None
+    for rep in range(5):
+        out = ops.edge_gate(ee, P[:, :H], P[:, H:], gv, W3, 0, sc, sh, out=torch.empty_like(ee))
+        assert (out - ref).abs().max().item() <= 2e-6 * scale
+        first = out if first is None else first
+        assert torch.equal(out, first)
+    inplace = ee.clone()
+    ops.edge_gate(inplace, P[:, :H], P[:, H:], gv, W3, 0, sc, sh)
+    assert torch.equal(inplace, first)
 
 
 def test_h256_shard_of_configs3_properties():

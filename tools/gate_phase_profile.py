@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--hidden", type=int, default=128)
 ap.add_argument("--edges", type=int, default=1_000_000)
 ap.add_argument("--ablation", type=int, default=0)
+ap.add_argument("--variant", type=int, default=0, help="gnnome_set_tuning(0, v): 0 = k_edge_gate_bf, 7 = k_edge_gate_pl (slot 2 = waiting for the other compute waves)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 n, e, H = a.edges // 10, a.edges, a.hidden
@@ -27,9 +28,10 @@ P = torch.randn(n, 5 * H, device=dev, generator=gen)
 W3 = torch.randn(H, H, device=dev, generator=gen) / H ** 0.5
 sc, sh = torch.rand(H, device=dev, generator=gen) * 0.1, torch.randn(H, device=dev, generator=gen)
 ops.set_tuning(1, a.ablation)
+ops.set_tuning(0, a.variant)
 for _ in range(3):
     ops.edge_gate(ee, P[:, 3 * H:4 * H], P[:, 4 * H:], views, W3, 0, sc, sh, out=out)
-prof = torch.zeros(256 * 8, dtype=torch.int64, device=dev)
+prof = torch.zeros(2 * 256 * 8, dtype=torch.int64, device=dev)   # [256 compute-wave records | 256 load-wave records (variant 7)]
 lib = _lib.load()
 lib.gnnome_debug_gate_profile(prof.data_ptr())
 s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,7 +41,9 @@ t.record()
 torch.cuda.synchronize()
 lib.gnnome_debug_gate_profile(None)
 ops.set_tuning(1, 0)
-p = prof.view(256, 8).cpu().double()
+ops.set_tuning(0, 0)
+p = prof[:256 * 8].view(256, 8).cpu().double()
+lw = prof[256 * 8:].view(256, 8).cpu().double()
 tiles = p[:, 4].sum().item()
 names = ["wait for slot", "prologue (first fragment)", "MFMA loop", "x write-back"]
 ms = s.elapsed_time(t)
@@ -53,3 +57,7 @@ span_c, span_r = p[:, 5].mean().item(), p[:, 6].mean().item()
 print(f"  loop span per workgroup: {span_c:.0f} shader cycles in {span_r / 100.0:.1f} us (100 MHz counter) -> shader clock {span_c / (span_r / 100.0) / 1e3:.2f} GHz; "
       f"accounted {total * tiles / 256 / span_c:.0%} of the span")
 print(f"  {'sum':28s} {total:8.0f} cycles / tile   -> {total * tiles / 256 / (ms * 1e-3) / 1e9:.2f} GHz if the wave were busy for the whole launch")
+if a.variant == 7 and lw[:, 4].sum().item() > 0:
+    t = lw[:, 4].sum().item()
+    print("  first load wave, cycles per tile IT handles (one in four): "
+          + ", ".join(f"{nm} {lw[:, k].sum().item() / t:.0f}" for k, nm in enumerate(["fetch arrival", "split + plane stores", "wait for compute", "epilogue + stores"])))
