@@ -700,9 +700,9 @@ int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStrea
         return GNNOME_EINVAL;
     }
     if (hidden == 128) {
-        // mode 0: the plane form (k_edge_gate_pl) is the default without the folded encoder; variant 7 forces it for the encoder
-        // launch too (its 24 extra registers spill there), variant 8 forces the second-generation kernel
-        if (mode == 0 && tuning(kTuneGateVariant) != 8 && (!enc || tuning(kTuneGateVariant) == 7)) return enc ? launch_pl<true>(a, s) : launch_pl<false>(a, s);
+        // mode 0: the plane form (k_edge_gate_pl) is the default, with the folded encoder too (its 24 extra registers spill
+        // there, and it still measures 0.025 ms ahead); variant 8 forces the second-generation kernel
+        if (mode == 0 && tuning(kTuneGateVariant) != 8) return enc ? launch_pl<true>(a, s) : launch_pl<false>(a, s);
         if (mode == 0) return enc ? launch_bf<4, 1, 0, true>(a, s) : launch_bf<4, 1, 0, false>(a, s);
         if (mode == 3) return launch_bf<4, 1, 3, false>(a, s);
         return mode == 1 ? launch_bf<4, 1, 1, false>(a, s) : launch_bf<4, 1, 2, false>(a, s);

@@ -316,8 +316,8 @@ def test_edge_gate_with_folded_encoder(hidden, e_count):
     _assert_close(got, want, scale=20.0)
     alts = []
     try:  # the exact-fp32-MFMA generation of the kernel, slot hand-over by LDS counters (5) or workgroup barriers (6);
-          # 7 = the plane form with the folded encoder (not the default for this launch: it spills)
-        for variant in (5, 6, 7):
+          # 8 = the second-generation bf16x6 kernel with the folded encoder (the default is its plane form)
+        for variant in (5, 6, 8):
             ops.set_tuning(0, variant)
             alts.append(ops.edge_gate_encode(e_raw.to(dev()), enc_d, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], d["scale"],
                                              d["shift"]))
