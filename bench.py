@@ -535,7 +535,7 @@ def main():
                 # bf16x6 edge-tile kernel: the exact-fp32 product costs 6 bf16 MFMAs per K=16 (197 GF per launch at
                 # configs[1] = 0.08 ms at the 2.5 PF bf16 peak) against 1.03 GB = 0.13 ms at 8 TB/s: HBM is the bound
                 res["roofline"] = {
-                    "kernel": "k_edge_gate_bf (fused B_3 GEMM as bf16x6 + u_add_v + bn_e + relu + residual)",
+                    "kernel": ("k_edge_gate_pl" if hidden == 128 else "k_edge_gate_bf") + " (fused B_3 GEMM as bf16x6 + u_add_v + bn_e + relu + residual)",
                     "bound": "hbm", "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK,
                     "traffic": _pmc_traffic(args, hidden, e) if world == 1 else None,

@@ -13,7 +13,7 @@ for mode in infer train; do
   head -14 $O/${TAG}_c2_$mode.kernel_stats.md
 done
 bash tools/pmc_traffic.sh $O/pmc
-python tools/pmc_to_json.py $O/pmc $O/${TAG}_gate_pmc.json k_edge_gate_bf | tail -8
+python tools/pmc_to_json.py $O/pmc $O/${TAG}_gate_pmc.json k_edge_gate_ | tail -8   # k_edge_gate_pl at H = 128, k_edge_gate_bf at H = 64
 rm -rf $O/pmc
 bash tools/pmc_forward.sh $O/pmc_fwd > $O/${TAG}_forward_hbm_traffic.md 2>&1; tail -12 $O/${TAG}_forward_hbm_traffic.md
 rm -rf $O/pmc_fwd

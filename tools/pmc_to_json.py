@@ -24,7 +24,7 @@ def mean_counter(path, needle):
 
 def main():
     src, out = sys.argv[1], sys.argv[2]
-    needle = sys.argv[3] if len(sys.argv) > 3 else "k_edge_gate_bf"
+    needle = sys.argv[3] if len(sys.argv) > 3 else "k_edge_gate_"
     fetch, n_f = mean_counter(os.path.join(src, "FETCH_SIZE", "p_counter_collection.csv"), needle)
     write, n_w = mean_counter(os.path.join(src, "WRITE_SIZE", "p_counter_collection.csv"), needle)
     e, hidden = 1_000_000, 128

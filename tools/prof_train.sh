@@ -14,7 +14,7 @@ for l in open(sys.argv[1]):
     m = re.match(r"\| `(.*?)` \| (\d+) \| ([\d.]+) \| ([\d.]+) \|", l)
     if m:
         rows.append((m.group(1), int(m.group(2)), float(m.group(3)), float(m.group(4))))
-steps = max(1, [r[1] for r in rows if "k_edge_gate_bf<4, 1, 1" in r[0]][0] // 8)
+steps = max(1, [r[1] for r in rows if "k_edge_gate_bf<4, 1, 1" in r[0] or "k_edge_gate_bf<2, 2, 1" in r[0]][0] // 8)
 small = [r for r in rows if r[3] < 50]
 print(f"steps traced {steps}: {sum(r[2] for r in rows) / steps / 1e3:.2f} ms of kernels per step in {sum(r[1] for r in rows) / steps:.0f} launches; "
       f"kernels under 50 us: {sum(r[2] for r in small) / steps / 1e3:.2f} ms in {sum(r[1] for r in small) / steps:.0f} launches")
