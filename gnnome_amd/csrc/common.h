@@ -21,6 +21,7 @@ struct GateEnc {
     const float* e_raw;       // [E,2] in edge-id order
     const int32_t* srt_eid;   // sorted position -> edge id
     const float *W1, *b1, *W2, *b2;   // [16,2] [16] [H,16] [H]
+    const float *W23, *b23;           // filled by the launcher for k_edge_gate_enc16: W3 * W2 [H,16] and W3 * b2 [H]
 };
 
 // Mode 3 of the edge-tile kernel: the A operand is not read but COMPUTED by the load waves from two streams,

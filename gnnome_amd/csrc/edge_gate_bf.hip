@@ -676,6 +676,213 @@ static int launch_pl(const GateBfArgs& args, hipStream_t s) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Layer 0 at H = 128 with the edge encoder folded ALGEBRAICALLY.  e0 = t W2^T + b2 with t = relu(W1 e_raw + b1) of width 16,
+// so B_3(e0) = t (W3 W2)^T + W3 b2: both the gate's GEMM and the residual e0 are K = 16 products of the same [32 x 16] tile t.
+// k_edge_gate_pl<ENC> computed e0 [32 x 128] in the load waves (~900 VALU operations per lane and tile) and then ran the K = 128
+// GEMM on it; here the load waves produce t (one row and four hidden units per lane), the compute waves run 6 + 6 MFMAs per tile
+// (x = t W23^T and e0 = t W2^T into two accumulators) and the kernel is bound by its 512 MB of output.  W23 = W3 W2 and
+// b23 = W3 b2 come from k_fold_encoder (fp32, one wave per element, fixed summation tree) on the same stream.
+// Three load groups: a slot holds the three [32 x 16] bf16 planes of t and the two fp32 tiles x and e0 (38 KB).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fold_encoder(const float* __restrict__ W3, int ldw, const float* __restrict__ W2,
+                                                      const float* __restrict__ b2, int H, float* __restrict__ W23, float* __restrict__ b23) {
+    // one wave per output element: H*16 products W23[col][j] = sum_k W3[col][k] W2[k][j], then H bias terms sum_k W3[col][k] b2[k];
+    // lane l takes k = l, l + 64, ...; the 64 lane sums are folded by a butterfly (a fixed tree: the same bits on every launch)
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= H * 17) return;
+    const bool bias = i >= H * 16;
+    const int col = bias ? i - H * 16 : i / 16, j = i % 16;
+    float s = 0.f;
+    for (int k = lane; k < H; k += 64) s = __builtin_fmaf(W3[(int64_t)col * ldw + k], bias ? b2[k] : W2[k * 16 + j], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) (bias ? b23[col] : W23[i]) = s;
+}
+
+__global__ __launch_bounds__(640) void k_edge_gate_enc16(GateBfArgs a) {
+    constexpr int H = 128, TM = 32, RING = 3, LDK = H + 4, TPLD = 48, TPLANE = TM * TPLD, TILEF = TM * LDK;
+    constexpr int SLOTB = 3 * TPLANE + 2 * TILEF * 4, NP = 8, RSTEP = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char ring[RING * SLOTB];
+    __shared__ __attribute__((aligned(16))) float consts[4 * H];   // scale | shift | b23 | b2
+    __shared__ float w1s[32], b1s[16];
+    __shared__ unsigned flags[2 * RING];   // full[RING], done[RING]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned full0 = lds_addr_bf(&flags[0]), done0 = lds_addr_bf(&flags[RING]);
+    const int per_xcd = gridDim.x / kXcds;
+    const int first = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
+    const int stride = (int)gridDim.x;
+    const int n = first < a.num_tiles ? (a.num_tiles - first + stride - 1) / stride : 0;
+    if (n <= 0) return;
+    auto tile_of = [&](int r) { return first + r * stride; };
+    auto tile_valid = [&](int r) { return (int)min((int64_t)TM, a.E - (int64_t)tile_of(r) * TM); };
+    if (tid < 4 * H) {
+        const int q = tid / H, c = tid % H;
+        consts[tid] = q == 0 ? a.scale[c] : q == 1 ? a.shift[c] : q == 2 ? a.enc.b23[c] : a.enc.b2[c];
+    }
+    if (tid >= 4 * H && tid < 4 * H + 32) w1s[tid - 4 * H] = a.enc.W1[tid - 4 * H];
+    if (tid >= 4 * H + 32 && tid < 4 * H + 48) b1s[tid - 4 * H - 32] = a.enc.b1[tid - 4 * H - 32];
+    if (tid < 2 * RING) flags[tid] = 0;
+    __syncthreads();
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ compute wave: 32 rows x 32 columns, K = 16
+        const int cl = lane & 31, half = lane >> 5, col = 32 * wave + cl;
+        uint4 u1, u2, u3, v1, v2, v3;
+        {
+            const float* p = a.enc.W23 + col * 16 + 8 * half;
+            split3(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), u1, u2, u3);
+            const float* q = a.enc.W2 + col * 16 + 8 * half;
+            split3(*reinterpret_cast<const f32x4*>(q), *reinterpret_cast<const f32x4*>(q + 4), v1, v2, v3);
+        }
+        auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
+        const int lane_x = 4 * half * LDK + col;
+        for (int i = 0; i < n; ++i) {
+            const int slot = i % RING;
+            const unsigned use = (unsigned)(i / RING) + 1u;
+            flag_wait_bf(full0 + 4 * slot, 2u * use, 0);
+            const unsigned char* tp = ring + slot * SLOTB + cl * TPLD + 16 * half;
+            const uint4 c1 = *reinterpret_cast<const uint4*>(tp), c2 = *reinterpret_cast<const uint4*>(tp + TPLANE),
+                        c3 = *reinterpret_cast<const uint4*>(tp + 2 * TPLANE);
+            f32x16 ax, ae;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ax[r] = ae[r] = 0.f;
+            // smallest terms first; the two products alternate
+            ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c3), as_bf(u1), ax, 0, 0, 0);
+            ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c3), as_bf(v1), ae, 0, 0, 0);
+            ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(u3), ax, 0, 0, 0);
+            ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(v3), ae, 0, 0, 0);
+            ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c2), as_bf(u2), ax, 0, 0, 0);
+            ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c2), as_bf(v2), ae, 0, 0, 0);
+            ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c2), as_bf(u1), ax, 0, 0, 0);
+            ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c2), as_bf(v1), ae, 0, 0, 0);
+            ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(u2), ax, 0, 0, 0);
+            ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(v2), ae, 0, 0, 0);
+            ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(u1), ax, 0, 0, 0);
+            ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(v1), ae, 0, 0, 0);
+            float* X = reinterpret_cast<float*>(ring + slot * SLOTB + 3 * TPLANE) + lane_x;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                X[crow(r) * LDK] = ax[r];
+                X[TILEF + crow(r) * LDK] = ae[r];
+            }
+            flag_bump_bf(done0 + 4 * slot, lane);
+        }
+    } else {
+        // ------------------------------------------------------------------ load / store wave
+        const int group = (wave - 4) / 2;
+        const int gl = ((wave - 4) % 2) * 64 + lane;   // 0..127
+        const int r0 = gl / (H / 4), c4 = gl % (H / 4);   // epilogue role: rows r0 + 4 p, columns 4 c4 .. + 3
+        const int trow = gl >> 2, jq = gl & 3;             // encoder role: row trow, hidden units 4 jq .. + 3
+        f32x4 g1[NP], g2[NP], gk[NP];
+        int si[NP], di[NP], eid = 0;
+        float raw0 = 0.f, raw1 = 0.f;
+        const unsigned off_row = (unsigned)(r0 * H + 4 * c4);
+        auto issue_early = [&](int r) {
+            const int64_t row0 = (int64_t)tile_of(r) * TM;
+            const int valid = tile_valid(r);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {   // rows past the end of the list read the last valid row (never stored)
+                const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
+                si[p] = a.srt_src[row];
+                di[p] = a.srt_dst[row];
+            }
+            eid = a.enc.srt_eid[row0 + min(trow, valid - 1)];
+        };
+        auto issue_late = [&]() {
+            raw0 = a.enc.e_raw[2 * (int64_t)eid];
+            raw1 = a.enc.e_raw[2 * (int64_t)eid + 1];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + (int64_t)si[p] * a.ldn + 4 * c4);
+                g2[p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)di[p] * a.ldn + 4 * c4);
+            }
+        };
+        if (group < n) {
+            issue_early(group);
+            issue_late();
+        }
+        unsigned char* S = ring + group * SLOTB;
+        const float* Xs = reinterpret_cast<const float*>(S + 3 * TPLANE);
+        for (int r = group; r < n; r += RING) {
+            const unsigned use = (unsigned)(r / RING) + 1u;
+            {   // t = relu(W1 e_raw + b1) in the reference's order (models/full_graph.py:27), four hidden units of one row
+                f32x4 t;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int hu = 4 * jq + j;
+                    t[j] = fmaxf(__builtin_fmaf(raw1, w1s[2 * hu + 1], raw0 * w1s[2 * hu]) + b1s[hu], 0.f);
+                }
+                uint2 p1, p2, p3;
+                split4_planes(t, p1, p2, p3);
+                unsigned char* d = S + trow * TPLD + 8 * jq;
+                *reinterpret_cast<uint2*>(d) = p1;
+                *reinterpret_cast<uint2*>(d + TPLANE) = p2;
+                *reinterpret_cast<uint2*>(d + 2 * TPLANE) = p3;
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                gk[p] = g1[p] + g2[p];
+                asm volatile("" : "+v"(gk[p]));   // summed here, not in the epilogue (see k_edge_gate_pl)
+            }
+            flag_bump_bf(full0 + 4 * group, lane);
+            if (r + RING < n) issue_early(r + RING);
+            flag_wait_bf(done0 + 4 * group, 4u * use, a.xp & 3);
+            const int valid = tile_valid(r);
+            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(consts + 4 * c4), sh4 = *reinterpret_cast<const f32x4*>(consts + H + 4 * c4);
+            const f32x4 bx4 = *reinterpret_cast<const f32x4*>(consts + 2 * H + 4 * c4), be4 = *reinterpret_cast<const f32x4*>(consts + 3 * H + 4 * c4);
+            float* out = a.e_out + (int64_t)tile_of(r) * TM * H;
+#pragma unroll
+            for (int pb = 0; pb < NP; pb += 4) {
+                f32x4 x[4], e0[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    x[u] = *reinterpret_cast<const f32x4*>(Xs + (r0 + (pb + u) * RSTEP) * LDK + 4 * c4);
+                    e0[u] = *reinterpret_cast<const f32x4*>(Xs + TILEF + (r0 + (pb + u) * RSTEP) * LDK + 4 * c4);
+                }
+                asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = pb + u, row = r0 + p * RSTEP;
+                    f32x4 y;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = fmaxf(((x[u][j] + bx4[j]) + gk[p][j]) * sc4[j] + sh4[j], 0.f) + (e0[u][j] + be4[j]);
+                    if (row < valid) *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
+                }
+            }
+            if (r + RING < n) issue_late();
+        }
+    }
+}
+
+struct EncFoldScratch {
+    float* w23 = nullptr;   // [128*16 + 128]
+};
+static EncFoldScratch g_enc_fold[16];
+
+static int launch_enc16(const GateBfArgs& args, hipStream_t s) {
+    GateBfArgs a = args;
+    const int64_t tiles = (a.E + 31) / 32;
+    GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
+    a.num_tiles = (int)tiles;
+    a.xp = tuning(kTuneGateExperiment);
+    int dev = 0;
+    GN_HIP(hipGetDevice(&dev));
+    GN_REQUIRE(dev >= 0 && dev < 16, "edge_gate_encode: device index %d", dev);
+    // W3 W2 and W3 b2, recomputed at every call (the weights may have changed) into one small per-device buffer: calls on
+    // different streams of one device must not overlap (as for the aggregation's hub scratch)
+    if (!g_enc_fold[dev].w23) GN_HIP(hipMalloc(&g_enc_fold[dev].w23, sizeof(float) * (128 * 16 + 128)));
+    float* w23 = g_enc_fold[dev].w23;
+    hipLaunchKernelGGL(k_fold_encoder, dim3((128 * 17 + 3) / 4), dim3(256), 0, s, a.W3, a.ldw, a.enc.W2, a.enc.b2, 128, w23, w23 + 128 * 16);
+    GN_LAUNCH_CHECK();
+    a.enc.W23 = w23;
+    a.enc.b23 = w23 + 128 * 16;
+    hipLaunchKernelGGL(k_edge_gate_enc16, dim3(persistent_grid()), dim3(640), 0, s, a);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
 template <int CB, int RB, int MODE, bool ENC, bool X16 = false>
 static int launch_bf(const GateBfArgs& args, hipStream_t s) {
     using P = GateBF<CB, RB>;
@@ -702,6 +909,7 @@ int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStrea
     if (hidden == 128) {
         // mode 0: the plane form (k_edge_gate_pl) is the default, with the folded encoder too (its 24 extra registers spill
         // there, and it still measures 0.025 ms ahead); variant 8 forces the second-generation kernel
+        if (mode == 0 && enc && tuning(kTuneGateVariant) == 0) return launch_enc16(a, s);   // the encoder folded algebraically: K = 16
         if (mode == 0 && tuning(kTuneGateVariant) != 8) return enc ? launch_pl<true>(a, s) : launch_pl<false>(a, s);
         if (mode == 0) return enc ? launch_bf<4, 1, 0, true>(a, s) : launch_bf<4, 1, 0, false>(a, s);
         if (mode == 3) return launch_bf<4, 1, 3, false>(a, s);

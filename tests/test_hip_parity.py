@@ -562,6 +562,23 @@ def test_gate_plane_form_at_full_size_against_the_second_generation(kind):
     inplace = ee.clone()
     ops.edge_gate(inplace, P[:, :H], P[:, H:], gv, W3, 0, sc, sh)
     assert torch.equal(inplace, first)
+    # layer 0's form (k_edge_gate_enc16: the encoder folded algebraically, K = 16) against the second generation's, which
+    # computes e0 in fp32 and runs the K = 128 product on it: equal up to the reassociation (W3 W2) t vs W3 (W2 t)
+    e_raw = gr["e"].to(dev())
+    enc = (torch.randn(16, 2, device=dev(), generator=g), torch.randn(16, device=dev(), generator=g),
+           torch.randn(H, 16, device=dev(), generator=g) / 4, torch.randn(H, device=dev(), generator=g))
+    try:
+        ops.set_tuning(0, 8)
+        ref = ops.edge_gate_encode(e_raw, enc, P[:, :H], P[:, H:], gv, W3, sc, sh)
+    finally:
+        ops.set_tuning(0, 0)
+    scale = ref.abs().max().item()
+    first = None
+    for rep in range(5):
+        out = ops.edge_gate_encode(e_raw, enc, P[:, :H], P[:, H:], gv, W3, sc, sh)
+        assert (out - ref).abs().max().item() <= 4e-6 * scale
+        first = out if first is None else first
+        assert torch.equal(out, first)
 
 
 def test_h256_shard_of_configs3_properties():
