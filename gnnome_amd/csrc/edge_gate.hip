@@ -654,7 +654,7 @@ extern "C" int gnnome_edge_gate_raw_stats_rows(int hidden, int* rows_host) {
     using namespace gnnome;
     GN_REQUIRE(rows_host && (hidden == 64 || hidden == 128), "edge_gate_raw_stats_rows: hidden=%d not in {64,128}", hidden);
     // bf16x6 kernel (variant 0): one row per load/store wave (8 per workgroup); exact-fp32 kernel: one per row block
-    *rows_host = tuning(kTuneGateVariant) == 0 ? kNumCUs * 8 : kNumCUs * (hidden == 128 ? 1 : 2);
+    *rows_host = (tuning(kTuneGateVariant) == 0 || tuning(kTuneGateVariant) == 8) ? kNumCUs * 8 : kNumCUs * (hidden == 128 ? 1 : 2);
     return GNNOME_OK;
 }
 
@@ -670,7 +670,7 @@ static int raw_stats_impl(const float* e_in, void* x_out, int64_t num_edges, int
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0) && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0),
                "edge_gate_raw_stats: 16-byte alignment required");
     hipStream_t s = (hipStream_t)stream;
-    if (tuning(kTuneGateVariant) == 0 || x16) {
+    if (tuning(kTuneGateVariant) == 0 || tuning(kTuneGateVariant) == 8 || x16) {
         GateBfArgs a = {};
         a.e_in = e_in; a.e_out = (float*)x_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
         a.srt_dst = srt_dst; a.W3 = W3; a.ldw = ldw; a.scale = center; a.stats = stats_partial;

@@ -437,8 +437,13 @@ __device__ __forceinline__ void split4_planes(const f32x4 x, uint2& p1, uint2& p
     p3 = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
 }
 
-template <bool ENC>
+// MODE 0: the inference gate.  MODE 1: raw gate + shifted column sums (training forward; a.scale = the centres).  MODE 3: the
+// BatchNorm backward + data gradient of k_edge_gate_bf's mode 3 (A computed by the load waves from the old C rows and the rows at
+// e_in, written to bnb.a_out; C += A W^T).  X16: xe / dxe stored as bf16 (see common.h).  Modes 1 and 3 hold no e rows for a residual.
+template <bool ENC, int MODE = 0, bool X16 = false>
 __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
+    static_assert(MODE == 0 || MODE == 1 || MODE == 3, "modes of the plane form");
+    static_assert(!ENC || MODE == 0, "the folded encoder belongs to the inference gate");
     constexpr int H = 128, TM = 32, RING = 4, KS = H / 16, LDK = H + 4, PLD = 2 * H + 16, PLANE = TM * PLD, SLOTB = 3 * PLANE;
     constexpr int NP = 8, RSTEP = 4, NT = 768;
     static_assert(TM * LDK * 4 <= SLOTB, "the x tile reuses the planes' slot");
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char ring[RING * SLOTB];
     __shared__ __attribute__((aligned(16))) float encw[kEncFloats];
     __shared__ unsigned flags[4 * RING];   // full[RING], rd[RING], done[RING], drained[RING]
-    __shared__ __attribute__((aligned(16))) float norm_lds[2 * H];   // scale | shift: the epilogue reads them per tile (no global load there)
+    __shared__ __attribute__((aligned(16))) float norm_lds[7 * H];   // per-channel constants of the mode, read per tile from here (no global load in the loop)
     float* w2t = encw;                     // ENC only
     float* b2s = w2t + 16 * H;
     float* w1s = b2s + H;
@@ -470,7 +475,15 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
         if (tid < 16) b1s[tid] = a.enc.b1[tid];
     }
     if (tid < 4 * RING) flags[tid] = 0;
-    if (tid >= 64 && tid < 64 + 2 * H) norm_lds[tid - 64] = tid - 64 < H ? a.scale[tid - 64] : a.shift[tid - 64 - H];
+    for (int i = tid; i < 7 * H; i += NT) {
+        const int q = i / H, c = i % H;
+        if (MODE == 0 && q < 2) norm_lds[i] = q == 0 ? a.scale[c] : a.shift[c];
+        if (MODE == 1 && q < 1) norm_lds[i] = a.scale[c];   // the columns' centres
+        if (MODE == 3) {
+            const float* src = q == 0 ? a.bnb.a : q == 1 ? a.bnb.c1 : q == 2 ? a.bnb.c2 : q == 3 ? a.bnb.mean : q == 4 ? a.bnb.rstd : q == 5 ? a.bnb.scale : a.bnb.shift;
+            norm_lds[i] = src[c];
+        }
+    }
     __syncthreads();
 
     if (wave < 4) {
@@ -547,8 +560,10 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {   // rows past the end of the list read the last valid row (never stored)
                 const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
-                si[p] = a.srt_src[row];
-                di[p] = a.srt_dst[row];
+                if (MODE != 3) {
+                    si[p] = a.srt_src[row];
+                    di[p] = a.srt_dst[row];
+                }
                 if (ENC) ei[p] = a.enc.srt_eid[row];
             }
         };
@@ -560,10 +575,12 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
-                av[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + 4 * c4);
+                av[p] = load4_as<(X16 && MODE == 3)>(a.e_in, row * H + 4 * c4);   // mode 3: the xe rows
+                if (MODE == 3) g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * a.ldn + 4 * c4);   // the old rows of C
             }
         };
         auto issue_late = [&](int) {
+            if (MODE == 3) return;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 if (ENC) {
@@ -601,12 +618,33 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
         unsigned char* S = ring + group * SLOTB;
         const float* Xs = reinterpret_cast<const float*>(S);
         long long t_top = 0, t_split = 0, t_done = 0, t_epi = 0, t0 = 0, t1 = 0;
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1;   // MODE 1: this lane's running shifted sums of its four columns
         for (int r = group; r < n; r += RING) {
             const unsigned use = (unsigned)(r / RING) + 1u;
-            if (a.prof) { t0 = __builtin_readcyclecounter(); asm volatile("" ::"v"(av[0][0]), "v"(g1[NP - 1][0]), "v"(g2[NP - 1][0])); t1 = __builtin_readcyclecounter(); t_top += t1 - t0; t0 = t1; }
+            if (a.prof) { t0 = __builtin_readcyclecounter(); asm volatile("" ::"v"(av[0][0]), "v"(g1[NP - 1][0])); t1 = __builtin_readcyclecounter(); t_top += t1 - t0; t0 = t1; }
             // The slot is free once BOTH waves of the group have read the previous x tile out of it: the planes of a row do not
             // lie where its x row lay, so one wave's plane stores would land on x rows the other wave has yet to read.
             flag_wait_bf(drained0 + 4 * group, 2u * (use - 1u), 0);
+            if (MODE == 3) {
+                // A = BatchNorm backward of (dy = the old C rows, x = the xe rows) for this lane's four columns, written out as dxe
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4), k1 = *reinterpret_cast<const f32x4*>(norm_lds + H + 4 * c4);
+                const f32x4 k2 = *reinterpret_cast<const f32x4*>(norm_lds + 2 * H + 4 * c4), km = *reinterpret_cast<const f32x4*>(norm_lds + 3 * H + 4 * c4);
+                const f32x4 kr = *reinterpret_cast<const f32x4*>(norm_lds + 4 * H + 4 * c4), ks = *reinterpret_cast<const f32x4*>(norm_lds + 5 * H + 4 * c4);
+                const f32x4 kh = *reinterpret_cast<const f32x4*>(norm_lds + 6 * H + 4 * c4);
+                const int valid3 = tile_valid(r);
+                const int64_t base3 = (int64_t)tile_of(r) * TM * H;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    f32x4 t;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gm = (av[p][j] * ks[j] + kh[j] > 0.f) ? g1[p][j] : 0.f;
+                        t[j] = ka[j] * (gm - k1[j] - (av[p][j] - km[j]) * kr[j] * k2[j]);
+                    }
+                    av[p] = t;
+                    if (r0 + p * RSTEP < valid3) store4_as<X16>(a.bnb.a_out, base3 + (off_row + (unsigned)(p * RSTEP * H)), t);
+                }
+            }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 uint2 p1, p2, p3;
@@ -615,8 +653,8 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                 *reinterpret_cast<uint2*>(d) = p1;
                 *reinterpret_cast<uint2*>(d + PLANE) = p2;
                 *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
-                ek[p] = av[p];
-                gk[p] = g1[p] + g2[p];
+                if (MODE == 0) ek[p] = av[p];
+                gk[p] = MODE == 3 ? g1[p] : g1[p] + g2[p];
                 // G is summed HERE, not where it is used: sunk into the epilogue, the sum would drag the wait for the gathers
                 // behind that epilogue's own stores (one in-order counter for loads and stores) and stall on their completion
                 asm volatile("" : "+v"(gk[p]));
@@ -627,8 +665,10 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
             flag_wait_bf(done0 + 4 * group, 4u * use, a.xp & 3);
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_done += t1 - t0; t0 = t1; }
             const int valid = tile_valid(r);
+            // MODE 0: scale, shift; MODE 1: sc4 = the centres; MODE 3: unused
             const f32x4 sc4 = *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4), sh4 = *reinterpret_cast<const f32x4*>(norm_lds + H + 4 * c4);
             float* out = a.e_out + (int64_t)tile_of(r) * TM * H;
+            const int64_t obase = (int64_t)tile_of(r) * TM * H;
             // four x pieces are read together, BEFORE the row-validity branches: one LDS round trip (~400 cycles with the compute
             // waves reading planes flat out) per four pieces instead of one per piece
 #pragma unroll
@@ -641,9 +681,24 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                 for (int u = 0; u < 4; ++u) {
                     const int p = pb + u, row = r0 + p * RSTEP;
                     f32x4 y;
+                    if (MODE == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + gk[p][j]) * sc4[j] + sh4[j], 0.f) + ek[p][j];
-                    if (row < valid) *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
+                        for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + gk[p][j]) * sc4[j] + sh4[j], 0.f) + ek[p][j];
+                        if (row < valid) *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
+                    } else {
+                        y = x[u] + gk[p];
+                        if (MODE == 1 && X16) y = unpack_bf16x4(pack_bf16x4(y));   // the statistics are those of the stored values
+                        if (row < valid) {
+                            if (MODE == 1) {
+                                const f32x4 dlt = y - sc4;
+                                st1 += dlt;
+                                st2 += dlt * dlt;
+                                store4_as<X16>(a.e_out, obase + (off_row + (unsigned)(p * RSTEP * H)), y);
+                            } else {
+                                *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
+                            }
+                        }
+                    }
                 }
             }
             flag_bump_bf(drained0 + 4 * group, lane);
@@ -655,6 +710,20 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                 if (ENC) encode_pending();
             }
         }
+        if (MODE == 1) {
+            // lanes l and l + 32 hold different rows of the same four columns: fold them, then every load wave leaves one row of
+            // partial sums (stats[(block * 2 RING + wave - 4)][2H], the layout of k_edge_gate_bf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                st1[j] += __shfl_xor(st1[j], 32);
+                st2[j] += __shfl_xor(st2[j], 32);
+            }
+            if (lane < H / 4) {
+                float* dst = a.stats + ((int64_t)blockIdx.x * (RING * 2) + (wave - 4)) * 2 * H;
+                *reinterpret_cast<f32x4*>(dst + 4 * c4) = st1;
+                *reinterpret_cast<f32x4*>(dst + H + 4 * c4) = st2;
+            }
+        }
         if (a.prof && wave == 4 && lane == 0) {   // the first load wave's phases, after the 256 compute-wave records
             long long* o = a.prof + (int64_t)(256 + blockIdx.x) * 8;
             o[0] = t_top; o[1] = t_split; o[2] = t_done; o[3] = t_epi; o[4] = (n + RING - 1) / RING;
@@ -662,7 +731,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
     }
 }
 
-template <bool ENC>
+template <bool ENC, int MODE = 0, bool X16 = false>
 static int launch_pl(const GateBfArgs& args, hipStream_t s) {
     GateBfArgs a = args;
     const int64_t tiles = (a.E + 31) / 32;
@@ -670,7 +739,8 @@ static int launch_pl(const GateBfArgs& args, hipStream_t s) {
     a.num_tiles = (int)tiles;
     a.xp = tuning(kTuneGateExperiment);
     a.prof = g_gate_prof;
-    hipLaunchKernelGGL((k_edge_gate_pl<ENC>), dim3(persistent_grid()), dim3(768), 0, s, a);
+    if (MODE == 1) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * kNumCUs * 8 * 2 * 128, s));   // idle waves leave zeros
+    hipLaunchKernelGGL((k_edge_gate_pl<ENC, MODE, X16>), dim3(persistent_grid()), dim3(768), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
@@ -900,7 +970,10 @@ static int launch_bf(const GateBfArgs& args, hipStream_t s) {
 }
 
 int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStream_t s, bool x16) {
+    const bool planes = hidden == 128 && tuning(kTuneGateVariant) != 8;   // the plane form (k_edge_gate_pl), modes 0, 1 and 3
     if (x16) {   // bf16 storage of xe / dxe: modes 1 and 3 only
+        if (mode == 1 && planes) return launch_pl<false, 1, true>(a, s);
+        if (mode == 3 && planes) return launch_pl<false, 3, true>(a, s);
         if (mode == 1) return hidden == 128 ? launch_bf<4, 1, 1, false, true>(a, s) : launch_bf<2, 2, 1, false, true>(a, s);
         if (mode == 3) return hidden == 128 ? launch_bf<4, 1, 3, false, true>(a, s) : launch_bf<2, 2, 3, false, true>(a, s);
         set_error("edge-tile kernel: bf16 storage exists for modes 1 and 3 only");
@@ -911,6 +984,8 @@ int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStrea
         // there, and it still measures 0.025 ms ahead); variant 8 forces the second-generation kernel
         if (mode == 0 && enc && tuning(kTuneGateVariant) == 0) return launch_enc16(a, s);   // the encoder folded algebraically: K = 16
         if (mode == 0 && tuning(kTuneGateVariant) != 8) return enc ? launch_pl<true>(a, s) : launch_pl<false>(a, s);
+        if (mode == 1 && planes) return launch_pl<false, 1>(a, s);
+        if (mode == 3 && planes) return launch_pl<false, 3>(a, s);
         if (mode == 0) return enc ? launch_bf<4, 1, 0, true>(a, s) : launch_bf<4, 1, 0, false>(a, s);
         if (mode == 3) return launch_bf<4, 1, 3, false>(a, s);
         return mode == 1 ? launch_bf<4, 1, 1, false>(a, s) : launch_bf<4, 1, 2, false>(a, s);

@@ -562,6 +562,29 @@ def test_gate_plane_form_at_full_size_against_the_second_generation(kind):
     inplace = ee.clone()
     ops.edge_gate(inplace, P[:, :H], P[:, H:], gv, W3, 0, sc, sh)
     assert torch.equal(inplace, first)
+    # the training modes of the plane form: raw gate + statistics (mode 1) and BatchNorm backward + data gradient (mode 3)
+    a_, c1, c2 = torch.rand(H, device=dev(), generator=g) + 0.5, 0.1 * sh, 0.1 * sc
+    mean, rstd = sh * 0.5, torch.rand(H, device=dev(), generator=g) + 0.5
+
+    def raw_gate():
+        xe, (d1, d2, c, rows) = ops.edge_gate_raw_moments(ee, P[:, :H], P[:, H:], gv, W3)
+        return xe, d1, d2
+
+    def bn_backward(xe):   # (the relu mask is discontinuous in xe: both kernels get the SAME xe)
+        C = ee.clone()
+        dxe = ops.bn_bwd_dgrad(C, xe, sc + 0.5, sh, a_, c1, c2, mean, rstd, W3)
+        return dxe, C
+    try:
+        ops.set_tuning(0, 8)
+        want_raw = raw_gate()
+        want_bwd = bn_backward(want_raw[0])
+    finally:
+        ops.set_tuning(0, 0)
+    for rep in range(3):
+        got_raw, got_bwd = raw_gate(), bn_backward(want_raw[0])
+        for gt, wt, tol in zip(got_raw + got_bwd, want_raw + want_bwd, (2e-6, 2e-5, 2e-5, 2e-6, 2e-6)):
+            assert (gt - wt).abs().max().item() <= tol * max(1.0, wt.abs().max().item())
+        assert all(torch.equal(u, v) for u, v in zip(got_raw + got_bwd, raw_gate() + bn_backward(want_raw[0])))
     # layer 0's form (k_edge_gate_enc16: the encoder folded algebraically, K = 16) against the second generation's, which
     # computes e0 in fp32 and runs the K = 128 product on it: equal up to the reassociation (W3 W2) t vs W3 (W2 t)
     e_raw = gr["e"].to(dev())
