@@ -400,12 +400,13 @@ def main():
         t2 = time.perf_counter()
         # a FRESH graph in a warm process (the reference builds new graph objects per call when it masks, train.py:96,336):
         # the edge list reversed, so no cache can apply
-        t3 = time.perf_counter()
-        views2 = ops.GraphViews(dst, src, n, validate="lazy")
-        ops.degree_features(views2)
-        torch.cuda.synchronize()
-        t4 = time.perf_counter()
-        del views2
+        for _ in range(2):   # (the first of the two pays the one-time load of the deferred range check's kernel)
+            t3 = time.perf_counter()
+            views2 = ops.GraphViews(dst, src, n, validate="lazy")
+            ops.degree_features(views2)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            del views2
         cold = {"graph_views_and_features_ms": (t1 - t0) * 1e3, "first_call_ms": (t2 - t1) * 1e3,
                 "fresh_graph_warm_process_ms": (t4 - t3) * 1e3,
                 "note": "first call = weight preparation + allocator growth + one forward; the first view build pays the process's "
