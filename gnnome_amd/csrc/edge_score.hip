@@ -108,6 +108,182 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_score(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight-stationary streaming form (hs = 64, H in {64,128}; the inference path).  The tile kernel above re-stages and
+// re-splits W1e for every 128-edge tile and synchronises the workgroup eight times per tile.  Here W1e lives in LDS as
+// three bf16 planes for the whole launch (52 KB at H = 128); every wave owns 32 edges at a time and streams their e rows
+// STRAIGHT FROM GLOBAL MEMORY INTO MFMA FRAGMENTS (each e row is read exactly once: one 64-column chunk), parks e W1e^T in a
+// wave-private LDS tile, adds Ps[src] + Qd[dst] there row-wise (16-byte gathers, 16 lanes per row), and runs the 64 -> 32 -> 1
+// tail from that tile.  One barrier per launch; 8 waves per workgroup, one workgroup per CU.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void score_split8(const f32x4 lo4, const f32x4 hi4, uint4& p1, uint4& p2, uint4& p3) {
+    uint2 l1, l2, l3, h1, h2, h3;
+    tile_split4(lo4, l1, l2, l3);
+    tile_split4(hi4, h1, h2, h3);
+    p1 = make_uint4(l1.x, l1.y, h1.x, h1.y);
+    p2 = make_uint4(l2.x, l2.y, h2.x, h2.y);
+    p3 = make_uint4(l3.x, l3.y, h3.x, h3.y);
+}
+
+template <int K>
+__global__ __launch_bounds__(512) void k_edge_score_ws(
+    const float* __restrict__ e, int64_t E, const float* __restrict__ Ps, const float* __restrict__ Qd, int ldn,
+    const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const int32_t* __restrict__ srt_eid,
+    const float* __restrict__ W1e, int ldw1, const float* __restrict__ W2, const float* __restrict__ b2,
+    const float* __restrict__ W3, const float* __restrict__ b3, float* __restrict__ logits, int num_tiles, int tiles_per_group) {
+    constexpr int NW = 8, HS = 64, PLD = 2 * K + 16, PB = HS * PLD, KS = K / 16, LDZ = HS + 4, BATCH = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char Wp[3 * PB];
+    __shared__ __attribute__((aligned(16))) float W2s[32 * LDZ];
+    __shared__ __attribute__((aligned(16))) float Zall[NW * 32 * LDZ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 31, half = lane >> 5;
+    for (int f = tid; f < HS * (K / 8); f += 64 * NW) {   // split W1e once: eight consecutive k of one row per piece
+        const int row = f / (K / 8), c8 = f % (K / 8);
+        const float* src = W1e + (int64_t)row * ldw1 + 8 * c8;
+        uint4 p1, p2, p3;
+        score_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), p1, p2, p3);
+        unsigned char* dst = Wp + row * PLD + 16 * c8;
+        *reinterpret_cast<uint4*>(dst) = p1;
+        *reinterpret_cast<uint4*>(dst + PB) = p2;
+        *reinterpret_cast<uint4*>(dst + 2 * PB) = p3;
+    }
+    for (int i = tid; i < 32 * HS; i += 64 * NW) W2s[(i / HS) * LDZ + (i % HS)] = W2[i];
+    const float bias2 = b2[cl], w3 = W3[cl], bias3 = b3[0];
+    __syncthreads();   // the only barrier
+
+    auto bf = [](const uint4 v) { return __builtin_bit_cast(tile_bf16x8, v); };
+    float* Zs = Zall + wave * 32 * LDZ;
+    const unsigned char* wp = Wp + cl * PLD + 16 * half;
+    const int t0 = blockIdx.x * tiles_per_group, t_end = min(num_tiles, t0 + tiles_per_group);
+    for (int t = t0 + wave; t < t_end; t += NW) {
+        const int64_t row0 = (int64_t)t * 32;
+        const int valid = (int)min((int64_t)32, E - row0);
+        // Ps[src] + Qd[dst], row-wise: lane l takes rows 4 i + (l >> 4), columns 4 (l & 15) .. + 3; issued first, consumed last
+        const int grow = lane >> 4, gc4 = lane & 15;
+        int si[8], di[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t row = row0 + min(4 * i + grow, valid - 1);
+            si[i] = srt_src[row];
+            di[i] = srt_dst[row];
+        }
+        // e rows -> fragments (8 consecutive k of one row per lane and K = 16 step), BATCH steps in flight ahead of the MFMAs
+        const float* ap = e + (row0 + min(cl, valid - 1)) * K + 8 * half;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        f32x4 x[BATCH][2];
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+            x[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * q);
+            x[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * q + 4);
+        }
+#pragma unroll
+        for (int hq = 0; hq < KS; hq += BATCH) {
+            f32x4 nx[BATCH][2];
+            const int hn = hq + BATCH < KS ? hq + BATCH : hq;
+#pragma unroll
+            for (int q = 0; q < BATCH; ++q) {
+                nx[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * (hn + q));
+                nx[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * (hn + q) + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < BATCH; ++q) {
+                uint4 a1, a2, a3;
+                score_split8(x[q][0], x[q][1], a1, a2, a3);
+                const unsigned char* w = wp + 32 * (hq + q);
+                const uint4 u1 = *reinterpret_cast<const uint4*>(w), u2 = *reinterpret_cast<const uint4*>(w + PB),
+                            u3 = *reinterpret_cast<const uint4*>(w + 2 * PB);
+                const uint4 v1 = *reinterpret_cast<const uint4*>(w + 32 * PLD), v2 = *reinterpret_cast<const uint4*>(w + 32 * PLD + PB),
+                            v3 = *reinterpret_cast<const uint4*>(w + 32 * PLD + 2 * PB);
+                // smallest terms first; the two column blocks alternate
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a3), bf(u1), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a3), bf(v1), acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(u3), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(v3), acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2), bf(u2), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2), bf(v2), acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2), bf(u1), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2), bf(v1), acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(u2), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(v2), acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(u1), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1), bf(v1), acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < BATCH; ++q) {
+                x[q][0] = nx[q][0];
+                x[q][1] = nx[q][1];
+            }
+        }
+        // the gathers (their indices arrived under the GEMM)
+        f32x4 g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            g[i] = *reinterpret_cast<const f32x4*>(Ps + (int64_t)si[i] * ldn + 4 * gc4) + *reinterpret_cast<const f32x4*>(Qd + (int64_t)di[i] * ldn + 4 * gc4);
+        // e W1e^T -> the wave's LDS tile (accumulator layout), then relu(. + G) row-wise in place
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = cd_row(r, lane);
+            Zs[lr * LDZ + cl] = acc0[r];
+            Zs[lr * LDZ + 32 + cl] = acc1[r];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float* zr = Zs + (4 * i + grow) * LDZ + 4 * gc4;
+            f32x4 z = *reinterpret_cast<const f32x4*>(zr) + g[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = fmaxf(z[j], 0.f);
+            *reinterpret_cast<f32x4*>(zr) = z;
+        }
+        // z2 = relu(W2 z1 + b2) on the exact-fp32 matrix cores (K = 64), logit = W3 . z2 + b3
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = bias2;
+        const float* zp = Zs + cl * LDZ + 4 * half;
+        const float* w2p = W2s + cl * LDZ + 4 * half;
+#pragma unroll
+        for (int q = 0; q < HS / 8; ++q) {
+            const f32x4 za = *reinterpret_cast<const f32x4*>(zp + 8 * q);
+            const f32x4 wb = *reinterpret_cast<const f32x4*>(w2p + 8 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(za[k], wb[k], acc2, 0, 0, 0);
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sum = half_wave_sum(fmaxf(acc2[r], 0.f) * w3);
+            if (cl == r) mine = sum;
+        }
+        if (cl < 16) {
+            const int lr = cd_row(cl, lane);
+            if (lr < valid) {
+                const int64_t p = row0 + lr;
+                const int64_t eid = srt_eid != nullptr ? (int64_t)srt_eid[p] : p;
+                logits[eid] = mine + bias3;
+            }
+        }
+    }
+}
+
+template <int K>
+static int launch_score_ws(const float* e, int64_t E, const float* Ps, const float* Qd, int ldn, const int32_t* ss,
+                           const int32_t* sd, const int32_t* se, const float* W1e, int ldw1, const float* W2, const float* b2,
+                           const float* W3, const float* b3, float* logits, hipStream_t s) {
+    const int64_t tiles = (E + 31) / 32;
+    GN_REQUIRE(tiles < (1ll << 31), "edge_score: too many tiles");
+    int groups = persistent_grid();
+    if (groups > (tiles + 7) / 8) groups = (int)((tiles + 7) / 8);
+    const int tpg = (int)((tiles + groups - 1) / groups);
+    hipLaunchKernelGGL((k_edge_score_ws<K>), dim3(groups), dim3(512), 0, s, e, E, Ps, Qd, ldn, ss, sd, se, W1e, ldw1, W2, b2, W3, b3, logits,
+                       (int)tiles, tpg);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
 template <int NBH, int NBS>
 static int launch_score(const float* e, int64_t E, const float* Ps, const float* Qd, int ldn, const int32_t* ss,
                         const int32_t* sd, const int32_t* se, const float* W1e, int ldw1, const float* W2, const float* b2,
@@ -146,6 +322,12 @@ extern "C" int gnnome_edge_score_f32(const float* e, int64_t num_edges, int hidd
     GN_REQUIRE(ld_node >= hidden_edge_scores && ldw1 >= hidden && ldw1 % 4 == 0, "edge_score: bad strides");
     GN_REQUIRE(((uintptr_t)e % 16 == 0) && ((uintptr_t)W1e % 16 == 0), "edge_score: e and W1e must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    // inference at hs = 64: the weight-stationary streaming kernel (gnnome_set_tuning(2, 1) = the tile kernels keeps the old one)
+    if (z1_out == nullptr && hidden_edge_scores == 64 && (hidden == 64 || hidden == 128) && ld_node % 4 == 0 &&
+        ((uintptr_t)Ps % 16 == 0) && ((uintptr_t)Qd % 16 == 0) && tuning(kTuneLinearVariant) != 1) {
+        if (hidden == 128) return launch_score_ws<128>(e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s);
+        return launch_score_ws<64>(e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s);
+    }
     switch (hidden) {
         case 64: return dispatch_hs<2>(hidden_edge_scores, e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s, z1_out);
         case 128: return dispatch_hs<4>(hidden_edge_scores, e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s, z1_out);

@@ -297,6 +297,32 @@ def test_edge_score(hidden, hs):
         _assert_close(got, want, scale=20.0)
 
 
+@pytest.mark.parametrize("hidden,e", [(128, 1), (128, 33), (128, 400_003), (64, 70_001), (128, 8 * 32 * 256 + 5)])
+def test_edge_score_streaming_kernel_against_the_tile_kernel(hidden, e):
+    """k_edge_score_ws (inference, hs = 64: W1e stationary in LDS, e rows streamed into MFMA fragments, wave-private tail)
+    against the 128-edge tile kernel behind the same entry point (gnnome_set_tuning(2, 1)): one edge, a ragged last tile,
+    fewer tiles than waves, more tiles than one round of the persistent grid; scattered and sorted output; repeatable."""
+    hs, n = 64, max(8, e // 9)
+    g = torch.Generator().manual_seed(hidden + e)
+    src, dst = _rand_graph(n, e, hidden + e)
+    gv, _ = _views_pair(src, dst, n)
+    ee = (2.0 * torch.randn(e, hidden, generator=g)).to(dev())
+    PQ = torch.randn(n, 2 * hs, generator=g).to(dev())
+    W1e = (torch.randn(hs, hidden, generator=g) / hidden ** 0.5).to(dev())
+    W2, b2 = (torch.randn(32, hs, generator=g) / hs ** 0.5).to(dev()), torch.randn(32, generator=g).to(dev())
+    W3, b3 = torch.randn(32, generator=g).to(dev()), torch.randn(1, generator=g).to(dev())
+    for scatter in (True, False):
+        run = lambda: ops.edge_score(ee, PQ[:, :hs], PQ[:, hs:], gv, W1e, W2, b2, W3, b3, torch.zeros(e, device=dev()), scatter_to_edge_id=scatter)  # noqa: E731
+        got = run()
+        try:
+            ops.set_tuning(2, 1)
+            ref = run()
+        finally:
+            ops.set_tuning(2, 0)
+        assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+        assert torch.equal(got, run())
+
+
 @pytest.mark.parametrize("hidden", [64, 128])
 @pytest.mark.parametrize("e_count", [777, 90_001])
 def test_edge_gate_with_folded_encoder(hidden, e_count):
