@@ -509,10 +509,17 @@ def main():
         kt.on = False
     # untimed diagnostic pass: every kernel family instrumented, for the per-kernel table only
     others = [] if args.no_kernel_timers or world > 1 else ["node_aggregate", "linear", "edge_score", "encode"]
+    from gnnome_amd import engine
+    chunks_timed = engine.PIPELINE_CHUNKS if (world == 1 and n >= engine.PIPELINE_MIN_NODES) else 1
     with KernelTimer(ops, others) as kd:
         kd.on = True
-        for _ in range(min(args.steps, 5)):
-            step()
+        if others:
+            engine.PIPELINE_CHUNKS = 1   # the per-kernel table wants every kernel alone on the chip, one launch per layer
+        try:
+            for _ in range(min(args.steps, 5)):
+                step()
+        finally:
+            engine.PIPELINE_CHUNKS = chunks_timed if chunks_timed > 1 else engine.PIPELINE_CHUNKS
         barrier()
     timed = dominant
     if world > 1:
@@ -534,6 +541,8 @@ def main():
             "mfma_f32_frac_whole_fwd": (f_fwd / (ms * 1e-3)) / (world * MFMA_F32_PEAK),
             "algorithmic_bytes_fwd": b_fwd, "algorithmic_flops_fwd": f_fwd, "cold": cold, "timed_region_s": elapsed,
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "so_sha16": so_sha16(),
+            "streams": (f"2: every node projection after the first runs on a second HIP stream under the aggregation, which is cut into "
+                        f"{chunks_timed} node ranges (engine.aggregate_then_project)") if chunks_timed > 1 else "1",
         }
         res.update(extras)
         if "scaling_reference" in extras:

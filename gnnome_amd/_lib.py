@@ -30,6 +30,7 @@ SIGNATURES = {
     "gnnome_linear_ref_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "gnnome_edge_gate_ref_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_node_aggregate_f32": [_p, _i, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
+    "gnnome_node_aggregate_range_f32": [_p, _i, _l, _l, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
     "gnnome_edge_score_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_edge_gate_raw_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p],
     "gnnome_edge_gate_raw_stats_rows": [_i, ctypes.POINTER(_i)],

@@ -15,6 +15,7 @@ template <int K>
 struct GateStream {
     static constexpr int NW = 8, NT = 64 * NW, TM = 32 * NW, NC = 64, PLD = 2 * K + 16, kPlaneBytes = NC * PLD;
     static constexpr int kWPieces = NC * (K / 4) / NT;
+    static constexpr int TLD = 40;   // floats per row of the epilogue tile: the two half waves' rows (4 apart) land 32 banks apart
     static_assert(NC * (K / 4) % NT == 0, "piece count");
 };
 
@@ -25,8 +26,9 @@ __global__ __launch_bounds__(512) void k_edge_gate_stream(const float* __restric
                                                           const float* __restrict__ W3, int ldw, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int num_tiles, int tiles_per_group) {
     using P = GateStream<K>;
-    constexpr int PLD = P::PLD, PB = P::kPlaneBytes, KS = K / 16, H = K;
+    constexpr int PLD = P::PLD, PB = P::kPlaneBytes, KS = K / 16, H = K, NB = KS / 4;
     __shared__ __attribute__((aligned(16))) unsigned char Wp[3 * PB];
+    __shared__ __attribute__((aligned(16))) float T[P::NW][32 * P::TLD];   // per-wave epilogue tile (see below)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 31, half = lane >> 5;
@@ -43,59 +45,79 @@ __global__ __launch_bounds__(512) void k_edge_gate_stream(const float* __restric
         *reinterpret_cast<uint2*>(dst + PB) = p2;
         *reinterpret_cast<uint2*>(dst + 2 * PB) = p3;
     }
-    const float sc0 = scale[col0 + cl], sc1 = scale[col0 + 32 + cl], sh0 = shift[col0 + cl], sh1 = shift[col0 + 32 + cl];
     __syncthreads();   // the only barrier
 
     auto bf = [](const uint4 v) { return __builtin_bit_cast(tile_bf16x8, v); };
-    const unsigned char* wp = Wp + cl * PLD + 16 * half;
+    // k numbering of the matrix-core steps (the same for both operands, see the A fragments below): step 4 b + q of the lower /
+    // upper half wave takes k in [64 b + 32 half + 8 q, + 8)
+    const unsigned char* wp = Wp + cl * PLD + 64 * half;   // + 128 b + 16 q
+    // Epilogue layout: the accumulators (a column per lane, 16 rows in registers) go through a wave-private 32 x 32 LDS tile and
+    // come back ROW-major - lane l holds columns 4 (l % 8) .. + 3 of rows l / 8 + 8 it (it < 4) - so that the gathers of
+    // B1h[src] / B2h[dst], the residual and the stores are 16-byte pieces, eight lanes to a 128-byte row segment: 16 + 8 + 8
+    // vector-memory instructions per 32 x 64 block where the accumulator layout needed 64 + 32 + 32 dword ones.
+    float* tile = &T[wave][0];
+    const int er = lane >> 3, ec = 4 * (lane & 7);
+    f32x4 sc[2], sh[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        sc[cb] = *reinterpret_cast<const f32x4*>(scale + col0 + 32 * cb + ec);
+        sh[cb] = *reinterpret_cast<const f32x4*>(shift + col0 + 32 * cb + ec);
+    }
     for (int t = t0; t < t_end; ++t) {
         const int64_t row0 = (int64_t)t * P::TM + 32 * wave;
         if (row0 >= E) continue;
         const int64_t arow = min(row0 + cl, E - 1);   // rows past the end read the last row (never stored)
         // the gathers of this tile go out first; they are consumed after the MFMA loop
         const int my_s = srt_src[arow], my_d = srt_dst[arow];
-        float g0[16], g1[16];
+        f32x4 b1[2][4], b2[2][4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = cd_row(r, lane);
-            const int s = __shfl(my_s, lr), d = __shfl(my_d, lr);
-            const float* p1 = B1h + (int64_t)s * ldn + col0 + cl;
-            const float* p2 = B2h + (int64_t)d * ldn + col0 + cl;
-            g0[r] = p1[0] + p2[0];
-            g1[r] = p1[32] + p2[32];
+        for (int it = 0; it < 4; ++it) {
+            const int64_t so = (int64_t)__shfl(my_s, er + 8 * it) * ldn + col0 + ec, dof = (int64_t)__shfl(my_d, er + 8 * it) * ldn + col0 + ec;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                b1[cb][it] = *reinterpret_cast<const f32x4*>(B1h + so + 32 * cb);
+                b2[cb][it] = *reinterpret_cast<const f32x4*>(B2h + dof + 32 * cb);
+            }
         }
-        const float* ap = e_in + arow * H + 8 * half;  // + 16 q
+        // A fragments.  The k index a lane feeds into a matrix-core step is free as long as the W operand uses the same one (the
+        // product is a sum over k), so the steps are numbered such that a lane's share of FOUR consecutive steps is one whole
+        // 128-byte line of its row, fetched with eight back-to-back 16-byte loads.
+        const float* ap = e_in + arow * H + 32 * half;  // + 64 b
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             acc0[r] = 0.f;
             acc1[r] = 0.f;
         }
-        // fragments are fetched two K = 16 steps at a time, one batch AHEAD of the MFMAs that consume them
-        f32x4 x[2][2];
+        f32x4 x[8];   // one batch AHEAD of the MFMAs that consume it
+        f32x4 res[2][4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            x[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * q);
-            x[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * q + 4);
-        }
+        for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
 #pragma unroll
-        for (int hq = 0; hq < KS; hq += 2) {
-            f32x4 nx[2][2];
-            const int hn = hq + 2 < KS ? hq + 2 : hq;
+        for (int b = 0; b < NB; ++b) {
+            f32x4 nx[8];
+            if (b + 1 < NB) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                nx[q][0] = *reinterpret_cast<const f32x4*>(ap + 16 * (hn + q));
-                nx[q][1] = *reinterpret_cast<const f32x4*>(ap + 16 * (hn + q) + 4);
+                for (int i = 0; i < 8; ++i) nx[i] = *reinterpret_cast<const f32x4*>(ap + 64 * (b + 1) + 4 * i);
+            } else {
+                // last batch: nothing left to prefetch for the product - the registers of the look-ahead batch take the
+                // residual values of the epilogue instead, so that their latency runs under these 48 MFMAs
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const float* rp = e_in + min(row0 + er + 8 * it, E - 1) * H + col0 + ec;
+                    res[0][it] = *reinterpret_cast<const f32x4*>(rp);
+                    res[1][it] = *reinterpret_cast<const f32x4*>(rp + 32);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);   // the next batch's loads are in flight before this batch's MFMAs start
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 uint2 l1, l2, l3, h1, h2, h3;
-                tile_split4(x[q][0], l1, l2, l3);
-                tile_split4(x[q][1], h1, h2, h3);
+                tile_split4(x[2 * q], l1, l2, l3);
+                tile_split4(x[2 * q + 1], h1, h2, h3);
                 const uint4 a1 = make_uint4(l1.x, l1.y, h1.x, h1.y), a2 = make_uint4(l2.x, l2.y, h2.x, h2.y),
                             a3 = make_uint4(l3.x, l3.y, h3.x, h3.y);
-                const unsigned char* w = wp + 32 * (hq + q);
+                const unsigned char* w = wp + 128 * b + 16 * q;
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
                     const uint4 w1 = *reinterpret_cast<const uint4*>(w + cb * 32 * PLD), w2 = *reinterpret_cast<const uint4*>(w + cb * 32 * PLD + PB),
@@ -115,24 +137,27 @@ __global__ __launch_bounds__(512) void k_edge_gate_stream(const float* __restric
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (b + 1 < NB) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                x[q][0] = nx[q][0];
-                x[q][1] = nx[q][1];
+                for (int i = 0; i < 8; ++i) x[i] = nx[i];
             }
         }
         // epilogue: e' = relu((e W3^T + G) * scale + shift) + e   (gated_gcn_full.py:104-110)
-        const float* res = e_in + row0 * H + col0 + cl;
-        float* out = e_out + row0 * H + col0 + cl;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lr = cd_row(r, lane);
-            if (row0 + lr < E) {
-                const float* rr = res + (int64_t)lr * H;
-                float* o = out + (int64_t)lr * H;
-                o[0] = fmaxf((acc0[r] + g0[r]) * sc0 + sh0, 0.f) + rr[0];
-                o[32] = fmaxf((acc1[r] + g1[r]) * sc1 + sh1, 0.f) + rr[32];
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[cd_row(r, lane) * P::TLD + cl] = cb == 0 ? acc0[r] : acc1[r];
+            __builtin_amdgcn_wave_barrier();   // the tile is this wave's own: LDS keeps a wave's accesses in order
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(tile + (er + 8 * it) * P::TLD + ec);
+                f32x4 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    y[j] = fmaxf((a[j] + (b1[cb][it][j] + b2[cb][it][j])) * sc[cb][j] + sh[cb][j], 0.f) + res[cb][it][j];
+                if (row0 + er + 8 * it < E) *reinterpret_cast<f32x4*>(e_out + (row0 + er + 8 * it) * H + col0 + 32 * cb + ec) = y;
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
     const float* __restrict__ h_in, int ldh, float* __restrict__ h_out, const float* __restrict__ scale,
     const float* __restrict__ shift, int total_blocks, float* __restrict__ aux0, float* __restrict__ aux1,
     float* __restrict__ aux2, float* __restrict__ aux3, const int* __restrict__ hub_count, const int* __restrict__ hub_nodes,
-    const float* __restrict__ hub_partials) {
+    const float* __restrict__ hub_partials, int64_t node0) {
     constexpr int LPR = H / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t node;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
         if (hub_slot >= min(*hub_count, kHubCap)) return;
         node = hub_nodes[hub_slot];
     } else {
-        node = (int64_t)xcd_remap(blockIdx.x, total_blocks) * (kAggThreads / 64) + wave;
+        node = node0 + (int64_t)xcd_remap(blockIdx.x, total_blocks) * (kAggThreads / 64) + wave;
     }
     if (node >= n_out) return;
     const int group = lane / LPR, c = (lane % LPR) * 4;
@@ -298,15 +298,25 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
                       const int32_t* in_ptr, const int32_t* ss, const int32_t* out_ptr, const int32_t* out_pos,
                       const int32_t* od, const float* h_in, int ldh, float* h_out, int norm, const float* scale,
                       const float* shift, hipStream_t s, int mode = 0, float* aux0 = nullptr, float* aux1 = nullptr,
-                      float* aux2 = nullptr, float* aux3 = nullptr) {
-    const int64_t blocks = (n_out + (kAggThreads / 64) - 1) / (kAggThreads / 64);
+                      float* aux2 = nullptr, float* aux3 = nullptr, int64_t node_begin = 0, int64_t node_end = -1) {
+    // [node_begin, node_end): the rows the regular launch covers (gnnome_node_aggregate_range_f32); the hub path always works
+    // on the whole graph [0, n_out) and runs with the range that starts at node 0
+    if (node_end < 0) node_end = n_out;
+    const int64_t node0 = node_begin;
+    const int64_t blocks = (node_end - node_begin + (kAggThreads / 64) - 1) / (kAggThreads / 64);
     GN_REQUIRE(blocks < (1ll << 31), "node_aggregate: too many nodes");
+    GN_REQUIRE(node_begin >= 0 && node_begin < node_end && node_end <= n_out, "node_aggregate: bad node range [%lld, %lld) of %lld",
+               (long long)node_begin, (long long)node_end, (long long)n_out);
     // the hub path (see the header comment): find the long lists, reduce them chunk-wise, let the node's wave add the chunks
     HubScratch* hub = tuning(kTuneAggHubs) == 1 ? nullptr : hub_scratch();
+    const bool hub_pass = hub != nullptr && node_begin == 0;
     const int* hub_count = hub ? hub->count : nullptr;
     const int* hub_nodes = hub ? hub->nodes : nullptr;
     const float* hub_partials = hub ? hub->partials : nullptr;
-    if (hub) {
+    if (hub && !hub_pass)   // a later range of the same call sequence: the hub list must be the one its first range built
+        GN_REQUIRE(hub->key_in == in_ptr && hub->key_out == out_ptr && hub->key_n == n_out,
+                   "node_aggregate_range: the ranges of one aggregation must start with the range that begins at node 0");
+    if (hub_pass) {
         // The list is rebuilt when the CSR arrays change (8 layers share one graph).  A stale list - another graph at the
         // same addresses - costs speed only: the kernels re-read every count, a listed node that is no hub takes the normal
         // path, an unlisted hub the single-wave path, and the partials are recomputed at every call.
@@ -322,8 +332,8 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
     const size_t dyn = (size_t)tuning(kTuneAggLdsKiB) * 1024;
 #define GN_AGG_LAUNCH(NORM_, MODE_, FIN_, U_, WPS_, GRID_)                                                                              \
     hipLaunchKernelGGL((k_node_aggregate<H, NORM_, MODE_, FIN_, U_, WPS_>), dim3((unsigned)(GRID_)), dim3(kAggThreads), (FIN_) ? 0 : dyn, s, e, \
-                       n_out, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift, (int)blocks, aux0, \
-                       aux1, aux2, aux3, hub_count, hub_nodes, hub_partials)
+                       (FIN_) ? n_out : node_end, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,   \
+                       (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials, (FIN_) ? (int64_t)0 : node0)
     // items per lane group in flight: 4 at H <= 128.  Measured at configs[1] (tools/agg_time.py <H> variants): 1 item 0.2105 ms,
     // 2 items 0.2115, 4 items 0.2197, 8 items 0.2533 - the launch time hardly depends on the loads in flight per wave (the
     // kernel sits at the HBM rate this access pattern sustains) - but with 2 items the 8 resident waves per SIMD widen the
@@ -333,10 +343,10 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
     constexpr int kFinGrid = kHubCap / (kAggThreads / 64);
     if (mode == 1) {
         GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 1, false, UD, 0, blocks);
-        if (hub) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 1, true, UD, 0, kFinGrid);
+        if (hub_pass) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 1, true, UD, 0, kFinGrid);
     } else if (mode == 2) {
         GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 2, false, UD, 0, blocks);
-        if (hub) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 2, true, UD, 0, kFinGrid);
+        if (hub_pass) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 2, true, UD, 0, kFinGrid);
     } else if (norm == GNNOME_NORM_AFFINE) {
         switch (tuning(kTuneAggVariant)) {   // A/B of occupancy against items in flight (tools/agg_time.py)
             case 1: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 4, 8, blocks); break;
@@ -346,10 +356,10 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
             case 5: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 2, 0, blocks); break;
             default: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks); break;
         }
-        if (hub) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, true, UD, 0, kFinGrid);
+        if (hub_pass) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, true, UD, 0, kFinGrid);
     } else {
         GN_AGG_LAUNCH(GNNOME_NORM_LAYER, 0, false, UD, 0, blocks);
-        if (hub) GN_AGG_LAUNCH(GNNOME_NORM_LAYER, 0, true, UD, 0, kFinGrid);
+        if (hub_pass) GN_AGG_LAUNCH(GNNOME_NORM_LAYER, 0, true, UD, 0, kFinGrid);
     }
 #undef GN_AGG_LAUNCH
     GN_LAUNCH_CHECK();
@@ -381,6 +391,28 @@ extern "C" int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num
         case 128: return launch_agg<128>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
         case 256: return launch_agg<256>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
         default: set_error("node_aggregate: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
+    }
+}
+
+extern "C" int gnnome_node_aggregate_range_f32(const float* e, int hidden, int64_t num_nodes_out, int64_t node_begin, int64_t node_end,
+                                               const float* A1h, const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
+                                               const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
+                                               const int32_t* out_dst, const float* h_in, int ld_h, float* h_out, int norm_kind,
+                                               const float* norm_scale, const float* norm_shift, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(num_nodes_out > 0, "node_aggregate_range: empty graph");
+    GN_REQUIRE(A1h && A2h && A3h && in_ptr && out_ptr && h_in && h_out && norm_scale && norm_shift, "node_aggregate_range: null pointer");
+    GN_REQUIRE(norm_kind == GNNOME_NORM_AFFINE || norm_kind == GNNOME_NORM_LAYER, "node_aggregate_range: bad norm_kind %d", norm_kind);
+    GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ld_h >= hidden && ld_h % 4 == 0, "node_aggregate_range: bad strides");
+    GN_REQUIRE(((uintptr_t)A1h % 16 == 0) && ((uintptr_t)A2h % 16 == 0) && ((uintptr_t)A3h % 16 == 0) &&
+                   ((uintptr_t)h_in % 16 == 0) && ((uintptr_t)h_out % 16 == 0) && ((uintptr_t)e % 16 == 0),
+               "node_aggregate_range: tensors must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (hidden) {
+        case 64: return launch_agg<64>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, node_begin, node_end);
+        case 128: return launch_agg<128>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, node_begin, node_end);
+        case 256: return launch_agg<256>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, node_begin, node_end);
+        default: set_error("node_aggregate_range: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
 }
 

@@ -195,16 +195,71 @@ def gate(ops, lw, views, e, B1, B2, raw_edges=None, scratch=None):
     return gate_update(ops, lw, views, e, B1, B2, scratch)
 
 
-def layer_step(ops, lw, views, h, e, n_out=None, raw_edges=None, scratch=None):
-    """One SymGatedGCN layer on sorted-order e (updated in place, see gate_update); returns (new h, e).  With e = None and
-    raw_edges = (e_raw, encoder weights) the edge encoder is folded into the gate (layer 0)."""
+def aggregate_then_project(ops, lw, views, e, A1, A2, A3, h, then):
+    """h' = the layer's node update, and `then(h'[rows], out=...)` - the NEXT consumer's node projection (the next layer's
+    A1..B2, gated_gcn_full.py:91-96, or the scorer's node halves, score_predictor.py:13-14) - pipelined over node ranges:
+    the aggregation runs as PIPELINE_CHUNKS consecutive launches on the current stream (gnnome_node_aggregate_range_f32), and
+    as soon as a range of h' is complete its projection starts on a second, high-priority HIP stream, under the aggregation
+    of the next range.  Values are those of the one-stream sequence bit for bit (both kernels compute every row independently
+    of the launch's row count).
+
+    MEASURED NEGATIVE, hence off by default (PIPELINE_CHUNKS = 1; tools/pipeline_ab.py reproduces it): at configs[1] the
+    forward takes 4.89 ms on one stream and 5.20 / 5.25 / 5.54 ms with 2 / 4 / 8 ranges (10M edges: 47.4 against 49.0 ms;
+    replayed from a hipGraph 6.2-9 ms - cross-stream edges are expensive graph nodes on ROCm).  The aggregation waits on
+    memory for most of its cycles and the projection is bound by neither roof when it runs alone, but together they take
+    LONGER than one after the other: both live off the same L2 / fabric, and the projection's 256 MB of output evict the e'
+    rows the aggregation's out-edge pass expects to find in L2.  Nontemporal stores in the projection change nothing."""
+    n = h.shape[0]
+    side = ops.side_stream(h.device)
+    main = torch.cuda.current_stream(h.device)
+    h_out = torch.empty_like(h)
+    P_next = torch.empty((n, then.width), dtype=torch.float32, device=h.device)   # both live on the main stream, which joins the side stream below
+    bounds = [n * i // PIPELINE_CHUNKS // 32 * 32 for i in range(PIPELINE_CHUNKS)] + [n]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, node_range=(lo, hi), out=h_out)
+        done = torch.cuda.Event()
+        done.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(done)
+            then(h_out[lo:hi], out=P_next[lo:hi])
+    main.wait_stream(side)
+    return h_out, P_next
+
+
+PIPELINE_CHUNKS = 1   # off: measured slower, see aggregate_then_project
+PIPELINE_MIN_NODES = 1 << 15   # below this a launch is a few microseconds and the extra launches + events cost more than they hide
+
+
+class _Projection:
+    """`then` of aggregate_then_project: rows -> rows @ W^T + b through the layer's own projection kernel."""
+
+    def __init__(self, fn, W, b):
+        self.fn, self.W, self.b, self.width = fn, W, b, W.shape[0]
+
+    def __call__(self, rows, out=None):
+        return self.fn(rows, self.W, self.b, out=out)
+
+
+def layer_projection(ops, lw):
+    return _Projection(ops.linear_ref if lw.ref else ops.linear, lw.Wcat, lw.bcat)
+
+
+def layer_step(ops, lw, views, h, e, n_out=None, raw_edges=None, scratch=None, P=None, then=None):
+    """One SymGatedGCN layer on sorted-order e (updated in place, see gate_update); returns (new h, e, then's output).  With
+    e = None and raw_edges = (e_raw, encoder weights) the edge encoder is folded into the gate (layer 0).  P: this layer's
+    projection if the previous step already produced it; then: the next consumer's projection, to be run pipelined with
+    the aggregation (aggregate_then_project) - None: not computed here."""
     H = h.shape[1]
-    P = project(ops, lw, h)
+    if P is None:
+        P = project(ops, lw, h)
     A1, A2, A3, B1, B2 = (P[:, i * H:(i + 1) * H] for i in range(5))
     if views.transposed:  # dgl.reverse(g): src <-> dst, see GraphViews.reversed
         A2, A3, B1, B2 = A3, A2, B2, B1
     e = gate(ops, lw, views, e, B1, B2, raw_edges, scratch)
-    return ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_out), e
+    if then is not None:
+        h_new, P_next = aggregate_then_project(ops, lw, views, e, A1, A2, A3, h, then)
+        return h_new, e, P_next
+    return ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_out), e, None
 
 
 def encode_edges(ops, prep, views, e_raw):
@@ -215,9 +270,14 @@ def encode_edges(ops, prep, views, e_raw):
     return ops.encode(e_raw, *prep.enc_edge, gather=views.srt_eid, rows=views.num_edges)
 
 
-def score_step(ops, pw, views, h, e, logits, n_edges=None):
+def predictor_projection(ops, pw):
+    return _Projection(ops.linear, pw["W_nodes"], pw["b_nodes"])
+
+
+def score_step(ops, pw, views, h, e, logits, n_edges=None, PQ=None):
     hs = pw["hs"]
-    PQ = ops.linear(h, pw["W_nodes"], pw["b_nodes"])
+    if PQ is None:
+        PQ = ops.linear(h, pw["W_nodes"], pw["b_nodes"])
     Ps, Qd = PQ[:, :hs], PQ[:, hs:]
     if views.transposed:
         # x[src'] | x[dst'] = x[dst] | x[src]; b1 is added once either way
@@ -228,19 +288,27 @@ def score_step(ops, pw, views, h, e, logits, n_edges=None):
 def run_stack(ops, prep, views, x, e_raw, exchange=None, n_own=None, n_score=None, logits=None):
     """Encoders -> L layers -> scorer.  `exchange(h)` (optional) refreshes halo rows before every
     consumer of h; `n_own` limits the node update to the first rows, `n_score` the scorer to the first
-    sorted positions (both used by the destination-range partition, dist.py)."""
+    sorted positions (both used by the destination-range partition, dist.py).  With PIPELINE_CHUNKS > 1 (off by
+    default: measured slower) every node projection after the first runs under the preceding aggregation on a second
+    stream (aggregate_then_project)."""
     h = ops.encode(x, *prep.enc_node)
     e = encode_edges(ops, prep, views, e_raw)
     scratch = {}
-    for lw in prep.layers:
+    pipelined = (exchange is None and n_own is None and getattr(ops, "side_stream", None) is not None and PIPELINE_CHUNKS > 1
+                 and h.shape[0] >= PIPELINE_MIN_NODES)
+    P = None
+    for i, lw in enumerate(prep.layers):
         if exchange is not None:
             h = exchange(h)
-        h, e = layer_step(ops, lw, views, h, e, n_out=n_own, raw_edges=(e_raw, prep.enc_edge), scratch=scratch)
+        then = None
+        if pipelined:
+            then = layer_projection(ops, prep.layers[i + 1]) if i + 1 < len(prep.layers) else predictor_projection(ops, prep.predictor)
+        h, e, P = layer_step(ops, lw, views, h, e, n_out=n_own, raw_edges=(e_raw, prep.enc_edge), scratch=scratch, P=P, then=then)
     if exchange is not None:
         h = exchange(h)
     if logits is None:
         logits = torch.empty(views.num_edges if n_score is None else n_score, dtype=torch.float32, device=h.device)
-    score_step(ops, prep.predictor, views, h, e, logits, n_edges=n_score)
+    score_step(ops, prep.predictor, views, h, e, logits, n_edges=n_score, PQ=P)
     return logits
 
 
@@ -278,7 +346,7 @@ def layer_forward_edge_id_order(conv, g, h, e):
         hd = h.detach().to(device=device, dtype=torch.float32).contiguous()
         ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
         es = hip_ops.gather_rows(ed, views.srt_eid)
-        h_new, _ = layer_step(hip_ops, lw, views, hd, es)
+        h_new, _, _ = layer_step(hip_ops, lw, views, hd, es)
         e_new = torch.empty_like(es)
         e_new[views.srt_eid.long()] = es
         h_new = F.dropout(h_new, conv.dropout, training=conv.training)

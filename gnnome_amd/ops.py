@@ -16,6 +16,18 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """The second HIP stream of `device` (high priority: its workgroups are placed ahead of the queued ones of the main
+    stream) that engine.aggregate_then_project runs the next node projection on, under the aggregation."""
+    s = _SIDE_STREAMS.get(device.index)
+    if s is None:
+        s = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device, priority=-1)
+    return s
+
+
 class _on:
     """Make `device` current for the duration of a call - a no-op (no torch device-guard round trip, ~10 us
     per kernel launch otherwise) in the usual case that it already is."""
@@ -252,7 +264,9 @@ def edge_gate_ref(e, B1h, B2h, views, W3, b3, scale, shift, raw_edges=None, num_
     return out
 
 
-def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_nodes_out=None):
+def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_nodes_out=None, node_range=None, out=None):
+    """node_range = (begin, end): only those rows of `out` (required then) are computed - gnnome_node_aggregate_range_f32;
+    the ranges of one aggregation go in ascending order from node 0."""
     lib = _lib.load()
     A1h, ldn = _rows(A1h, "node_aggregate.A1h")
     A2h, l2 = _rows(A2h, "node_aggregate.A2h")
@@ -261,13 +275,22 @@ def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_n
     assert ldn == l2 == l3
     hidden = h_in.shape[1]
     n_out = int(h_in.shape[0] if num_nodes_out is None else num_nodes_out)
-    h_out = torch.empty((h_in.shape[0], hidden), dtype=torch.float32, device=h_in.device)
+    h_out = torch.empty((h_in.shape[0], hidden), dtype=torch.float32, device=h_in.device) if out is None else out
+    assert h_out.is_contiguous() and h_out.shape == (h_in.shape[0], hidden) and h_out.dtype == torch.float32
     with _on(h_in.device):
-        _lib.check(lib.gnnome_node_aggregate_f32(_ptr(e), hidden, n_out, _ptr(A1h), _ptr(A2h), _ptr(A3h), ldn,
-                                                 _ptr(views.in_ptr), _ptr(views.srt_src), _ptr(views.out_ptr),
-                                                 _ptr(views.out_pos), _ptr(views.out_dst), _ptr(h_in), ldh, _ptr(h_out),
-                                                 norm_kind, _ptr(scale), _ptr(shift), _stream(h_in.device)),
-                   "node_aggregate_f32")
+        if node_range is None:
+            _lib.check(lib.gnnome_node_aggregate_f32(_ptr(e), hidden, n_out, _ptr(A1h), _ptr(A2h), _ptr(A3h), ldn,
+                                                     _ptr(views.in_ptr), _ptr(views.srt_src), _ptr(views.out_ptr),
+                                                     _ptr(views.out_pos), _ptr(views.out_dst), _ptr(h_in), ldh, _ptr(h_out),
+                                                     norm_kind, _ptr(scale), _ptr(shift), _stream(h_in.device)),
+                       "node_aggregate_f32")
+        else:
+            assert out is not None, "node_aggregate(node_range=...) writes rows of a caller-owned `out`"
+            _lib.check(lib.gnnome_node_aggregate_range_f32(_ptr(e), hidden, n_out, int(node_range[0]), int(node_range[1]), _ptr(A1h),
+                                                           _ptr(A2h), _ptr(A3h), ldn, _ptr(views.in_ptr), _ptr(views.srt_src),
+                                                           _ptr(views.out_ptr), _ptr(views.out_pos), _ptr(views.out_dst), _ptr(h_in),
+                                                           ldh, _ptr(h_out), norm_kind, _ptr(scale), _ptr(shift),
+                                                           _stream(h_in.device)), "node_aggregate_range_f32")
     return h_out
 
 

@@ -170,6 +170,18 @@ int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num_nodes_out,
                               const int32_t* out_dst, const float* h_in, int ld_h, float* h_out, int norm_kind,
                               const float* norm_scale, const float* norm_shift, void* stream);
 
+/* The same update for the nodes [node_begin, node_end) only - all pointers and num_nodes_out describe the WHOLE graph
+ * exactly as for gnnome_node_aggregate_f32, rows outside the range are not touched.  Lets a caller cut one aggregation
+ * (gated_gcn_full.py:111-137) into consecutive launches and start the NEXT layer's node projection (:91-96) on the rows
+ * that are complete, on a second stream, while the remaining ranges are still being reduced (engine.aggregate_then_project).
+ * Results are bit-identical to the single launch.  The ranges of one aggregation must be issued in ascending order
+ * starting at node 0: the range that begins at 0 also runs the long-list (hub) path for the whole graph. */
+int gnnome_node_aggregate_range_f32(const float* e, int hidden, int64_t num_nodes_out, int64_t node_begin, int64_t node_end,
+                                    const float* A1h, const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
+                                    const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
+                                    const int32_t* out_dst, const float* h_in, int ld_h, float* h_out, int norm_kind,
+                                    const float* norm_scale, const float* norm_shift, void* stream);
+
 /* ---- fused edge scorer --------------------------------------------------------------------------
  * For every sorted position p < num_edges:
  *   z1 = relu(Ps[srt_src[p],:] + Qd[srt_dst[p],:] + e[p,:] * W1e^T)        (b1 folded into Qd)

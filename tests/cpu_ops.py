@@ -98,7 +98,7 @@ def edge_gate_ref(e, B1h, B2h, views, W3, b3, scale, shift, raw_edges=None, num_
     return e
 
 
-def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_nodes_out=None):
+def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_nodes_out=None, node_range=None, out=None):
     n = h_in.shape[0]
     n_out = n if num_nodes_out is None else num_nodes_out
     sig = torch.sigmoid(e)
@@ -110,6 +110,9 @@ def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_n
     db = zeros.index_add(0, s, sig)
     v = A1h + nf / (df + 1e-6) + nb / (db + 1e-6)
     y = torch.relu(_norm(v, norm_kind, scale, shift)) + h_in
+    if node_range is not None:   # gnnome_node_aggregate_range_f32: only these rows of the caller's `out`
+        out[node_range[0]:node_range[1]] = y[node_range[0]:node_range[1]]
+        return out
     out = torch.full_like(h_in, float("nan"))  # rows >= n_out are not written by the kernel
     out[:n_out] = y[:n_out]
     return out

@@ -276,6 +276,64 @@ def test_node_aggregate_hub_split_path(hidden, deg):
     print(f"hub of 2 x {deg} edges, H={hidden}: split path {t_split * 1e3:.3f} ms, single wave {t_single * 1e3:.3f} ms")
 
 
+@pytest.mark.parametrize("hidden", [64, 128, 256])
+def test_node_aggregate_in_node_ranges_is_bit_identical(hidden):
+    """gnnome_node_aggregate_range_f32: one aggregation cut into consecutive node ranges (ragged, one of them a single row,
+    a 6000-edge hub in the SECOND range - the hub path runs with the range that starts at node 0) gives the bits of the
+    single launch, and rows outside a range are not touched."""
+    n, H = 5003, hidden
+    g = torch.Generator().manual_seed(hidden)
+    src, dst = _rand_graph(n, 60_000, seed=hidden)
+    hub = 3100
+    dst[:6000] = hub
+    src[6000:9000] = hub
+    E = src.numel()
+    d = {"e": (2.0 * torch.randn(E, H, generator=g)).to(dev()), "h": torch.randn(n, H, generator=g).to(dev()),
+         "P": torch.randn(n, 3 * H, generator=g).to(dev()), "scale": (0.5 + torch.rand(H, generator=g)).to(dev()),
+         "shift": torch.randn(H, generator=g).to(dev())}
+    gv, _ = _views_pair(src, dst, n)
+    args = (d["e"], d["P"][:, :H], d["P"][:, H:2 * H], d["P"][:, 2 * H:], gv, d["h"], 0, d["scale"], d["shift"])
+    whole = ops.node_aggregate(*args)
+    out = torch.full_like(whole, float("nan"))
+    bounds = [0, 1, 1500, 1501, 4096, n]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        ops.node_aggregate(*args, node_range=(lo, hi), out=out)
+        untouched = torch.arange(n, device=dev()) >= hi
+        untouched[hub] = False   # the hub's row is written by the first range's hub launch
+        assert torch.isnan(out[untouched]).all() and not torch.isnan(out[:hi]).any()
+    assert torch.equal(out, whole)
+    with pytest.raises(Exception):
+        ops.node_aggregate(*args, node_range=(10, 5), out=out)
+
+
+def test_pipelined_projection_is_bit_identical_and_capturable():
+    """engine.aggregate_then_project (the next layer's node projection on a second stream under the aggregation's node
+    ranges; an option, off by default because it measured slower): same logits bit for bit as the one-stream sequence,
+    eager and replayed from a hipGraph, run after run."""
+    from gnnome_amd import engine
+    from gnnome_amd.capture import CapturedForward
+    n, e, hidden = 40_000, 400_000, 128
+    gr = make_graph(n, e, seed=5, kind="banded")
+    x = degree_features(gr["src"], gr["dst"], n).to(dev())
+    ef = gr["e"].to(dev())
+    m = _model(random_state_dict(hidden, seed=5), hidden)
+    views = views_for((gr["src"].to(dev()), gr["dst"].to(dev()), n), dev())
+    keep = engine.PIPELINE_CHUNKS, engine.PIPELINE_MIN_NODES
+    try:
+        engine.PIPELINE_CHUNKS = 1
+        plain = m(views, x, ef)
+        for chunks in (2, 4, 7):
+            engine.PIPELINE_CHUNKS, engine.PIPELINE_MIN_NODES = chunks, 0
+            for _ in range(3):
+                assert torch.equal(m(views, x, ef), plain), chunks
+        engine.PIPELINE_CHUNKS = 4
+        cap = CapturedForward(m, views, x, ef)
+        for _ in range(3):
+            assert torch.equal(cap(), plain)
+    finally:
+        engine.PIPELINE_CHUNKS, engine.PIPELINE_MIN_NODES = keep
+
+
 @pytest.mark.parametrize("hidden,hs", [(64, 64), (128, 64), (256, 64), (64, 32), (128, 128)])
 def test_edge_score(hidden, hs):
     n, e = 400, 1500
