@@ -20,10 +20,11 @@ m.to(dev)
 views = ops.GraphViews(g["src"].to(dev), g["dst"].to(dev), n)
 x, ef = ops.degree_features(views), g["e"].to(dev)
 ref = None
+KEY = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # tuning key the variants belong to (0 = gate variant, 7 = aggregation variant)
 with torch.no_grad():
     for rnd in range(2):
         for v in [int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "0,8").split(",")]:
-            ops.set_tuning(0, v)
+            ops.set_tuning(KEY, v)
             for _ in range(5):
                 out = m(views, x, ef)
             s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,5 +34,5 @@ with torch.no_grad():
             t.record()
             torch.cuda.synchronize()
             ref = out if ref is None else ref
-            print(f"round {rnd} gate variant {v}: {s.elapsed_time(t) / 50:.3f} ms / forward, max|dp| vs first {(torch.sigmoid(out) - torch.sigmoid(ref)).abs().max().item():.2e}", flush=True)
-ops.set_tuning(0, 0)
+            print(f"round {rnd} key {KEY} variant {v}: {s.elapsed_time(t) / 50:.3f} ms / forward, max|dp| vs first {(torch.sigmoid(out) - torch.sigmoid(ref)).abs().max().item():.2e}", flush=True)
+ops.set_tuning(KEY, 0)
