@@ -688,11 +688,12 @@ def test_gate_plane_form_at_full_size_against_the_second_generation(kind):
         assert torch.equal(out, first)
 
 
-def test_h256_shard_of_configs3_properties():
-    """One GPU's eighth of BASELINE configs[3] (N = 250k, E = 2.5M, H = 256): run-to-run identical, the reversed-graph /
-    swapped-roles identity, edge-id permutation equivariance - the size-independent properties of the path, at the width
-    and per-GPU size the 8-GPU configurations run."""
-    n, e, hidden = 250_000, 2_500_000, 256
+@pytest.mark.parametrize("n,e", [(250_000, 2_500_000), (2_000_000, 20_000_000)])
+def test_h256_configs3_properties(n, e):
+    """BASELINE configs[3] at H = 256 - one GPU's eighth of it (N = 250k, E = 2.5M), and the WHOLE graph (N = 2M, E = 20M:
+    20.5 GB of edge state, twice for the streaming gate's two buffers - one MI355X holds it): run-to-run identical, the
+    reversed-graph / swapped-roles identity, edge-id permutation equivariance - the size-independent properties of the path."""
+    hidden = 256
     gr = make_graph(n, e, seed=1, kind="banded")
     x = degree_features(gr["src"], gr["dst"], n).to(dev())
     ef = gr["e"].to(dev())
