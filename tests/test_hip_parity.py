@@ -202,6 +202,29 @@ def test_edge_gate(hidden, norm, e_base):
         ops.set_tuning(0, 0)
 
 
+def test_h256_streaming_gate_in_pieces_equals_one_launch():
+    """The H = 256 streaming gate cuts its launch into pieces of 64 tiles per workgroup (edge_gate_stream.hip): with the
+    piece size forced down to 3 tiles (gnnome_set_tuning key 4) a ragged 300k-edge input runs as seven launches with
+    offset row / index pointers - same bits as one uncut launch, which is itself checked against the contract."""
+    H, n, e = 256, 3000, 300_007
+    src, dst, t = _layer_inputs(H, n, e, seed=11)
+    gv, cv = _views_pair(src, dst, n)
+    d = {k: v.to(dev()) for k, v in t.items()}
+    args = (d["e"], d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], 0, d["scale"], d["shift"])
+    try:
+        ops.set_tuning(4, 1 << 20)   # one launch
+        whole = ops.edge_gate(*args, out=torch.empty_like(d["e"]))
+        ops.set_tuning(4, 3)
+        pieces = ops.edge_gate(*args, out=torch.full_like(d["e"], float("nan")))
+    finally:
+        ops.set_tuning(4, 0)
+    default = ops.edge_gate(*args, out=torch.empty_like(d["e"]))
+    assert torch.equal(pieces, whole) and torch.equal(default, whole)
+    want = cpu_ops.edge_gate(t["e"].double().clone(), t["P"][:, 3 * H:4 * H].double(), t["P"][:, 4 * H:].double(), cv, t["W3"].double(), 0,
+                             t["scale"].double(), t["shift"].double())
+    _assert_close(whole, want, scale=20.0)
+
+
 @pytest.mark.parametrize("hidden", [64, 128, 256])
 @pytest.mark.parametrize("norm", [0, 1])
 def test_node_aggregate(hidden, norm):

@@ -21,11 +21,14 @@ cp $O/${TAG}_gate_pmc.json profiles/   # so that the bench line below can quote 
 timeout 900 python bench.py > $O/${TAG}_bench_c2.json 2> $O/bench_c2.err; tail -c 400 $O/${TAG}_bench_c2.json
 for w in 10m parity64 c4shard; do timeout 400 python bench.py --workload $w --no-cpu-baseline --no-extras > $O/${TAG}_bench_$w.json 2>/dev/null; done
 timeout 400 python bench.py --kind uniform --no-cpu-baseline --no-extras > $O/${TAG}_bench_c2_uniform.json 2>/dev/null
+# the whole configs[3] graph and the configs[4] graph (inference) on ONE GPU: H = 256, 20M / 50M edges
+timeout 400 python bench.py --workload c4 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/${TAG}_bench_c4_one_gpu.json 2>/dev/null
+timeout 600 python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_bench_c5_one_gpu.json 2>/dev/null
 timeout 600 python bench.py --mode train > $O/${TAG}_bench_c3_train_step.json 2>/dev/null
 timeout 600 python bench.py --mode train --storage bf16 --no-cpu-baseline > $O/${TAG}_bench_c3_train_bf16_storage.json 2>/dev/null
 timeout 600 python bench.py --mode train --symmetry --no-cpu-baseline > $O/${TAG}_bench_c3_train_symmetry.json 2>/dev/null
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --one-gpu-gloo --workload c2 --steps 5 --warmup 2 > $O/${TAG}_bench_n2_plumbing.json 2>/dev/null
-for f in c2 10m parity64 c4shard c2_uniform c3_train_step c3_train_bf16_storage c3_train_symmetry n2_plumbing; do python - "$f" "$TAG" <<'PY'
+for f in c2 10m parity64 c4shard c4_one_gpu c5_one_gpu c2_uniform c3_train_step c3_train_bf16_storage c3_train_symmetry n2_plumbing; do python - "$f" "$TAG" <<'PY'
 import json,sys
 f,tag=sys.argv[1],sys.argv[2]
 try:
