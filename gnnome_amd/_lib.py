@@ -64,8 +64,8 @@ SIGNATURES = {
     "gnnome_closure_workspace_bytes": [ctypes.POINTER(_sz)],
     "gnnome_degree_features_f32": [_p, _p, _l, _i, _p, _p, _sz, _p],
     "gnnome_edge_features_f32": [_p, _p, _l, _p, _p, _sz, _p],
-    "gnnome_bn_bwd_dgrad_f32": [_p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
-    "gnnome_bn_bwd_dgrad_x16": [_p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "gnnome_bn_bwd_dgrad_f32": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "gnnome_bn_bwd_dgrad_x16": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_agg_edge_bwd_stats_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_agg_edge_bwd_stats_x16": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_bn_train_finish_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _i, _p, _p, _p, _p, _p],
@@ -76,7 +76,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

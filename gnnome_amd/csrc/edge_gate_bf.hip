@@ -309,14 +309,16 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
                 const f32x4 kr = *reinterpret_cast<const f32x4*>(a.bnb.rstd + 4 * c4), ks = *reinterpret_cast<const f32x4*>(a.bnb.scale + 4 * c4);
                 const f32x4 kh = *reinterpret_cast<const f32x4*>(a.bnb.shift + 4 * c4);
                 const int valid3 = tile_valid(r);
+                const int64_t once3 = a.bnb.n_once - (int64_t)tile_of(r) * TM;   // rows of this tile that get the mean terms
                 float* aout = a.bnb.a_out + (int64_t)tile_of(r) * TM * H;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     f32x4 t;
+                    const float on = r0 + p * RSTEP < once3 ? 1.f : 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float gm = (av[p][j] * ks[j] + kh[j] > 0.f) ? g1[p][j] : 0.f;
-                        t[j] = ka[j] * (gm - k1[j] - (av[p][j] - km[j]) * kr[j] * k2[j]);
+                        t[j] = ka[j] * (gm - on * (k1[j] + (av[p][j] - km[j]) * kr[j] * k2[j]));
                     }
                     av[p] = t;
                     if (r0 + p * RSTEP < valid3) {
@@ -632,14 +634,16 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                 const f32x4 kr = *reinterpret_cast<const f32x4*>(norm_lds + 4 * H + 4 * c4), ks = *reinterpret_cast<const f32x4*>(norm_lds + 5 * H + 4 * c4);
                 const f32x4 kh = *reinterpret_cast<const f32x4*>(norm_lds + 6 * H + 4 * c4);
                 const int valid3 = tile_valid(r);
+                const int64_t once3 = a.bnb.n_once - (int64_t)tile_of(r) * TM;   // rows of this tile that get the mean terms
                 const int64_t base3 = (int64_t)tile_of(r) * TM * H;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     f32x4 t;
+                    const float on = r0 + p * RSTEP < once3 ? 1.f : 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float gm = (av[p][j] * ks[j] + kh[j] > 0.f) ? g1[p][j] : 0.f;
-                        t[j] = ka[j] * (gm - k1[j] - (av[p][j] - km[j]) * kr[j] * k2[j]);
+                        t[j] = ka[j] * (gm - on * (k1[j] + (av[p][j] - km[j]) * kr[j] * k2[j]));
                     }
                     av[p] = t;
                     if (r0 + p * RSTEP < valid3) store4_as<X16>(a.bnb.a_out, base3 + (off_row + (unsigned)(p * RSTEP * H)), t);
@@ -1004,11 +1008,12 @@ extern "C" int gnnome_debug_gate_profile(void* counters) {
 
 // C[M,H] += BatchNormBackward(C, X) W^T and dxe = BatchNormBackward(C, X) written out: gnnome_bn_bwd_apply_f32 followed by
 // gnnome_linear_acc_f32 in ONE pass over the [E,H] tensors (the A tile never comes from HBM: the load waves compute it).
-static int bn_bwd_dgrad_impl(float* C, const void* X, int64_t rows, int hidden, const float* scale, const float* shift,
+static int bn_bwd_dgrad_impl(float* C, const void* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift,
                              const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
                              const float* W, int ldw, void* dxe, void* stream, bool x16) {
     using namespace gnnome;
     GN_REQUIRE(rows >= 0 && (hidden == 64 || hidden == 128), "bn_bwd_dgrad: hidden=%d not in {64,128}", hidden);
+    GN_REQUIRE(rows_once >= 0 && rows_once <= rows, "bn_bwd_dgrad: rows_once=%lld outside [0, rows]", (long long)rows_once);
     if (rows == 0) return GNNOME_OK;
     GN_REQUIRE(C && X && scale && shift && a && c1 && c2 && mean && rstd && W && dxe && dxe != (void*)C && ldw >= hidden && ldw % 4 == 0,
                "bn_bwd_dgrad: bad arguments");
@@ -1016,18 +1021,18 @@ static int bn_bwd_dgrad_impl(float* C, const void* X, int64_t rows, int hidden, 
                "bn_bwd_dgrad: tensors must be 16-byte aligned");
     GateBfArgs g = {};
     g.e_in = (const float*)X; g.e_out = C; g.E = rows; g.B1h = C; g.ldn = hidden; g.W3 = W; g.ldw = ldw;
-    g.bnb = GateBnBwd{a, c1, c2, mean, rstd, scale, shift, (float*)dxe};
+    g.bnb = GateBnBwd{a, c1, c2, mean, rstd, scale, shift, (float*)dxe, rows_once};
     return gate_bf_launch(hidden, 3, false, g, (hipStream_t)stream, x16);
 }
 
-extern "C" int gnnome_bn_bwd_dgrad_f32(float* C, const float* X, int64_t rows, int hidden, const float* scale, const float* shift,
+extern "C" int gnnome_bn_bwd_dgrad_f32(float* C, const float* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift,
                                        const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
                                        const float* W, int ldw, float* dxe, void* stream) {
-    return bn_bwd_dgrad_impl(C, X, rows, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, false);
+    return bn_bwd_dgrad_impl(C, X, rows, rows_once, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, false);
 }
 
-extern "C" int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows, int hidden, const float* scale, const float* shift,
+extern "C" int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift,
                                        const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
                                        const float* W, int ldw, uint16_t* dxe, void* stream) {
-    return bn_bwd_dgrad_impl(C, X, rows, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, true);
+    return bn_bwd_dgrad_impl(C, X, rows, rows_once, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, true);
 }

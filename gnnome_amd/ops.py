@@ -675,14 +675,16 @@ def can_fuse_bn_bwd_dgrad(de, W):
     return de.shape[1] in (64, 128) and de.shape[0] > 0 and de.is_contiguous() and W.stride(0) % 4 == 0
 
 
-def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt):
+def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None):
     """dxe = BatchNorm-backward(de, xe) (as bn_bwd_apply) and de += dxe @ Wt.T in ONE pass (gnnome_bn_bwd_dgrad_f32): the
-    edge-tile kernel's load waves compute the A tile instead of reading it.  Returns dxe; de is updated in place."""
+    edge-tile kernel's load waves compute the A tile instead of reading it.  Returns dxe; de is updated in place.
+    rows_once: the mean terms c1, c2 enter the first rows_once rows only (a partition's owned in-edges); default all rows."""
     de, (xe, x16) = _dense(de, "bn_bwd_dgrad.de"), _act(xe, "bn_bwd_dgrad.xe")
     Wt, ldw = _rows(Wt, "bn_bwd_dgrad.W")
     dxe = torch.empty_like(xe)     # dxe is stored the way xe is
-    _call("gnnome_bn_bwd_dgrad_x16" if x16 else "gnnome_bn_bwd_dgrad_f32", de.device, _ptr(de), _ptr(xe), de.shape[0], de.shape[1], _ptr(scale), _ptr(shift), _ptr(a), _ptr(c1),
-          _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))
+    once = de.shape[0] if rows_once is None else int(rows_once)
+    _call("gnnome_bn_bwd_dgrad_x16" if x16 else "gnnome_bn_bwd_dgrad_f32", de.device, _ptr(de), _ptr(xe), de.shape[0], once, de.shape[1], _ptr(scale), _ptr(shift),
+          _ptr(a), _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))
     return dxe
 
 

@@ -301,11 +301,11 @@ class _TrainStep(torch.autograd.Function):
                 _, g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = ops.ln_bwd(de, s["xe"], d(conv.bn_e.weight), d(conv.bn_e.bias), out=dxe)
             else:
                 W3t = d(conv.B_3.weight).t().contiguous()
-                if e_own == e_local and hasattr(ops, "bn_bwd_dgrad") and ops.can_fuse_bn_bwd_dgrad(de, W3t):
+                if hasattr(ops, "bn_bwd_dgrad") and ops.can_fuse_bn_bwd_dgrad(de, W3t):
                     # BatchNorm backward and d e_in = d e' + dxe W3 in one pass over the edges (dxe computed by the load waves)
                     g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"], c1, c2 = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
                                                                                    sh.e_global, e_own, None, stats=stats_e, apply=False)
-                    dxe = ops.bn_bwd_dgrad(de, s["xe"], s["sc_e"], s["sh_e"], s["sc_e"], c1, c2, s["mean_e"], s["rstd_e"], W3t)
+                    dxe = ops.bn_bwd_dgrad(de, s["xe"], s["sc_e"], s["sh_e"], s["sc_e"], c1, c2, s["mean_e"], s["rstd_e"], W3t, rows_once=e_own)
                     W3t = None
                 elif s["xe"].dtype != torch.float32:
                     raise _no_bf16_storage()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 5
+#define GNNOME_ABI_VERSION 6
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -359,8 +359,11 @@ int gnnome_edge_loss_f32(const float* logits, const float* logits_rev, const flo
 /* gnnome_bn_bwd_apply_f32 followed by gnnome_linear_acc_f32 in one pass over the [rows,hidden] tensors (hidden in {64,128}):
  *   dxe[r,:] = a (C[r,:] m - c1 - (X[r,:] - mean) rstd c2),  m = (X scale + shift > 0)        (written out)
  *   C[r,:]  += dxe[r,:] * W^T                                                                  (in place)
- * i.e. train.py's  dxe = bn_e backward(de, xe);  d e_in = d e' + dxe W3  with C = de, X = xe, W = W3^T. */
-int gnnome_bn_bwd_dgrad_f32(float* C, const float* X, int64_t rows, int hidden, const float* scale, const float* shift,
+ * i.e. train.py's  dxe = bn_e backward(de, xe);  d e_in = d e' + dxe W3  with C = de, X = xe, W = W3^T.
+ * rows_once (0 <= rows_once <= rows): the mean-subtraction terms c1, c2 enter the first rows_once rows only - on a
+ * destination-range partition the rows past the owned in-edges are replicas of edges another rank owns, and those terms
+ * must enter once per edge of the whole graph; rows_once = rows on a single rank. */
+int gnnome_bn_bwd_dgrad_f32(float* C, const float* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift,
                             const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
                             const float* W, int ldw, float* dxe, void* stream);
 
@@ -428,7 +431,7 @@ int gnnome_agg_edge_bwd_stats_x16(const float* e, int64_t num_edges, int hidden,
                                   const float* Ub, const float* A2h, const float* A3h, int ld_node, const int32_t* srt_src,
                                   const int32_t* srt_dst, float* de, const uint16_t* xe, const float* scale, const float* shift,
                                   const float* mean, float* s1, float* s2, void* workspace, size_t workspace_bytes, void* stream);
-int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows, int hidden, const float* scale, const float* shift, const float* a,
+int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift, const float* a,
                             const float* c1, const float* c2, const float* mean, const float* rstd, const float* W, int ldw,
                             uint16_t* dxe, void* stream);
 int gnnome_segment_sum2_x16(const uint16_t* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,

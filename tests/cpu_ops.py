@@ -355,8 +355,13 @@ def can_fuse_bn_bwd_dgrad(de, W):
     return de.shape[0] > 0
 
 
-def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt):
-    dxe = bn_bwd_apply(de, xe.float(), scale, shift, a, c1, c2, mean, rstd)
+def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None):
+    once = de.shape[0] if rows_once is None else int(rows_once)
+    dxe = torch.empty_like(de)
+    dxe[:once] = bn_bwd_apply(de[:once], xe[:once].float(), scale, shift, a, c1, c2, mean, rstd)
+    if once < de.shape[0]:   # replicas of rows another rank owns: no mean-subtraction terms
+        zero = torch.zeros_like(c1)
+        dxe[once:] = bn_bwd_apply(de[once:], xe[once:].float(), scale, shift, a, zero, zero, mean, rstd)
     de.add_(dxe @ Wt.t())
     return dxe.to(xe.dtype)     # stored the way xe is; the product above used the unrounded values
 

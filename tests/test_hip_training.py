@@ -365,6 +365,16 @@ def test_fused_backward_kernels_equal_their_unfused_pairs(hidden, e):
     got_dxe = ops.bn_bwd_dgrad(c, xe, scale, shift, a, c1, c2, mean, rstd, Wt)
     assert (got_dxe - want_dxe).abs().max().item() <= 1e-5 * max(1.0, want_dxe.abs().max().item())
     assert (c - want_c).abs().max().item() <= 2e-5 * max(1.0, want_c.abs().max().item())
+    # rows_once (a partition's owned in-edges come first): the mean terms enter those rows only; the boundary falls inside a tile
+    for once in (0, e // 3 + 7, e):
+        zero = torch.zeros_like(c1)
+        want_dxe = torch.cat([ops.bn_bwd_apply(want_de[:once], xe[:once], scale, shift, a, c1, c2, mean, rstd),
+                              ops.bn_bwd_apply(want_de[once:], xe[once:], scale, shift, a, zero, zero, mean, rstd)], 0)
+        c = want_de.clone()
+        got_dxe = ops.bn_bwd_dgrad(c, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=once)
+        assert (got_dxe - want_dxe).abs().max().item() <= 1e-5 * max(1.0, want_dxe.abs().max().item()), once
+        want_c = ops.linear(want_dxe, Wt, None, out=want_de.clone(), accumulate=True)
+        assert (c - want_c).abs().max().item() <= 2e-5 * max(1.0, want_c.abs().max().item()), once
 
 
 @pytest.mark.parametrize("hidden,e", [(128, 50_001), (64, 7000), (128, 31)])
