@@ -207,8 +207,9 @@ def aggregate_then_project(ops, lw, views, e, A1, A2, A3, h, then):
     forward takes 4.89 ms on one stream and 5.20 / 5.25 / 5.54 ms with 2 / 4 / 8 ranges (10M edges: 47.4 against 49.0 ms;
     replayed from a hipGraph 6.2-9 ms - cross-stream edges are expensive graph nodes on ROCm).  The aggregation waits on
     memory for most of its cycles and the projection is bound by neither roof when it runs alone, but together they take
-    LONGER than one after the other: both live off the same L2 / fabric, and the projection's 256 MB of output evict the e'
-    rows the aggregation's out-edge pass expects to find in L2.  Nontemporal stores in the projection change nothing."""
+    LONGER than one after the other: both live off the same L2 / fabric (a likely mechanism, not isolated: the projection's
+    256 MB of output displace the e' rows the aggregation's out-edge pass otherwise finds in L2; nontemporal stores in the
+    projection change nothing)."""
     n = h.shape[0]
     side = ops.side_stream(h.device)
     main = torch.cuda.current_stream(h.device)
