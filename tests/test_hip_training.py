@@ -252,7 +252,7 @@ def test_training_step_matches_reference_golden_g3():
     assert bufs["gnn.convs.0.bn_e.num_batches_tracked"].item() == 2 and bufs["gnn.convs.0.bn_h.num_batches_tracked"].item() == 1
 
 
-@pytest.mark.parametrize("hidden,reverse", [(128, False), (64, True)])
+@pytest.mark.parametrize("hidden,reverse", [(128, False), (64, True), (256, False)])   # 256: the width of BASELINE configs[3] / [4]
 def test_training_step_matches_oracle_autograd(hidden, reverse):
     n, e = 3000, 30000
     gr = make_graph(n, e, seed=9)
