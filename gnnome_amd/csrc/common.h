@@ -64,6 +64,7 @@ int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* 
 // C[M,K] += A[M,K] * W[K,K]^T for K in {64,128}, contiguous 16-byte aligned A and C: the wave-specialised
 // edge-tile kernel (edge_gate.hip) in accumulate mode; linear.hip routes the backward's [E,H] dgrad here.
 int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, float* C, hipStream_t s);
+int stream_linear_acc_256(const float* A, int64_t M, const float* W, int ldw, float* C, hipStream_t s);   // edge_gate_stream.hip
 
 #define GN_REQUIRE(cond, ...)                 \
     do {                                      \

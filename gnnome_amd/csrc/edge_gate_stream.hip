@@ -21,7 +21,9 @@ struct GateStream {
     static_assert(NC * (K / 4) % NT == 0, "piece count");
 };
 
-template <int K>
+// MODE 0: the gate.  MODE 2: the residual GEMM e_out += e_in W3^T (no gathers, no norm; e_out read and written by the lane that owns
+// the element, so it is updated in place; e_in is a different tensor) - gnnome_linear_acc_f32 at K = Nout = 256, the backward's d e_in.
+template <int K, int MODE = 0>
 __global__ __launch_bounds__(512) void k_edge_gate_stream(const float* __restrict__ e_in, float* __restrict__ e_out, int64_t E,
                                                           const float* __restrict__ B1h, const float* __restrict__ B2h, int ldn,
                                                           const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst,
@@ -62,18 +64,20 @@ __global__ __launch_bounds__(512) void k_edge_gate_stream(const float* __restric
     f32x4 sc[2], sh[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-        sc[cb] = *reinterpret_cast<const f32x4*>(scale + col0 + 32 * cb + ec);
-        sh[cb] = *reinterpret_cast<const f32x4*>(shift + col0 + 32 * cb + ec);
+        if (MODE == 0) {
+            sc[cb] = *reinterpret_cast<const f32x4*>(scale + col0 + 32 * cb + ec);
+            sh[cb] = *reinterpret_cast<const f32x4*>(shift + col0 + 32 * cb + ec);
+        }
     }
     for (int t = t0; t < t_end; ++t) {
         const int64_t row0 = (int64_t)t * P::TM + 32 * wave;
         if (row0 >= E) continue;
         const int64_t arow = min(row0 + cl, E - 1);   // rows past the end read the last row (never stored)
         // the gathers of this tile go out first; they are consumed after the MFMA loop
-        const int my_s = srt_src[arow], my_d = srt_dst[arow];
+        const int my_s = MODE == 0 ? srt_src[arow] : 0, my_d = MODE == 0 ? srt_dst[arow] : 0;
         f32x4 b1[2][4], b2[2][4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; MODE == 0 && it < 4; ++it) {
             const int64_t so = (int64_t)__shfl(my_s, er + 8 * it) * ldn + col0 + ec, dof = (int64_t)__shfl(my_d, er + 8 * it) * ldn + col0 + ec;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_stream(const float* __restric
                 // residual values of the epilogue instead, so that their latency runs under these 48 MFMAs
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const float* rp = e_in + min(row0 + er + 8 * it, E - 1) * H + col0 + ec;
+                    const float* rp = (MODE == 2 ? e_out : e_in) + min(row0 + er + 8 * it, E - 1) * H + col0 + ec;   // mode 2: the old C
                     res[0][it] = *reinterpret_cast<const f32x4*>(rp);
                     res[1][it] = *reinterpret_cast<const f32x4*>(rp + 32);
                 }
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(512) void k_edge_gate_stream(const float* __restric
                 f32x4 y;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    y[j] = fmaxf((a[j] + (b1[cb][it][j] + b2[cb][it][j])) * sc[cb][j] + sh[cb][j], 0.f) + res[cb][it][j];
+                    y[j] = MODE == 2 ? a[j] + res[cb][it][j]
+                                     : fmaxf((a[j] + (b1[cb][it][j] + b2[cb][it][j])) * sc[cb][j] + sh[cb][j], 0.f) + res[cb][it][j];
                 if (row0 + er + 8 * it < E) *reinterpret_cast<f32x4*>(e_out + (row0 + er + 8 * it) * H + col0 + 32 * cb + ec) = y;
             }
             __builtin_amdgcn_wave_barrier();
@@ -164,8 +169,9 @@ __global__ __launch_bounds__(512) void k_edge_gate_stream(const float* __restric
     }
 }
 
-int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn, const int32_t* ss,
-                       const int32_t* sd, const float* W3, int ldw, const float* scale, const float* shift, hipStream_t s) {
+template <int MODE>
+static int stream_launch(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn, const int32_t* ss,
+                         const int32_t* sd, const float* W3, int ldw, const float* scale, const float* shift, hipStream_t s) {
     using P = GateStream<256>;
     const int n_chunks = 256 / P::NC;
     const int64_t tiles = (E + P::TM - 1) / P::TM;
@@ -186,11 +192,21 @@ int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* 
         const int64_t row_off = first * P::TM, rows = (E - row_off) < n_t * P::TM ? (E - row_off) : n_t * P::TM;
         int g = groups > n_t ? (int)n_t : groups;
         const int tpg = (int)((n_t + g - 1) / g);
-        hipLaunchKernelGGL((k_edge_gate_stream<256>), dim3(g, n_chunks), dim3(P::NT), 0, s, e_in + row_off * 256, e_out + row_off * 256, rows,
-                           B1h, B2h, ldn, ss + row_off, sd + row_off, W3, ldw, scale, shift, (int)n_t, tpg);
+        hipLaunchKernelGGL((k_edge_gate_stream<256, MODE>), dim3(g, n_chunks), dim3(P::NT), 0, s, e_in + row_off * 256, e_out + row_off * 256, rows,
+                           B1h, B2h, ldn, MODE == 0 ? ss + row_off : nullptr, MODE == 0 ? sd + row_off : nullptr, W3, ldw, scale, shift, (int)n_t, tpg);
     }
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
+}
+
+int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn, const int32_t* ss,
+                       const int32_t* sd, const float* W3, int ldw, const float* scale, const float* shift, hipStream_t s) {
+    return stream_launch<0>(e_in, e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, scale, shift, s);
+}
+
+// C[M,256] += A[M,256] W^T (W = [256,256], row stride ldw; A and C dense, distinct): the streaming kernel as a residual GEMM
+int stream_linear_acc_256(const float* A, int64_t M, const float* W, int ldw, float* C, hipStream_t s) {
+    return stream_launch<2>(A, C, M, nullptr, nullptr, 0, nullptr, nullptr, W, ldw, nullptr, nullptr, s);
 }
 
 }  // namespace gnnome

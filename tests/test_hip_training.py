@@ -171,7 +171,7 @@ def test_gate_raw_with_fused_batch_statistics(H, e_base):
     assert torch.equal(again[1], mean) and torch.equal(again[2], var)
 
 
-@pytest.mark.parametrize("H", [64, 128])
+@pytest.mark.parametrize("H", [64, 128, 256])   # 256: the streaming edge-tile kernel as a residual GEMM
 def test_edge_sized_residual_gemm(H):
     """C += A W^T on [E,H] rows (d e_in = d e' + dxe W3): the wave-specialised kernel behind gnnome_linear_acc_f32."""
     e = 40_000 + H + 7
