@@ -312,7 +312,7 @@ def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: 200 forwards at c2 (>= 1 s timed), fewer for the larger workloads")
+    ap.add_argument("--steps", type=int, default=None, help="default: 250 forwards at c2 (>= 1.2 s timed), fewer for the larger workloads")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: c2 at --gpus 1, 10m at --gpus > 1")
     ap.add_argument("--kind", default="banded", choices=["banded", "uniform"])
@@ -337,7 +337,7 @@ def main():
         return
     n, e, hidden = WORKLOADS[args.workload]
     if args.steps is None:
-        args.steps = max(10, min(200, int(2e8 // e))) if args.mode == "infer" else max(5, min(50, int(5e7 // e)))
+        args.steps = max(10, min(250, int(2.5e8 // e))) if args.mode == "infer" else max(5, min(50, int(5e7 // e)))
     if args.warmup is None:
         args.warmup = max(3, args.steps // 20)
 
