@@ -320,7 +320,7 @@ def main():
                     help="infer: one forward (BASELINE configs[1]); train: the training step as the headline value (configs[2], fp32)")
     ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"], help="train: model.activation_storage (bf16 = xe / dxe stored as bfloat16)")
     ap.add_argument("--symmetry", action="store_true", help="train: the reference's default step (symmetry loss: two forwards, dropout 0.2)")
-    ap.add_argument("--hipgraph", action="store_true", help="replay the forward from a captured hipGraph (single GPU, infer)")
+    ap.add_argument("--hipgraph", action="store_true", help="replay the forward from a captured hipGraph (infer; at --gpus > 1: one graph per stretch between two collectives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="SURVEY.md 8d's protocol: E = 1M median of 3 + one E = 10M run (minutes)")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -459,6 +459,10 @@ def main():
         if args.mode == "train":
             raise SystemExit("--mode train at --gpus > 1: use tests/test_hip_partition.py's harness; the bench times inference at N > 1")
 
+        if args.hipgraph:   # the kernels between two collectives replayed from one hipGraph each (dist.CapturedPartitionedForward)
+            runner.capture()
+            args.no_kernel_timers = True  # events cannot be recorded inside a replayed graph
+
         def step():
             return runner.forward()
 
@@ -466,7 +470,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-        parallelism = f"dst-range x{world}" + (" (ALL RANKS ON ONE GPU over gloo: plumbing check, not a measurement)" if args.one_gpu_gloo
+        parallelism = f"dst-range x{world}" + (" (hipGraph segments between the collectives)" if args.hipgraph else "") + (" (ALL RANKS ON ONE GPU over gloo: plumbing check, not a measurement)" if args.one_gpu_gloo
                                                else " (RCCL FAILED: host-staged gloo transport)" if gloo_transport else " over RCCL")
         # what the halo exchange moves: rows this rank sends / receives per layer, and the time of one exchange alone
         sent, recv = int(sum(plan.send_counts)), int(sum(plan.recv_counts))

@@ -323,6 +323,73 @@ def run_partitioned(ops, prep, part, x_local, e_local, group=None, reduce_result
     return part.assemble_logits(piece, group)
 
 
+class CapturedPartitionedForward:
+    """run_partitioned with every stretch of kernels BETWEEN two collectives recorded once as a hipGraph: one forward is then
+    L + 1 graph replays + L halo exchanges + the logits all-gather instead of ~55 Python-issued launches - what a rank needs
+    when its share of the graph is small enough for the host to become the limit (eight ranks on the 10M-edge graph: ~6 ms
+    of kernels per rank).  The collectives themselves stay OUTSIDE the graphs (RCCL / gloo calls between replays, ordered on
+    the stream), so nothing depends on capturing a communicator; the price is that the exchange no longer overlaps the
+    projection of the owned rows (the halo rows of a layout-ordered graph are a few per cent of a rank's rows).
+    Same kernels, same order: the logits equal run_partitioned's bit for bit.  Inputs are the runner's static x / e."""
+
+    def __init__(self, runner):
+        if runner.prep is None:
+            raise RuntimeError("CapturedPartitionedForward is for eval-mode inference")
+        ops, prep, part = runner.ops, runner.prep, runner.part
+        self.part, self.group, self.ops = part, runner.group, ops
+        dev = runner.x.device
+        with torch.no_grad():
+            for _ in range(2):   # eager warm-up: weight preparation, allocator pools, the aggregation's hub scratch
+                run_partitioned(ops, prep, part, runner.x, runner.e, runner.group)
+        torch.cuda.synchronize(dev)
+        views, n_own, H = part.views, part.n_own, prep.hidden
+        pool = torch.cuda.graph_pool_handle()
+        self.graphs, self.h, self.packed = [], [], []
+        state = {"h": None, "e": None, "scratch": {}}
+
+        def layer(li):
+            lw = prep.layers[li]
+            if li == 0:
+                state["h"] = ops.encode(runner.x, *prep.enc_node)
+                state["e"] = engine.encode_edges(ops, prep, views, runner.e)
+            h = state["h"]
+            P = engine.project(ops, lw, h)
+            A1, A2, A3, B1, B2 = (P[:, i * H:(i + 1) * H] for i in range(5))
+            state["e"] = engine.gate(ops, lw, views, state["e"], B1, B2, (runner.e, prep.enc_edge), state["scratch"])
+            state["h"] = ops.node_aggregate(state["e"], A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_own)
+            self.h.append(state["h"])
+            self.packed.append(ops.gather_rows(state["h"], part.send_idx) if part.world > 1 else None)
+
+        def score():
+            pw = prep.predictor
+            hs = pw["hs"]
+            PQ = ops.linear(state["h"], pw["W_nodes"], pw["b_nodes"])
+            sv = _ScoreViews(views, part.srt_geid)
+            if part.world == 1:
+                self.piece = torch.empty(part.num_edges_global, dtype=torch.float32, device=dev)
+            else:
+                self.piece = torch.empty(part.score_pad, dtype=torch.float32, device=dev)
+            if part.n_score > 0:
+                ops.edge_score(state["e"], PQ[:, :hs], PQ[:, hs:], sv, pw["W1_e"], pw["W2"], pw["b2"], pw["W3"], pw["b3"], self.piece,
+                               num_edges=part.n_score, scatter_to_edge_id=part.world == 1)
+
+        with torch.no_grad():
+            for fn in [lambda li=li: layer(li) for li in range(len(prep.layers))] + [score]:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    fn()
+                self.graphs.append(g)
+        self._keep = state   # the recorded kernels read and write these tensors at their recorded addresses
+
+    def __call__(self):
+        p = self.part
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.h) and p.world > 1:
+                all_to_all_rows(self.h[i][p.n_own:], self.packed[i], p.recv_counts, p.send_counts, self.group)
+        return (self.piece if p.world == 1 else p.assemble_logits(self.piece, self.group)).unsqueeze(1)
+
+
 class _ScoreViews:
     """The scorer only reads srt_src / srt_dst / srt_eid."""
 
@@ -339,10 +406,17 @@ class PartitionedRunner:
         self.x = part.local_node_rows(x_global).to(device=device, dtype=torch.float32).contiguous()
         self.e = part.local_edge_rows(e_global).to(device=device, dtype=torch.float32).contiguous()
 
+    def capture(self):
+        """Record the forward as hipGraph segments between the collectives (CapturedPartitionedForward); forward() replays them."""
+        self._captured = CapturedPartitionedForward(self)
+        return self
+
     def forward(self):
         """eval mode: logits[E,1] of one whole-graph scoring pass."""
         if self.prep is None:
             raise RuntimeError("built from a model in train mode: use train_forward()")
+        if getattr(self, "_captured", None) is not None:
+            return self._captured()
         with torch.no_grad():
             return run_partitioned(self.ops, self.prep, self.part, self.x, self.e, self.group).unsqueeze(1)
 

@@ -50,7 +50,12 @@ def worker(rank, world, port, case, out_dir):
         with torch.no_grad():
             logits = gdist.run_partitioned(backend, prep, part, part.local_node_rows(g["x"]).contiguous(),
                                            part.local_edge_rows(g["e"]).contiguous())
-        torch.save({"logits": logits.cpu(), "n_own": part.n_own, "n_local": part.n_local, "n_score": part.n_score,
+        replayed = None
+        if g.get("captured"):   # the same forward as hipGraph segments between the collectives, replayed twice
+            runner = gdist.PartitionedRunner(m, part, g["x"], g["e"], where, ops=backend).capture()
+            runner.forward()
+            replayed = runner.forward().squeeze(1).cpu()
+        torch.save({"logits": logits.cpu(), "replayed": replayed, "n_own": part.n_own, "n_local": part.n_local, "n_score": part.n_score,
                     "e_local": int(part.edge_gid.numel()), "bounds": part.bounds, "send": part.send_counts,
                     "recv": part.recv_counts}, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:

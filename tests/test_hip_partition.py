@@ -60,6 +60,25 @@ def test_two_ranks_inference_matches_reference_golden_g2(tmp_path, shipped_weigh
     assert sum(o["n_score"] for o in outs) == g["src"].numel() and all(sum(o["send"]) > 0 for o in outs)
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_partitioned_forward_replayed_from_hipgraph_segments(tmp_path, world):
+    """dist.CapturedPartitionedForward: the kernels between two collectives recorded as one hipGraph each, the halo
+    exchanges and the logits all-gather issued between the replays - bit-identical to the eager partitioned forward, on one
+    rank and on two ranks sharing the GPU (banded 40k-edge graph, H = 128: cut edges, halo rows both ways)."""
+    from gnnome_amd.synth import make_graph
+    from oracle.symgated_oracle import degree_features
+    n, e, hidden = 4000, 40_000, 128
+    gr = make_graph(n, e, seed=4, kind="banded")
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=degree_features(gr["src"], gr["dst"], n), e=gr["e"], hidden=hidden, layers=8,
+                state_dict=random_state_dict(hidden, seed=4), device="cuda", captured=True)
+    outs = _run(world, case, tmp_path)
+    for o in outs:
+        assert o["replayed"] is not None and torch.equal(o["replayed"], o["logits"])
+    assert all(torch.equal(o["logits"], outs[0]["logits"]) for o in outs)
+    if world > 1:
+        assert all(sum(o["send"]) > 0 for o in outs)
+
+
 def test_two_ranks_training_step_matches_reference_golden_g3(tmp_path):
     g = load_golden("g3_train_h64.pt")
     case = dict(src=g["src"], dst=g["dst"], num_nodes=g["num_nodes"], x=g["x"], e=g["e"], y=g["y"], pos_weight=g["pos_weight"],
