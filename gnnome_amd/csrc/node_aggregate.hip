@@ -140,6 +140,80 @@ __device__ __forceinline__ void accumulate_items(const float* __restrict__ e, co
     }
 }
 
+// The same sums with the same association (every item goes to the same lane group and is added in the same order: bit-identical
+// results), restructured so that the e rows of the IN-edges - whose positions follow from the CSR pointer alone - are requested
+// before the wave waits for its index loads: the in-items and the out-items of a 64-item batch run as two loops (the step that
+// straddles the boundary is cut in two; the two directions have separate accumulators, so the order within each is unchanged),
+// and inside the in-loop all row loads go out first, then the neighbour indices are awaited and the table rows gathered.
+template <int H, int U = (H == 256 ? 8 : 4)>
+__device__ __forceinline__ void accumulate_items_split(const float* __restrict__ e, const float* __restrict__ A2h, const float* __restrict__ A3h,
+                                                       int ldn, const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_pos,
+                                                       const int32_t* __restrict__ out_dst, int ib, int din, int ob, int lo, int hi, int lane,
+                                                       int group, int c, f32x4& nf, f32x4& df, f32x4& nb, f32x4& db) {
+    constexpr int LPR = H / 4, G = 64 / LPR;
+    for (int base = lo; base < hi; base += 64) {
+        const int j = base + lane;   // lane l owns item base + l
+        int my_p = 0, my_n = 0;
+        if (j < din) {
+            my_n = srt_src[ib + j];
+        } else if (j < hi) {
+            my_p = out_pos[ob + j - din];
+            my_n = out_dst[ob + j - din];
+        }
+        const int m = min(64, hi - base);
+        const int m_in = min(m, max(din - base, 0));   // items [0, m_in) of this batch are in-edges
+        for (int j0 = 0; j0 < m_in; j0 += G * U) {
+            f32x4 x[U], a[U];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int item = j0 + u * G + group;
+                live[u] = item < m_in;
+                x[u] = *reinterpret_cast<const f32x4*>(e + (int64_t)(ib + base + (live[u] ? item : 0)) * H + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int item = j0 + u * G + group;
+                const int nn = __shfl(my_n, live[u] ? item : 0);
+                a[u] = *reinterpret_cast<const f32x4*>(A2h + (int64_t)nn * ldn + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (live[u]) {
+                    f32x4 s;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] = sigmoidf_(x[u][k]);
+                    nf += s * a[u];
+                    df += s;
+                }
+            }
+        }
+        for (int j0 = m_in / (G * U) * (G * U); j0 < m; j0 += G * U) {
+            f32x4 x[U], a[U];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int item = j0 + u * G + group;
+                live[u] = item >= m_in && item < m;
+                const int it = live[u] ? item : m_in;   // (m_in < m here: a valid out-item)
+                const int p = __shfl(my_p, it), nn = __shfl(my_n, it);
+                x[u] = *reinterpret_cast<const f32x4*>(e + (int64_t)p * H + c);
+                a[u] = *reinterpret_cast<const f32x4*>(A3h + (int64_t)nn * ldn + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (live[u]) {
+                    f32x4 s;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] = sigmoidf_(x[u][k]);
+                    nb += s * a[u];
+                    db += s;
+                }
+            }
+        }
+    }
+}
+
 // First launch of the hub path: wave (blockIdx.x * 4 + wave) reduces chunk c of EVERY split hub to (sum s*A2h, sum s,
 // sum s*A3h, sum s) partials; chunk boundaries are a function of the node's item count only.
 template <int H>
@@ -193,7 +267,7 @@ __global__ __launch_bounds__(kAggThreads) void k_hub_partials(const float* __res
 // shares everything after the sums (two launches instead of a branch: the partial-sum loop cost the regular kernel 22
 // registers and a third of its occupancy).  U: items per lane group in flight, WPS: waves per SIMD asked of the register
 // allocator (0 = unconstrained).
-template <int H, int NORM, int MODE, bool HUBFIN = false, int U = (H == 256 ? 8 : 4), int WPS = 0>
+template <int H, int NORM, int MODE, bool HUBFIN = false, int U = (H == 256 ? 8 : 4), int WPS = 0, int SPLIT = 0>
 __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggregate(
     const float* __restrict__ e, int64_t n_out, const float* __restrict__ A1h, const float* __restrict__ A2h,
     const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src,
@@ -242,7 +316,10 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
             }
         }
     } else {
-        accumulate_items<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
+        if (SPLIT == 1)
+            accumulate_items_split<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
+        else
+            accumulate_items<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
     }
 
     f32x4 v, t0, t1, t2, t3;
@@ -330,10 +407,15 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
     }
     // (measurement knob: unused dynamic LDS caps the workgroups resident per CU, i.e. the window of nodes in flight)
     const size_t dyn = (size_t)tuning(kTuneAggLdsKiB) * 1024;
-#define GN_AGG_LAUNCH(NORM_, MODE_, FIN_, U_, WPS_, GRID_)                                                                              \
-    hipLaunchKernelGGL((k_node_aggregate<H, NORM_, MODE_, FIN_, U_, WPS_>), dim3((unsigned)(GRID_)), dim3(kAggThreads), (FIN_) ? 0 : dyn, s, e, \
+#define GN_AGG_LAUNCH_S(NORM_, MODE_, FIN_, U_, WPS_, GRID_, SPLIT_)                                                                           \
+    hipLaunchKernelGGL((k_node_aggregate<H, NORM_, MODE_, FIN_, U_, WPS_, SPLIT_>), dim3((unsigned)(GRID_)), dim3(kAggThreads), (FIN_) ? 0 : dyn, s, e, \
                        (FIN_) ? n_out : node_end, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,   \
                        (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials, (FIN_) ? (int64_t)0 : node0)
+#define GN_AGG_LAUNCH(NORM_, MODE_, FIN_, U_, WPS_, GRID_) GN_AGG_LAUNCH_S(NORM_, MODE_, FIN_, U_, WPS_, GRID_, 1)
+    // The regular launches run the split item loop (accumulate_items_split: 0.2207 -> 0.2103 ms per launch at configs[1], whole forward
+    // 4.89 -> 4.78 ms, the same bits, the same 782 MB fetched); variant 6 keeps the single loop for A/B.  (A single loop with a
+    // wave-uniform fast path for steps of in-edges only - one round fewer, the overlap only when a node has >= G U in-edges - measured
+    // the same as the split form: 4.875 against 4.881 ms.)
     // items per lane group in flight: 4 at H <= 128.  Measured at configs[1] (tools/agg_time.py <H> variants): 1 item 0.2105 ms,
     // 2 items 0.2115, 4 items 0.2197, 8 items 0.2533 - the launch time hardly depends on the loads in flight per wave (the
     // kernel sits at the HBM rate this access pattern sustains) - but with 2 items the 8 resident waves per SIMD widen the
@@ -354,6 +436,7 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
             case 3: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 1, 0, blocks); break;
             case 4: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 8, 0, blocks); break;
             case 5: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 2, 0, blocks); break;
+            case 6: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 0); break;   // the unsplit item loop (in-edge rows requested after the index wait)
             default: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks); break;
         }
         if (hub_pass) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, true, UD, 0, kFinGrid);
@@ -362,6 +445,7 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
         if (hub_pass) GN_AGG_LAUNCH(GNNOME_NORM_LAYER, 0, true, UD, 0, kFinGrid);
     }
 #undef GN_AGG_LAUNCH
+#undef GN_AGG_LAUNCH_S
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }

@@ -292,16 +292,26 @@ __global__ __launch_bounds__(256) void k_segment_sum2(const void* __restrict__ X
     if (node >= n_nodes) return;
     const int group = lane / LPR, c = (lane % LPR) * 4;
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // all four CSR pointers and the positions of the first 64 out-edges (one per lane) are requested up front: the out-edge pass
+    // then starts without its own pointer -> position -> row chain of round trips (same sums in the same order)
+    const int b_in = in_ptr[node], e_in = in_ptr[node + 1], b_out = out_ptr[node], e_out = out_ptr[node + 1];
+    const int my_pos = b_out + lane < e_out ? out_pos[b_out + lane] : 0;
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
-        const int32_t* ptr = side == 0 ? in_ptr : out_ptr;
-        const int b = ptr[node], e = ptr[node + 1];
+        const int b = side == 0 ? b_in : b_out, e = side == 0 ? e_in : e_out;
         for (int q0 = b; q0 < e; q0 += G * U) {
             f32x4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int q = q0 + u * G + group;
-                const int64_t p = q < e ? (side == 0 ? q : out_pos[q]) : 0;
+                int64_t p = 0;
+                if (side == 0) {
+                    p = q < e ? q : 0;
+                } else {
+                    const int k = q - b;   // position in the node's out-list
+                    const int near = __shfl(my_pos, k < 64 ? k : 0);
+                    p = q < e ? (k < 64 ? near : out_pos[q]) : 0;
+                }
                 v[u] = q < e ? load4_as<X16>(X, p * W + c) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -569,7 +579,7 @@ extern "C" int gnnome_gate_center_f32(const float* e, int64_t num_edges, int hid
 // (m = relu mask rebuilt from the forward's expression).  One read of xe here replaces gnnome_bn_bwd_stats_f32's reads of de'
 // and xe.
 namespace gnnome {
-template <int H, bool X16>
+template <int H, bool X16, bool BATCH = true>
 __global__ __launch_bounds__(kEwThreads) void k_agg_edge_bwd_stats(const float* __restrict__ e, int64_t E, const float* __restrict__ Tf,
                                                                    const float* __restrict__ Uf, const float* __restrict__ Tb,
                                                                    const float* __restrict__ Ub, const float* __restrict__ A2h,
@@ -579,13 +589,17 @@ __global__ __launch_bounds__(kEwThreads) void k_agg_edge_bwd_stats(const float* 
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ mean, float* __restrict__ part) {
     column_reduce<2>(E, H, part, [&](int64_t p, int c, f32x4 (&acc)[2]) {
+        // the three row loads whose addresses need no index go out with the index loads; the six gathers follow when the indices are in
         const int64_t s_ = srt_src[p], d_ = srt_dst[p];
         const f32x4 x = *reinterpret_cast<const f32x4*>(e + p * H + c);
+        const f32x4 xv = load4_as<X16>(xe, p * H + c);
+        f32x4 g = *reinterpret_cast<const f32x4*>(de + p * H + c);
         const f32x4 tf = *reinterpret_cast<const f32x4*>(Tf + d_ * H + c), uf = *reinterpret_cast<const f32x4*>(Uf + d_ * H + c);
         const f32x4 tb = *reinterpret_cast<const f32x4*>(Tb + s_ * H + c), ub = *reinterpret_cast<const f32x4*>(Ub + s_ * H + c);
         const f32x4 a2 = *reinterpret_cast<const f32x4*>(A2h + s_ * ldn + c), a3 = *reinterpret_cast<const f32x4*>(A3h + d_ * ldn + c);
-        const f32x4 xv = load4_as<X16>(xe, p * H + c);
-        f32x4 g = *reinterpret_cast<const f32x4*>(de + p * H + c);
+        // Left alone, the compiler sinks every load to its first use to save registers - one memory round trip after the other
+        // (seven `s_waitcnt vmcnt(0)` per row in the ISA).  Nothing may cross this line: all nine loads are in flight together.
+        if (BATCH) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float sg = sigmoidf_(x[j]);
@@ -618,7 +632,13 @@ static int agg_edge_bwd_stats_impl(const float* e, int64_t num_edges, int hidden
                        srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace)
     switch (hidden) {
         case 64: if (x16) GN_AEBS(64, true); else GN_AEBS(64, false); break;
-        case 128: if (x16) GN_AEBS(128, true); else GN_AEBS(128, false); break;
+        case 128:
+            if (x16) GN_AEBS(128, true);
+            else if (tuning(kTuneGateExperiment) == 77)   // A/B: the compiler's own load placement
+                hipLaunchKernelGGL((k_agg_edge_bwd_stats<128, false, false>), dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h,
+                                   ld_node, srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace);
+            else GN_AEBS(128, false);
+            break;
         case 256: if (x16) GN_AEBS(256, true); else GN_AEBS(256, false); break;
         default: set_error("agg_edge_bwd_stats: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }

@@ -25,7 +25,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "once":   # a few launches of the defaul
         ops.node_aggregate(ee, A1, A2, A3, views, h, 0, sc, sh)
     torch.cuda.synchronize()
     sys.exit(0)
-VARIANTS = {0: "default (U=4 at H<=128, 8 at 256)", 1: "U=4, 8 waves/SIMD", 2: "U=2, 8 waves/SIMD", 3: "U=1", 4: "U=8", 5: "U=2"}
+VARIANTS = {0: "default (U=4 at H<=128, 8 at 256)", 1: "U=4, 8 waves/SIMD", 2: "U=2, 8 waves/SIMD", 3: "U=1", 4: "U=8", 5: "U=2", 6: "U=4, single item loop (in-edge rows requested after the index wait; the round-1 form)"}
 if len(sys.argv) > 2 and sys.argv[2] == "variants":   # items in flight per lane group against occupancy (gnnome_set_tuning key 7)
     for rnd in range(3):
         for v, name in VARIANTS.items():
