@@ -26,6 +26,8 @@
 // single-wave sum.  Up to kHubCap hubs per call take this path; any further ones fall back to the single wave.
 #include "common.h"
 
+#include <mutex>
+
 namespace gnnome {
 
 constexpr int kAggThreads = 256;
@@ -45,14 +47,25 @@ struct HubScratch {
 // Per-device scratch of the hub path, allocated on first use (never inside a stream capture: the first call of any
 // process is an eager one - CapturedForward and the benchmarks warm up before they record).  One buffer per device:
 // launches of this library on one device are stream-ordered.
-static HubScratch* hub_scratch() {
+// CONTRACT: the scratch is shared by every stream of a device, so two aggregations of graphs WITH hubs must not
+// be in flight on two streams of one device at once (this package launches all its work on torch's current stream; the
+// optional second stream of engine.aggregate_then_project runs projections only).  The host-side table is guarded by a
+// mutex, and the first use never allocates inside a stream capture: it reports an error instead (warm up eagerly first).
+static HubScratch* hub_scratch(hipStream_t s, bool* capturing_unallocated) {
     static HubScratch table[64];
+    static std::mutex guard;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(guard);
     HubScratch& h = table[dev];
-    if (h.count == nullptr) {
-        if (hipMalloc(&h.count, sizeof(int)) != hipSuccess) return nullptr;
-        if (hipMalloc(&h.nodes, sizeof(int) * kHubCap) != hipSuccess) return nullptr;
+    if (h.partials == nullptr) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            *capturing_unallocated = true;
+            return nullptr;
+        }
+        if (h.count == nullptr && hipMalloc(&h.count, sizeof(int)) != hipSuccess) return nullptr;
+        if (h.nodes == nullptr && hipMalloc(&h.nodes, sizeof(int) * kHubCap) != hipSuccess) return nullptr;
         if (hipMalloc(&h.partials, sizeof(float) * (size_t)kHubCap * kHubChunks * 4 * kHubMaxH) != hipSuccess) return nullptr;
     }
     return &h;
@@ -385,7 +398,10 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
     GN_REQUIRE(node_begin >= 0 && node_begin < node_end && node_end <= n_out, "node_aggregate: bad node range [%lld, %lld) of %lld",
                (long long)node_begin, (long long)node_end, (long long)n_out);
     // the hub path (see the header comment): find the long lists, reduce them chunk-wise, let the node's wave add the chunks
-    HubScratch* hub = tuning(kTuneAggHubs) == 1 ? nullptr : hub_scratch();
+    bool capturing_unallocated = false;
+    HubScratch* hub = tuning(kTuneAggHubs) == 1 ? nullptr : hub_scratch(s, &capturing_unallocated);
+    GN_REQUIRE(!capturing_unallocated, "node_aggregate: first call on this device inside a stream capture - run one eager call first "
+                                       "(the hub scratch is allocated on first use)");
     const bool hub_pass = hub != nullptr && node_begin == 0;
     const int* hub_count = hub ? hub->count : nullptr;
     const int* hub_nodes = hub ? hub->nodes : nullptr;

@@ -18,6 +18,7 @@ them on the CPU (csrc/decode.hip replays libstdc++'s nth_element), successor lis
 graph_parser.py:31-37.
 """
 import ctypes
+import logging
 import math
 import os
 import pickle
@@ -155,10 +156,10 @@ REFERENCE_SAMPLER_LIMIT = 2 ** 22   # remaining edges x nb_paths up to which the
 def decode_contigs(dg, len_threshold, nb_paths=50, sampler=None, checkpoint_dir=None, load_checkpoint=False, visited=None,
                    stats=None):
     """The outer loop of get_contigs_greedy (inference.py:193-359) on a DecodeGraph with scores set.  `sampler(prob, k)`
-    -> k indices into the remaining edges.  Default: the reference's own draw (sample_edges: torch's CPU generator, the
-    same random stream) while remaining edges x nb_paths <= REFERENCE_SAMPLER_LIMIT, sample_edges_device beyond (the
-    reference's nb_paths-fold copy of the probabilities is what costs it seconds per contig on large graphs).  Returns
-    the list of walks (lists of node ids)."""
+    -> k indices into the remaining edges.  sampler=None (this function's default, NOT get_contigs_greedy's, which always
+    passes the reference's sampler): the reference's own draw (sample_edges: torch's CPU generator, the same random stream)
+    while remaining edges x nb_paths <= REFERENCE_SAMPLER_LIMIT (2^22: ~42k edges at 100 paths), sample_edges_device beyond -
+    a DIFFERENT random stream; the switch is logged once per call.  Returns the list of walks (lists of node ids)."""
     dev = dg.device
     visited = torch.zeros(dg.num_nodes, dtype=torch.uint8, device=dev) if visited is None else visited
     all_contigs, all_walks_len, all_contigs_len = [], [], []
@@ -170,12 +171,17 @@ def decode_contigs(dg, len_threshold, nb_paths=50, sampler=None, checkpoint_dir=
         if state["visited"]:
             visited[torch.tensor(sorted(state["visited"]), device=dev)] = 1
     src_l, dst_l = dg.src.long(), dg.dst.long()
+    switched = False
     while True:
         remaining = torch.nonzero((visited[src_l] == 0) & (visited[dst_l] == 0)).squeeze(1)   # get_subgraph, :39-51
         if remaining.numel() == 0:
             break
         prob = dg.prob[remaining]
         draw = sampler or (sample_edges if remaining.numel() * nb_paths <= REFERENCE_SAMPLER_LIMIT else sample_edges_device)
+        if sampler is None and draw is sample_edges_device and not switched:
+            switched = True
+            logging.getLogger(__name__).info("decode_contigs: %d remaining edges x %d paths > %d: start edges drawn by the device "
+                                             "sampler (not the reference's random stream)", remaining.numel(), nb_paths, REFERENCE_SAMPLER_LIMIT)
         idx = draw(prob.cpu() if draw is sample_edges else prob, nb_paths)
         cand = remaining[torch.as_tensor(idx).to(dev).long()]
         res = greedy_walks(dg, visited, cand)
@@ -215,8 +221,15 @@ def get_contigs_greedy(g, succs, preds, edges, len_threshold, nb_paths=50, use_l
     edata['score'] (or ['y'] with use_labels), edata['prefix_length'], ndata['read_length'].  `succs`, `preds`, `edges`
     (the pickled dicts of graph_parser.py:409-411) are accepted for signature compatibility and NOT read: they are
     functions of g.edges() in edge-id order (graph_parser.py:31-37, :55-58, :77-80), which is what the device arrays are
-    built from."""
+    built from.  `sampler(prob, k)`: default = the reference's draw (sample_edges), so integer results equal the reference's
+    under the same seed at every graph size; pass sample_edges_device for one device-side multinomial per contig."""
     del succs, preds, edges
+    if sampler is None:
+        # the reference's own Categorical draw from torch's CPU generator at EVERY size: with the same torch.manual_seed the
+        # start edges, and therefore the contigs, are the reference's.  (It copies the probabilities nb_paths times - 0.3 s
+        # per contig at 1M edges; `sampler=sample_edges_device` is the opt-in fast path with a different random stream,
+        # which pipeline.assemble uses by default.)
+        sampler = sample_edges
     src, dst = g.edges()
     dg = DecodeGraph(src, dst, int(g.num_nodes()), g.edata["prefix_length"], g.ndata["read_length"])
     dg.set_scores(g.edata["y"] if use_labels else g.edata["score"], logprobs_on_device=logprobs_on_device, use_labels=use_labels)

@@ -400,10 +400,13 @@ class _ScoreViews:
 class PartitionedRunner:
     """Holds one rank's partition, weights and inputs on its GPU; forward() = one whole-graph scoring pass."""
 
-    def __init__(self, model, part, x_global, e_global, device, ops=hip_ops, group=None):
+    def __init__(self, model, part, x_global, e_global, device, ops=hip_ops, group=None, x_local=None):
+        """x_global[N,F]: the node features of the whole graph (this rank keeps its owned + halo rows), or x_local: those rows
+        already selected (part.local_node_rows), for callers that never hold the [N,F] table on this device."""
         self.ops, self.part, self.group, self.model = ops, part, group, model
         self.prep = None if model.training else engine.prepared_for(model, device, engine.Prepared)
-        self.x = part.local_node_rows(x_global).to(device=device, dtype=torch.float32).contiguous()
+        rows = part.local_node_rows(x_global) if x_local is None else x_local
+        self.x = rows.to(device=device, dtype=torch.float32).contiguous()
         self.e = part.local_edge_rows(e_global).to(device=device, dtype=torch.float32).contiguous()
 
     def capture(self):

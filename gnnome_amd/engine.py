@@ -155,10 +155,10 @@ def _refuse_training(module):
         raise NotImplementedError("train mode is supported through SymGatedGCNModel.forward only; call .eval() for the "
                                   "layer-level API")
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        # the layer-level entries return tensors WITHOUT autograd history: say so instead of handing back None gradients
-        import warnings
-        warnings.warn("gnnome_amd layer-level forward is inference-only: its outputs carry no autograd history "
-                      "(wrap the call in torch.no_grad(), or train through SymGatedGCNModel.forward)", stacklevel=3)
+        # the layer-level entries return tensors WITHOUT autograd history: refuse instead of handing back None gradients
+        # (a frozen-BatchNorm fine-tune through the layer API in eval mode would otherwise train nothing, silently)
+        raise NotImplementedError("gnnome_amd layer-level forward is inference-only: its outputs carry no autograd history - wrap the "
+                                  "call in torch.no_grad() (or freeze the parameters), or train through SymGatedGCNModel.forward")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -351,6 +351,7 @@ def layer_forward_edge_id_order(conv, g, h, e):
         e_new = torch.empty_like(es)
         e_new[views.srt_eid.long()] = es
         h_new = F.dropout(h_new, conv.dropout, training=conv.training)
+    views.check_range()   # deferred endpoint check of a fresh graph (GraphViews validate="lazy")
     return h_new.to(out_device), e_new.to(out_device)
 
 
@@ -366,4 +367,5 @@ def score_forward_edge_id_order(pred, graph, x, e):
         es = hip_ops.gather_rows(ed, views.srt_eid)
         logits = torch.empty(views.num_edges, dtype=torch.float32, device=device)
         score_step(hip_ops, pw, views, xd, es, logits)
+    views.check_range()
     return logits.unsqueeze(1).to(out_device)

@@ -34,7 +34,35 @@ def degree_features(graph, reverse=False, device=None):
             cols.append(((d - d.mean()) / d.std()).unsqueeze(1))   # torch.std: unbiased, as in the reference
         return torch.cat(cols, 1).contiguous()
     views = graph if isinstance(graph, ops.GraphViews) else views_for(graph, device)
-    return ops.degree_features(views, reverse)
+    x = ops.degree_features(views, reverse)
+    views.check_range()   # a fresh graph's deferred endpoint check (GraphViews validate="lazy"): clamped endpoints never pass silently
+    return x
+
+
+def stored_degrees(graph, device=None):
+    """(in_deg, out_deg) float32[N] of `graph` as the reference's parser stores them in ndata (graph_parser.py: the degrees
+    of the FULL graph, which sub-graphs index into), counted on the device from the views' CSR pointers."""
+    device = device or (graph.device if isinstance(graph, ops.GraphViews) else torch.device("cuda", torch.cuda.current_device()))
+    views = graph if isinstance(graph, ops.GraphViews) else views_for(graph, device)
+    views.check_range()
+    ind = (views.in_ptr[1:] - views.in_ptr[:-1]).float()
+    outd = (views.out_ptr[1:] - views.out_ptr[:-1]).float()
+    return (outd, ind) if views.transposed else (ind, outd)
+
+
+def partition_degree_features(full_in_deg, full_out_deg, nid, reverse=False):
+    """get_partition_ne_features(sub_g, g, reverse)[0] (train.py:125-135): the FULL graph's stored degrees of the sub-graph's
+    nodes (`nid` = sub_g.ndata['_ID']: MaskedGraph.nid, Cluster.nid), z-scored with the mean and unbiased std of THOSE nodes -
+    neither a slice of the full graph's z-scored table (different mean / std) nor the degrees recounted on the induced
+    sub-graph (different counts).  The strand-wise mask (train.py:311-313) and the METIS mini-batches (:339-346) both feed
+    the model this."""
+    nid = torch.as_tensor(nid).long()
+    cols = []
+    for d in ((full_out_deg, full_in_deg) if reverse else (full_in_deg, full_out_deg)):
+        d = torch.as_tensor(d).to(dtype=torch.float32)
+        d = d[nid.to(d.device)]
+        cols.append(((d - d.mean()) / d.std()).unsqueeze(1))
+    return torch.cat(cols, 1).contiguous()
 
 
 def edge_features(overlap_length, overlap_similarity):

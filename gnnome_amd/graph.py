@@ -43,6 +43,8 @@ def views_for(graph, device):
             # the edge count is re-checked where the object can tell it without building the edge list)
             count = getattr(graph, "num_edges", None)
             if count is None or hit.num_edges == int(count()):
+                if hit._bad is not None:   # a graph whose deferred range check failed stays refused on every later call
+                    raise IndexError(hit._bad)
                 return hit
     src, dst, n = edge_list(graph)
     src = src.to(device=device, dtype=torch.int32).contiguous()

@@ -81,7 +81,7 @@ class GraphViews:
     """In-edge / out-edge orderings of one edge list (see include/gnnome_hip.h, "graph views")."""
 
     __slots__ = ("num_nodes", "num_edges", "in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst", "device",
-                 "transposed", "_range", "__weakref__")
+                 "transposed", "_range", "_bad", "__weakref__")
 
     def __init__(self, src, dst, num_nodes, validate="now"):
         """validate = "now": endpoints are range-checked before anything is built (one host sync).  "lazy": no host sync -
@@ -94,7 +94,7 @@ class GraphViews:
         n, e = int(num_nodes), int(src.numel())
         if dst.numel() != e:
             raise ValueError("src and dst differ in length")
-        self._range = None
+        self._range, self._bad = None, None
         if e > 0 and validate:
             ext = torch.stack([torch.minimum(src.min(), dst.min()), torch.maximum(src.max(), dst.max())])
             self._range = (ext, n)
@@ -119,11 +119,15 @@ class GraphViews:
 
     def check_range(self):
         """Raise IndexError if an endpoint lay outside [0, N) (the deferred half of validate="lazy"; one host sync, once)."""
+        if self._bad is not None:      # sticky: views built from a clamped (= different) edge list never become usable
+            raise IndexError(self._bad)
         if self._range is not None:
-            (ext, n), self._range = self._range, None
+            ext, n = self._range
             lo, hi = (int(v) for v in ext.tolist())
             if lo < 0 or hi >= n:
-                raise IndexError(f"edge endpoint out of range [0,{n}): min {lo}, max {hi}")
+                self._bad = f"edge endpoint out of range [0,{n}): min {lo}, max {hi}"
+                raise IndexError(self._bad)
+            self._range = None
 
     def reversed(self):
         """Views of dgl.reverse(g, copy_ndata=True, copy_edata=True) - endpoints swapped, edge ids and edge

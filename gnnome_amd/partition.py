@@ -7,8 +7,10 @@ provided here is the ROLE of that call, not METIS: a deterministic, balanced reg
 the cluster + halo subgraphs the training loop iterates over.
 
     parts = cluster_partition(graph, num_clusters, extra_cached_hops=1)     # dict: part id -> ClusterGraph
+    in_deg, out_deg = features.stored_degrees(graph)                          # the FULL graph's degrees (ndata['in_deg'/'out_deg'])
     for sub in parts.values():
-        x = x_full[sub.nid];  e = e_full[sub.eid];  y = y_full[sub.eid]      # get_partition_ne_features, train.py:125-135
+        x = features.partition_degree_features(in_deg, out_deg, sub.nid)       # get_partition_ne_features, train.py:125-135:
+        e = e_full[sub.eid];  y = y_full[sub.eid]                              #   z-scored over the PARTITION's nodes
         logits = model(sub, x, e)                                           # get_bce_loss_partition, train.py:148-156
 
 Differences from the reference, stated plainly:

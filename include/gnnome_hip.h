@@ -46,13 +46,21 @@ const char* gnnome_last_error(void);
 
 /* Measurement knobs, not part of the reference-facing contract: select kernel variants for A/B runs
  * (tools/kernel_ab.py).  0 is always the shipped default.
- *   key 0 edge gate variant : 1 tile-per-workgroup, 2 persistent, 3 persistent + software-pipelined,
- *                             4 staged (row-wise gathers / stores through LDS), 5 wave-specialised (= default
- *                             for H in {64,128} with the affine norm)
+ *   key 0 edge gate variant : 0 shipped default (H = 128: plane-form bf16x6 edge-tile kernel k_edge_gate_pl, layer 0
+ *                             k_edge_gate_enc16; H = 64: k_edge_gate_bf; H = 256: the wave-specialised / streaming kernel),
+ *                             1 tile-per-workgroup kernel, 5 exact-fp32 MFMA wave-specialised kernel (LDS-counter
+ *                             hand-over), 6 the same with workgroup barriers, 7 = 0 spelled out (plane form),
+ *                             8 second-generation bf16x6 kernel k_edge_gate_bf at H = 128 (split in the compute waves)
  *   key 1 edge gate ablation: bit mask, timing only (results are wrong): 1 no node gathers, 2 no stores,
  *                             4 no e loads, 8 no MFMA, 16 nontemporal e loads / e' stores
- *   key 2 linear variant    : 1 tile kernel
- *   key 3 gate tile order   : 1 contiguous run per workgroup (default: interleaved, XCD-contiguous) */
+ *   key 2 linear variant    : 0 shipped default (bf16x6 streaming kernel, A-stationary from 400k rows), 1 tile kernel,
+ *                             2 exact-fp32 weight-stationary, 3 bf16x6 with A staged through LDS, 4 8-wave workgroups,
+ *                             5 2-wave workgroups, 6 A-stationary at every size
+ *   key 3 gate tile order   : 1 contiguous run per workgroup (default: interleaved, XCD-contiguous)
+ *   key 4 gate experiment   : kernel-specific measurement switch (H = 256 streaming gate: tiles per workgroup piece)
+ *   key 5 aggregation LDS   : KiB of unused dynamic LDS per workgroup (caps the resident workgroups per CU)
+ *   key 6 aggregation hubs  : 1 = hub split path off
+ *   key 7 aggregation variant: 1-5 items in flight / occupancy A/B, 6 unsplit item loop */
 int gnnome_set_tuning(int key, int value);
 
 /* Measurement only: when set to a device buffer of 256 x 8 int64, every launch of the edge-tile kernel leaves, per

@@ -118,6 +118,34 @@ def test_partitioned_training_on_a_mostly_cut_graph_matches_oracle_autograd(tmp_
             assert torch.allclose(o["buffers"][k].float(), b.float(), atol=1e-5, rtol=1e-4), k
 
 
+def test_partitioned_training_step_at_h256_matches_oracle_autograd(tmp_path):
+    """The width of BASELINE configs[3] / [4]: at H = 256 the host takes the UNFUSED backward sequence (bn_bwd_apply with the
+    mean terms on the owned rows only + a separate data-gradient GEMM) - here on the checker backend over gloo, the GPU twin
+    is tests/test_hip_partition.py::test_two_ranks_training_step_h256_matches_oracle_autograd."""
+    from oracle.symgated_oracle import OracleModel, bce_loss
+    from test_train_host import check_grads
+    n, e, hidden, layers = 300, 3000, 256, 2
+    gr = make_graph(n, e, seed=6, kind="banded")
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(hidden, num_layers=layers, seed=7)
+    om = OracleModel(2, 2, hidden, 16, layers, 64, "batch", dropout=0.0)
+    om.load_state_dict(sd)
+    om.train()
+    want = om((gr["src"], gr["dst"], n), x, gr["e"])
+    want_loss = bce_loss(want, gr["y"], gr["pos_weight"])
+    want_loss.backward()
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], y=gr["y"], pos_weight=gr["pos_weight"], hidden=hidden,
+                layers=layers, state_dict=sd, train=True)
+    outs = _run(2, case, tmp_path)
+    assert sum(o["n_score"] for o in outs) == e and sum(o["e_local"] for o in outs) > e
+    for o in outs:
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(want.detach().squeeze(-1))).abs().max().item() < 1e-4
+        assert abs(o["loss"].item() - want_loss.item()) < 1e-5
+        check_grads(o["grads"], {k: p.grad for k, p in om.named_parameters()}, rtol=2e-3)
+    for k in outs[0]["grads"]:
+        assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k
+
+
 def test_partitioned_layernorm_training_step_matches_reference_golden_g8(tmp_path):
     """normalization='layer': per-row statistics need no cross-rank reduction; the partial gradients of replicated
     edges still add up because the LayerNorm backward is linear in the incoming gradient."""

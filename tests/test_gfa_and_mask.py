@@ -136,8 +136,16 @@ def test_cluster_partition_with_halo():
     m.to(dev())
     sub = parts[3]
     from gnnome_amd import features
-    x_full = features.degree_features(gnnome_amd.graph.views_for((gr["src"], gr["dst"], n), dev()))
-    logits = m(sub, x_full[sub.nid], gr["e"].to(dev())[sub.eid])
+    # get_partition_ne_features (train.py:125-135): the FULL graph's degrees of the cluster's nodes, z-scored over the cluster
+    in_deg, out_deg = features.stored_degrees(gnnome_amd.graph.views_for((gr["src"], gr["dst"], n), dev()))
+    x = features.partition_degree_features(in_deg, out_deg, sub.nid)
+    full_in = torch.bincount(dst, minlength=n).float()[sub.nid.cpu()]
+    full_out = torch.bincount(src, minlength=n).float()[sub.nid.cpu()]
+    want_x = torch.stack([(full_in - full_in.mean()) / full_in.std(), (full_out - full_out.mean()) / full_out.std()], 1)
+    assert torch.allclose(x.cpu(), want_x, atol=1e-6)
+    rev_x = features.partition_degree_features(in_deg, out_deg, sub.nid, reverse=True)
+    assert torch.equal(rev_x[:, 0], x[:, 1]) and torch.equal(rev_x[:, 1], x[:, 0])
+    logits = m(sub, x, gr["e"].to(dev())[sub.eid])
     loss = bce_loss(logits.squeeze(-1), gr["y"].to(dev())[sub.eid], gr["pos_weight"].to(dev()))
     loss.backward()
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())

@@ -67,6 +67,32 @@ def test_graph_views_rejects_out_of_range():
     m = gnnome_amd.SymGatedGCNModel(2, 2, 64, 16, 2, 64, "batch").eval().to(dev())
     with pytest.raises(IndexError):
         m((torch.tensor([0, 9]), torch.tensor([1, 2]), 4), torch.randn(4, 2, device=dev()), torch.randn(2, 2, device=dev()))
+    with pytest.raises(IndexError):   # sticky: a second look at the same views raises again
+        lazy.check_range()
+
+    class Graph:   # a graph OBJECT is cached per identity: the refused views must not be served on the second call
+        def edges(self):
+            return torch.tensor([0, 9]), torch.tensor([1, 2])
+
+        def num_nodes(self):
+            return 4
+
+        def num_edges(self):
+            return 2
+
+    g = Graph()
+    x, e = torch.randn(4, 2, device=dev()), torch.randn(2, 2, device=dev())
+    for _ in range(2):
+        with pytest.raises(IndexError):
+            m(g, x, e)
+    # every entry point that builds views from a caller's graph checks them: layer-level API, scorer, degree features
+    from gnnome_amd import features
+    h, eh = torch.randn(4, 64, device=dev()), torch.randn(2, 64, device=dev())
+    with torch.no_grad():
+        for call in (lambda: m.gnn.convs[0](g, h, eh), lambda: m.predictor(g, h, eh), lambda: features.degree_features(Graph()),
+                     lambda: m.gnn.convs[0]((torch.tensor([0, 9]), torch.tensor([1, 2]), 4), h, eh)):
+            with pytest.raises(IndexError):
+                call()
 
 
 # ------------------------------------------------------------------------------------ kernels
@@ -556,12 +582,19 @@ def test_layer_and_predictor_level_api(shipped_weights):
     with torch.no_grad():
         wh, we = om._layer_forward(om.gnn.convs[0], g["src"].long(), g["dst"].long(), g["num_nodes"], h, e)
         ws = om._score(g["src"].long(), g["dst"].long(), h, e)
-    gh, ge = m.gnn.convs[0](graph, h.to(dev()), e.to(dev()))
-    gs = m.predictor(graph, h.to(dev()), e.to(dev()))
+    # the layer-level entries are inference-only: with grad enabled and trainable parameters they REFUSE (their outputs would
+    # carry no autograd history and a fine-tune through them would train nothing) - ADVICE r2
+    with pytest.raises(NotImplementedError):
+        m.gnn.convs[0](graph, h.to(dev()), e.to(dev()))
+    with pytest.raises(NotImplementedError):
+        m.predictor(graph, h.to(dev()), e.to(dev()))
+    with torch.no_grad():
+        gh, ge = m.gnn.convs[0](graph, h.to(dev()), e.to(dev()))
+        gs = m.predictor(graph, h.to(dev()), e.to(dev()))
+        ph, pe = m.gnn(graph, h.to(dev()), e.to(dev()))  # processor loop, layers/processor.py:16-19
     _assert_close(gh, wh.double(), tol=2e-5)
     _assert_close(ge, we.double(), tol=2e-5)
     _assert_close(gs, ws.double(), tol=2e-5)
-    ph, pe = m.gnn(graph, h.to(dev()), e.to(dev()))  # processor loop, layers/processor.py:16-19
     assert ph.shape == h.shape and pe.shape == e.shape and torch.isfinite(ph).all()
 
 

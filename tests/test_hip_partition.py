@@ -128,3 +128,64 @@ def test_two_ranks_h256_banded_200k_edges_equals_one_rank(tmp_path):
         assert (torch.sigmoid(o["logits"]) - torch.sigmoid(want)).abs().max().item() < 1e-5
     assert torch.equal(outs[0]["logits"], outs[1]["logits"])
     assert all(o["n_local"] > o["n_own"] for o in outs) and all(sum(o["send"]) < 0.2 * n for o in outs)   # banded: thin halo
+
+
+def _oracle_step(gr, x, n, sd, hidden, layers=8):
+    from oracle.symgated_oracle import OracleModel, bce_loss
+    om = OracleModel(2, 2, hidden, 16, layers, 64, "batch", dropout=0.0)
+    om.load_state_dict(sd)
+    om.train()
+    want = om((gr["src"], gr["dst"], n), x, gr["e"])
+    loss = bce_loss(want, gr["y"], gr["pos_weight"])
+    loss.backward()
+    return om, want.detach().squeeze(-1), loss.detach()
+
+
+def _check_partitioned_step(outs, om, want, want_loss, rtol):
+    want_g = {k: p.grad for k, p in om.named_parameters()}
+    for o in outs:
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(want)).abs().max().item() < 1e-4
+        assert abs(o["loss"].item() - want_loss.item()) < 1e-5
+        check_grads(o["grads"], want_g, rtol=rtol)
+        num = sum(((o["grads"][k] - want_g[k]).double() ** 2).sum().item() for k in want_g) ** 0.5
+        den = sum((want_g[k].double() ** 2).sum().item() for k in want_g) ** 0.5
+        assert num / den < 3e-3, f"relative L2 error of the full gradient {num / den:.2e}"
+        for k, b in om.named_buffers():
+            assert torch.allclose(o["buffers"][k].float(), b.float(), atol=1e-5, rtol=1e-4), k
+    for k in outs[0]["grads"]:   # every rank holds the same bits: per-rank optimizers stay in step
+        assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k
+
+
+def test_two_ranks_training_step_h256_matches_oracle_autograd(tmp_path):
+    """BASELINE configs[4]'s combination: a destination-range partition, train mode, H = 256 - two ranks sharing the GPU
+    against the oracle's autograd on the UNPARTITIONED graph (the single-rank twin is
+    test_hip_training.py::test_training_step_matches_oracle_autograd[256]; same graph, same weights, same tolerances)."""
+    from gnnome_amd.synth import make_graph
+    from oracle.symgated_oracle import degree_features
+    n, e, hidden = 3000, 30_000, 256
+    gr = make_graph(n, e, seed=9)
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(hidden, seed=3)
+    om, want, want_loss = _oracle_step(gr, x, n, sd, hidden)
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], y=gr["y"], pos_weight=gr["pos_weight"], hidden=hidden, layers=8,
+                state_dict=sd, train=True, device="cuda")
+    outs = _run(2, case, tmp_path)
+    assert sum(o["n_score"] for o in outs) == e and all(o["n_local"] > o["n_own"] for o in outs)
+    _check_partitioned_step(outs, om, want, want_loss, rtol=3e-2)
+
+
+def test_two_ranks_training_step_h128_on_a_mostly_cut_graph(tmp_path):
+    """uniform graph at H = 128: half of the edges live on both ranks, so most gradient rows are assembled from partial sums
+    (the fused BatchNorm-backward + data-gradient pass with rows_once < rows, halo gradients both ways)."""
+    from gnnome_amd.synth import make_graph
+    from oracle.symgated_oracle import degree_features
+    n, e, hidden = 3000, 30_000, 128
+    gr = make_graph(n, e, seed=11, kind="uniform")
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(hidden, seed=5)
+    om, want, want_loss = _oracle_step(gr, x, n, sd, hidden)
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], y=gr["y"], pos_weight=gr["pos_weight"], hidden=hidden, layers=8,
+                state_dict=sd, train=True, device="cuda")
+    outs = _run(2, case, tmp_path)
+    assert sum(o["e_local"] for o in outs) > 1.45 * e      # > 45 % of the edges are replicated (cut)
+    _check_partitioned_step(outs, om, want, want_loss, rtol=3e-2)
