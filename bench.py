@@ -259,6 +259,20 @@ def _spawn_ranks(gpus):
     return subprocess.call(cmd, env=env)
 
 
+def _stdout_to_stderr(fn):
+    """Run fn with file descriptor 1 pointing at stderr: gloo's C++ side prints its connection banner to stdout, and this
+    program's stdout carries exactly ONE JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return fn()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def _time_steps(step, steps, warmup, barrier):
     for _ in range(warmup):
         step()
@@ -482,7 +496,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         gloo_transport = args.one_gpu_gloo
         if gloo_transport:
-            dist.init_process_group("gloo")
+            _stdout_to_stderr(lambda: dist.init_process_group("gloo"))
         else:
             try:   # RCCL over xGMI; a collective is run right away so that a broken transport shows here, on every rank alike
                 dist.init_process_group("nccl", device_id=dev)
@@ -496,7 +510,7 @@ def main():
                     dist.destroy_process_group()
                 except Exception:  # noqa: BLE001
                     pass
-                dist.init_process_group("gloo")
+                _stdout_to_stderr(lambda: dist.init_process_group("gloo"))
                 gloo_transport = True
 
     extras = {}

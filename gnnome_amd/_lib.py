@@ -73,10 +73,12 @@ SIGNATURES = {
     "gnnome_greedy_walks_workspace_bytes": [_l, _i, ctypes.POINTER(_sz)],
     "gnnome_greedy_walks": [_p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_mark_walk_visited": [_p, _p, _p, _l, _p, _p],
+    "gnnome_overlap_workspace_bytes": [ctypes.POINTER(_sz)],
+    "gnnome_overlap_edit_distance": [_p, _p, _l, _p, _i, _p, _p, _p, _l, _p, _p, _p, _sz, _p],
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

@@ -22,27 +22,21 @@ What is reproduced from the reference, line by line:
     what `src`, `dst` and every per-edge array here follow.  (DGL itself cannot be run here; this is its documented
     behaviour, pinned in tests/golden/g10_gfa.pt through networkx's own iteration order - see make_golden_gfa.py.)
 
-overlap_similarity (:101-117, :372-376) is 1 - editDistance(suffix, prefix) / overlap_length, computed by the
-third-party aligner edlib on the read sequences.  edlib is not part of this image and is not re-implemented: the
-similarity is taken from the GFA where the `L` line carries it as an `SI:f:` tag (our own extension, written by
-`write_similarity_tags`), from a caller-supplied `similarity(src_seq, dst_seq, overlap_length)` callable, from edlib if
-it happens to be importable - and is None otherwise (hyperparameters.py:17 `use_similarities`; a model trained with
-them needs them)."""
+overlap_similarity (:101-117, :372-376) is 1 - editDistance(suffix, prefix) / overlap_length, which the reference gets
+from the third-party aligner edlib on the CPU.  Here (`similarity="auto"`, the default) it comes, in this order, from
+`SI:f:` tags on the `L` lines where the GFA carries them (our own extension, written by `write_similarity_tags`), else - for
+a GFA with sequences - from the device kernel gnnome_overlap_edit_distance (gnnome_amd/overlap.py: exact edit distances,
+one wavefront per overlap; needs the MI355X, there is no CPU version in this package); a caller-supplied
+`similarity(src_seq, dst_seq, overlap_length)` callable overrides both.  A GFA without sequences and without tags gives
+None - never a guess (hyperparameters.py:17 `use_similarities`: a model trained with them needs them)."""
 import gzip
 import re
 
 import torch
 
 _HIFIASM_ID = re.compile(r"(.*):\d-\d*")
-_COMPLEMENT = str.maketrans("ACGTacgtNn", "TGCAtgcaNn")
-
-
-def _edlib_similarity():
-    try:
-        import edlib
-    except Exception:  # noqa: BLE001
-        return None
-    return lambda a, b, ol: 1 - edlib.align(a[-ol:], b[:ol])["editDistance"] / ol   # graph_parser.py:110-111
+# Bio.Seq.reverse_complement's table (IUPAC ambiguity codes, both cases) - the same one gnnome_amd/overlap.py hands the device
+_COMPLEMENT = str.maketrans("ACGTMRWSYKVHDBXNUacgtmrwsykvhdbxnu", "TGCAKYWSRMBDHVXNAtgcakywsrmbdhvxna")
 
 
 def read_gfa(path, similarity="auto", keep_sequences=False):
@@ -52,7 +46,7 @@ def read_gfa(path, similarity="auto", keep_sequences=False):
     with opener(path, "rt") as f:
         lines = f.readlines()
     read_to_node, node_to_read, read_to_node2 = {}, {}, {}
-    read_lengths, read_seqs = [], {}
+    read_lengths, read_seqs, forward = [], {}, []
     adj = []                      # adj[u]: dict v -> (overlap_length, similarity tag or None); insertion-ordered like networkx's adjacency
     no_seqs = False
     node_idx, i = 0, 0
@@ -68,7 +62,9 @@ def read_gfa(path, similarity="auto", keep_sequences=False):
             real, virt = node_idx, node_idx + 1
             read_to_node[rid] = (real, virt)
             node_to_read[real] = node_to_read[virt] = rid
-            if keep_sequences or similarity not in (None, False):
+            if similarity not in (None, False):
+                forward.append(sequence)
+            if keep_sequences or callable(similarity):
                 read_seqs[real] = sequence
                 read_seqs[virt] = sequence.translate(_COMPLEMENT)[::-1]
             ln = int(length[5:])
@@ -130,11 +126,12 @@ def read_gfa(path, similarity="auto", keep_sequences=False):
            "read_seqs": read_seqs if keep_sequences else None, "overlap_similarity": None}
     if sims and all(s is not None for s in sims):
         out["overlap_similarity"] = torch.tensor(sims, dtype=torch.float32)
-    elif similarity not in (None, False) and not no_seqs:
-        fn = similarity if callable(similarity) else _edlib_similarity()
-        if fn is not None:
-            out["overlap_similarity"] = torch.tensor([fn(read_seqs[u], read_seqs[v], ol) if ol > 0 else 0.5 for u, v, ol in zip(src, dst, ols)],
-                                                     dtype=torch.float32)
+    elif callable(similarity) and not no_seqs:
+        out["overlap_similarity"] = torch.tensor([similarity(read_seqs[u], read_seqs[v], ol) if ol > 0 else 0.5 for u, v, ol in zip(src, dst, ols)],
+                                                 dtype=torch.float32)
+    elif similarity not in (None, False) and not no_seqs and (similarity == "device" or torch.cuda.is_available()):
+        from .overlap import overlap_similarity   # the MI355X kernel; raises without the library or a device ("device" insists)
+        out["overlap_similarity"] = overlap_similarity(forward, src_t, dst_t, ol_t).cpu()
     return out
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 6
+#define GNNOME_ABI_VERSION 7
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -421,6 +421,26 @@ int gnnome_greedy_walks(const int32_t* succ_ptr, const int32_t* succ_nbr, const 
  * succs[ss] & preds[dd] and their mates (inference.py:313-318, :334). */
 int gnnome_mark_walk_visited(const int32_t* succ_ptr, const int32_t* succ_nbr, const int32_t* walk, int64_t walk_len,
                              uint8_t* visited, void* stream);
+
+/* ---- overlap similarity -------------------------------------------------------------------------------
+ * Replaces graph_parser.py:101-117 (calculate_similarities): for every edge
+ *     edit_distance = edlib.align(read_seqs[src][-ol:], read_seqs[dst][:ol])['editDistance']     (edlib defaults: global / NW)
+ *     overlap_similarity = 1 - edit_distance / ol        (0.5 where ol == 0)
+ * with read_seqs[2r] = read r, read_seqs[2r+1] = its reverse complement (:365).  The distance is the exact Levenshtein
+ * distance (Myers' bit-vector programme, one wavefront per overlap: csrc/overlap_similarity.hip).
+ *   reads       uint8[total]   the reads as the S lines give them, concatenated (forward strand only)
+ *   read_off    int64[R+1]     offsets of read r in `reads`
+ *   symtab      uint8[512]     [b] = index of byte b in the caller's alphabet, [256+b] = index of complement(b)
+ *                              (the table Bio.Seq.reverse_complement applies); num_symbols <= 32
+ *   src, dst    int32[E]       node ids (graph.edges()); overlap_length int32[E]
+ *   dist_out    int32[E]       edit distances; entries the kernels cannot serve keep the caller's fill value (fill with -1):
+ *                              a query longer than 65 536 bases, or an alphabet whose match masks exceed LDS at that length
+ *   similarity_out float32[E]  (NULL: skip) 1 - dist / ol evaluated in double precision like the reference's Python floats */
+int gnnome_overlap_workspace_bytes(size_t* bytes_host);
+int gnnome_overlap_edit_distance(const uint8_t* reads, const int64_t* read_off, int64_t num_reads, const uint8_t* symtab,
+                                 int num_symbols, const int32_t* src, const int32_t* dst, const int32_t* overlap_length,
+                                 int64_t num_edges, int32_t* dist_out, float* similarity_out, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /* ---- bf16 STORAGE of two training activations (activation_storage = "bf16", BASELINE configs[2]) ------------------------------
  * The reference trains in fp32 throughout; as an OPTION the pre-normalisation gate output xe[E,H] (written once, read three

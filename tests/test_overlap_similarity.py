@@ -1,0 +1,159 @@
+"""overlap_similarity (graph_parser.py:101-117): the oracle against the reference's own values (golden
+G10), and the device kernel gnnome_overlap_edit_distance against the oracle - bit-exact integer distances."""
+import os
+import random
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from gnnome_amd import gfa
+from oracle import overlap_oracle
+
+
+def _py_edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def _forward_reads(g):
+    return [g["read_seqs"][2 * r] for r in range(g["num_nodes"] // 2)]
+
+
+def test_oracle_edit_distance_is_the_wagner_fischer_value():
+    rng = random.Random(0)
+    for _ in range(60):
+        a = "".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 70)))
+        b = "".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 70)))
+        assert overlap_oracle.edit_distance(a, b) == _py_edit_distance(a, b)
+    assert overlap_oracle.edit_distance("", "") == 0 and overlap_oracle.edit_distance("ACGT", "") == 4
+
+
+def test_oracle_matches_the_reference_parsers_similarities_golden_g10():
+    """The values calculate_similarities itself produced (make_golden_gfa.py: the reference's parser text, run as is)."""
+    for c in load_golden("g10_gfa.pt")["cases"]:
+        g = gfa.read_gfa(os.path.join(GOLDEN, c["gfa"]), similarity=None, keep_sequences=True)
+        if not g["read_seqs"] or any(s == "*" for s in g["read_seqs"].values()):
+            continue
+        _, sims = overlap_oracle.calculate_similarities(_forward_reads(g), g["src"], g["dst"], g["overlap_length"])
+        assert torch.allclose(torch.tensor(sims, dtype=torch.float64), c["overlap_similarity"].double(), atol=1e-7), c["name"]
+        # the reverse-complement strand is the reference's: read_seqs[2r+1] of this package's reader and of the oracle agree
+        assert overlap_oracle.read_seqs(_forward_reads(g)) == g["read_seqs"]
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def _mutate(rng, s, rate, alphabet="ACGT"):
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < rate / 3:
+            continue                      # deletion
+        if r < 2 * rate / 3:
+            out.append(rng.choice(alphabet))   # substitution
+            continue
+        if r < rate:
+            out.append(rng.choice(alphabet))   # insertion
+        out.append(ch)
+    return "".join(out)
+
+
+def _overlapping_reads(rng, lengths, rate, alphabet="ACGT"):
+    """reads laid out on one genome so that consecutive reads truly overlap (distance ~ rate * overlap), plus noise."""
+    genome = "".join(rng.choice(alphabet) for _ in range(sum(lengths)))
+    reads, pos = [], 0
+    for ln in lengths:
+        reads.append(_mutate(rng, genome[pos:pos + ln], rate, alphabet))
+        pos += max(1, ln // 3)
+    return reads
+
+
+@pytest.mark.gpu
+def test_device_edit_distance_equals_the_oracle_on_every_orientation_and_block_boundary():
+    from gnnome_amd import overlap
+    rng = random.Random(1)
+    lengths = [31, 32, 33, 64, 65, 100, 500, 2047, 2048, 2049, 2100, 4095, 4097, 6200, 7000, 9000, 12_289, 40, 1, 3000]
+    reads = _overlapping_reads(rng, lengths, 0.05)
+    R = len(reads)
+    src, dst, ol = [], [], []
+    for r in range(R - 1):
+        for su in (0, 1):
+            for sv in (0, 1):
+                src.append(2 * r + su)
+                dst.append(2 * (r + 1) + sv)
+                ol.append(rng.randrange(1, min(len(reads[r]), len(reads[r + 1])) + 1))
+    # overlaps longer than one or both reads (read_src[-ol:] / read_dst[:ol] are then the whole reads), zero-length, exact
+    # block boundaries, a read against itself and against its own reverse complement
+    extra = [(0, 2, 10_000), (5, 12, 100_000), (26, 28, 2048), (27, 29, 2047), (18, 21, 4096), (6, 6, 64), (6, 7, 64), (36, 2, 0), (36, 37, 1)]
+    for u, v, L in extra:
+        src.append(u), dst.append(v), ol.append(L)
+    want_d, want_s = overlap_oracle.calculate_similarities(reads, src, dst, ol)
+    d, s = overlap.edit_distances(reads, src, dst, ol, device=dev())
+    assert d.cpu().tolist() == want_d
+    assert torch.allclose(s.cpu().double(), torch.tensor(want_s, dtype=torch.float64), atol=1e-7)
+    assert (s.cpu()[torch.tensor(ol) == 0] == 0.5).all()
+
+
+@pytest.mark.gpu
+def test_device_edit_distance_long_overlaps_and_wide_alphabets():
+    """Every blocks-per-lane class up to 32 (65 536 query rows), ambiguity codes and lower case through the complement table."""
+    from gnnome_amd import overlap
+    rng = random.Random(2)
+    alphabet = "ACGTNacgtnRYKMSW"
+    big = "".join(rng.choice("ACGT") for _ in range(66_000))
+    reads = [big[:20_000], _mutate(rng, big[:20_000], 0.02), big[:40_000], _mutate(rng, big[30_000:40_000], 0.1),
+             big[:60_000], _mutate(rng, big[58_000:60_000], 0.03), big,
+             "".join(rng.choice(alphabet) for _ in range(3000)), "".join(rng.choice(alphabet) for _ in range(2500))]
+    cases = [(0, 2, 20_000), (3, 1, 20_000),          # 20k x 20k, both strands                         (class 12)
+             (4, 6, 10_000), (7, 5, 10_000),           # 40k-base read's suffix against a 10k read        (class 6)
+             (4, 6, 40_000),                           # query 40 000 rows against the whole 10k read      (class 24)
+             (8, 10, 60_000), (11, 9, 2000),           # query 60 000 rows against a 2k read               (class 32)
+             (14, 16, 3000), (17, 15, 2500), (15, 17, 2999), (14, 15, 3000)]   # 16-symbol alphabet, rc through the IUPAC table
+    src, dst, ol = (list(t) for t in zip(*cases))
+    want_d, want_s = overlap_oracle.calculate_similarities(reads, src, dst, ol)
+    d, s = overlap.edit_distances(reads, src, dst, ol, device=dev())
+    assert d.cpu().tolist() == want_d
+    assert torch.allclose(s.cpu().double(), torch.tensor(want_s, dtype=torch.float64), atol=1e-7)
+    with pytest.raises(ValueError):                    # 66 000 query rows: refused, not guessed
+        overlap.edit_distances(reads, [12], [0], [66_000], device=dev())
+
+
+@pytest.mark.gpu
+def test_gfa_reader_computes_similarities_on_the_device_golden_g10():
+    """read_gfa(path) with no tags, no callable and no edlib returns the reference parser's similarities."""
+    seen = 0
+    for c in load_golden("g10_gfa.pt")["cases"]:
+        path = os.path.join(GOLDEN, c["gfa"])
+        with open(path) as f:
+            if any(line.startswith("S") and line.split()[2] == "*" for line in f):
+                continue
+        g = gfa.read_gfa(path)
+        assert g["overlap_similarity"] is not None and g["overlap_similarity"].dtype == torch.float32
+        assert torch.allclose(g["overlap_similarity"].double(), c["overlap_similarity"].double(), atol=1e-7), c["name"]
+        seen += 1
+    assert seen >= 1
+
+
+@pytest.mark.gpu
+def test_many_overlaps_of_assembly_shape_against_the_oracle():
+    """A few thousand overlaps of HiFi-like shape (0.5 % divergence, lengths 1-6 kb) - all classes' ticket loops interleaved."""
+    from gnnome_amd import overlap
+    rng = random.Random(3)
+    lengths = [rng.randrange(1500, 6500) for _ in range(150)]
+    reads = _overlapping_reads(rng, lengths, 0.005)
+    src, dst, ol = [], [], []
+    for r in range(len(reads) - 3):
+        for t in (1, 2, 3):
+            su, sv = rng.randrange(2), rng.randrange(2)
+            src.append(2 * r + su), dst.append(2 * (r + t) + sv)
+            ol.append(rng.randrange(500, min(len(reads[r]), len(reads[r + t]))))
+    want_d, _ = overlap_oracle.calculate_similarities(reads, src, dst, ol)
+    d, _ = overlap.edit_distances(reads, src, dst, ol, device=dev())
+    assert d.cpu().tolist() == want_d
