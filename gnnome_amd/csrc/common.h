@@ -11,7 +11,7 @@ namespace gnnome {
 void set_error(const char* fmt, ...);
 
 // Tuning knobs (gnnome_set_tuning): variant selection for A/B measurements; 0 = the shipped default.
-enum { kTuneGateVariant = 0, kTuneGateAblation = 1, kTuneLinearVariant = 2, kTuneGateTileOrder = 3, kTuneGateExperiment = 4, kTuneAggLdsKiB = 5, kTuneAggHubs = 6, kTuneAggVariant = 7, kTuneCount = 8 };
+enum { kTuneGateVariant = 0, kTuneGateAblation = 1, kTuneLinearVariant = 2, kTuneGateTileOrder = 3, kTuneGateExperiment = 4, kTuneAggLdsKiB = 5, kTuneAggHubs = 6, kTuneAggVariant = 7, kTuneRefVariant = 8, kTuneCount = 16 };
 int tuning(int key);
 
 // Layer 0 only: the e tile is not loaded but COMPUTED by the load waves from the raw edge features,
@@ -65,6 +65,16 @@ int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* 
 // edge-tile kernel (edge_gate.hip) in accumulate mode; linear.hip routes the backward's [E,H] dgrad here.
 int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, float* C, hipStream_t s);
 int stream_linear_acc_256(const float* A, int64_t M, const float* W, int ldw, float* C, hipStream_t s);   // edge_gate_stream.hip
+// H = 256 in the wave-specialised plane form (edge_gate_pl256.hip): modes 0 (gate), 1 (raw gate, optional statistics), 2 (C += A W^T)
+int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s);
+int gate_pl256_stats_rows();
+long long* gate_profile_buffer();   // gnnome_debug_gate_profile's buffer (edge_gate_bf.hip), NULL in normal use
+// reference-order kernels on the fp32 matrix cores (reference_order_mfma.hip); K / hidden in {64, 128}
+int linear_refm_launch(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias, int Nout, float* C, int ldc,
+                       hipStream_t s);
+int gate_refm_launch(int hidden, bool with_enc, const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
+                     const int32_t* ss, const int32_t* sd, const float* W3, int ldw, const float* b3, const float* scale, const float* shift,
+                     const GateEnc& enc, hipStream_t s);
 
 #define GN_REQUIRE(cond, ...)                 \
     do {                                      \

@@ -621,9 +621,16 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
     }
     // H = 256 with separate input and output buffers: the streaming kernel (its column chunks run in different workgroups,
     // so it cannot update e in place; in place - or LayerNorm - goes to the 128-edge tile kernel below)
-    if (hidden == 256 && norm_kind == GNNOME_NORM_AFFINE && variant == 0 && e_in != e_out && ld_node % 4 == 0 &&
-        ((uintptr_t)e_out % 16 == 0))
-        return gate_stream_launch(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);
+    if (hidden == 256 && norm_kind == GNNOME_NORM_AFFINE && (variant == 0 || variant == 9) && e_in != e_out && ld_node % 4 == 0 &&
+        ((uintptr_t)e_out % 16 == 0)) {
+        if (variant == 0 && rows16) {   // the shipped default: wave-specialised plane form, W3 in registers (edge_gate_pl256.hip)
+            GateBfArgs a = {};
+            a.e_in = e_in; a.e_out = e_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
+            a.srt_dst = srt_dst; a.W3 = W3; a.ldw = ldw; a.scale = norm_scale; a.shift = norm_shift;
+            return gate_pl256_launch(0, a, s);
+        }
+        return gate_stream_launch(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);   // variant 9: round 2's streaming kernel
+    }
     switch (hidden) {
         case 64: return launch_gate<2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);
         case 128: return launch_gate<4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);
@@ -642,6 +649,13 @@ extern "C" int gnnome_edge_gate_raw_f32(const float* e_in, float* x_out, int64_t
     GN_REQUIRE(ld_node >= hidden && ldw >= hidden && ldw % 4 == 0, "edge_gate_raw: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0), "edge_gate_raw: e_in and W3 must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (hidden == 256 && tuning(kTuneGateVariant) == 0 && ld_node % 4 == 0 && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0) &&
+        ((uintptr_t)x_out % 16 == 0)) {   // the plane form's raw mode (no statistics)
+        GateBfArgs a = {};
+        a.e_in = e_in; a.e_out = x_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
+        a.srt_dst = srt_dst; a.W3 = W3; a.ldw = ldw;
+        return gate_pl256_launch(1, a, s);
+    }
     switch (hidden) {
         case 64: return launch_gate<2>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, 2, nullptr, nullptr, s);
         case 128: return launch_gate<4>(e_in, x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, 2, nullptr, nullptr, s);
@@ -652,7 +666,11 @@ extern "C" int gnnome_edge_gate_raw_f32(const float* e_in, float* x_out, int64_t
 
 extern "C" int gnnome_edge_gate_raw_stats_rows(int hidden, int* rows_host) {
     using namespace gnnome;
-    GN_REQUIRE(rows_host && (hidden == 64 || hidden == 128), "edge_gate_raw_stats_rows: hidden=%d not in {64,128}", hidden);
+    GN_REQUIRE(rows_host && (hidden == 64 || hidden == 128 || hidden == 256), "edge_gate_raw_stats_rows: hidden=%d not in {64,128,256}", hidden);
+    if (hidden == 256) {   // the plane form at H = 256: one row per load / store wave
+        *rows_host = gate_pl256_stats_rows();
+        return GNNOME_OK;
+    }
     // bf16x6 kernel (variant 0): one row per load/store wave (8 per workgroup); exact-fp32 kernel: one per row block
     *rows_host = (tuning(kTuneGateVariant) == 0 || tuning(kTuneGateVariant) == 8) ? kNumCUs * 8 : kNumCUs * (hidden == 128 ? 1 : 2);
     return GNNOME_OK;
@@ -665,11 +683,17 @@ static int raw_stats_impl(const float* e_in, void* x_out, int64_t num_edges, int
     GN_REQUIRE(num_edges > 0, "edge_gate_raw_stats: needs at least one edge");
     GN_REQUIRE(e_in && x_out && x_out != (const void*)e_in && B1h && B2h && srt_src && srt_dst && W3 && center && stats_partial,
                "edge_gate_raw_stats: bad pointers");
-    GN_REQUIRE(hidden == 64 || hidden == 128, "edge_gate_raw_stats: hidden=%d not in {64,128}", hidden);
+    GN_REQUIRE(hidden == 64 || hidden == 128 || (hidden == 256 && !x16), "edge_gate_raw_stats: hidden=%d not in {64,128,256 (fp32)}", hidden);
     GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ldw >= hidden && ldw % 4 == 0, "edge_gate_raw_stats: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0) && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0),
                "edge_gate_raw_stats: 16-byte alignment required");
     hipStream_t s = (hipStream_t)stream;
+    if (hidden == 256) {
+        GateBfArgs a = {};
+        a.e_in = e_in; a.e_out = (float*)x_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
+        a.srt_dst = srt_dst; a.W3 = W3; a.ldw = ldw; a.scale = center; a.stats = stats_partial;
+        return gate_pl256_launch(1, a, s);
+    }
     if (tuning(kTuneGateVariant) == 0 || tuning(kTuneGateVariant) == 8 || x16) {
         GateBfArgs a = {};
         a.e_in = e_in; a.e_out = (float*)x_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;

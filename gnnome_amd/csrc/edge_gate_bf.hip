@@ -412,6 +412,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_bf(GateBfArgs a) {
 }
 
 static long long* g_gate_prof = nullptr;
+long long* gate_profile_buffer() { return g_gate_prof; }
 
 // ---------------------------------------------------------------------------------------------------
 // Third generation, H = 128, mode 0 (the inference gate): the A operand is split ONCE per tile, by the load waves.
@@ -1035,4 +1036,23 @@ extern "C" int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows
                                        const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
                                        const float* W, int ldw, uint16_t* dxe, void* stream) {
     return bn_bwd_dgrad_impl(C, X, rows, rows_once, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, true);
+}
+
+// The same pass at hidden = 256, OUT OF PLACE: two workgroups (column halves) read whole rows of C while each writes its half, so the
+// updated rows go to C_out != C_in (edge_gate_pl256.hip, mode 3).
+extern "C" int gnnome_bn_bwd_dgrad_out_f32(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
+                                           const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
+                                           const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(rows >= 0 && hidden == 256, "bn_bwd_dgrad_out: hidden=%d (256 only; 64 / 128 update C in place: gnnome_bn_bwd_dgrad_f32)", hidden);
+    GN_REQUIRE(rows_once >= 0 && rows_once <= rows, "bn_bwd_dgrad_out: rows_once=%lld outside [0, rows]", (long long)rows_once);
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(C_in && C_out && C_out != C_in && X && scale && shift && a && c1 && c2 && mean && rstd && W && dxe && dxe != C_out && dxe != C_in &&
+                   ldw >= hidden && ldw % 4 == 0, "bn_bwd_dgrad_out: bad arguments");
+    GN_REQUIRE(((uintptr_t)C_in % 16 == 0) && ((uintptr_t)C_out % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)dxe % 16 == 0) &&
+                   ((uintptr_t)W % 16 == 0), "bn_bwd_dgrad_out: tensors must be 16-byte aligned");
+    GateBfArgs g = {};
+    g.e_in = X; g.e_out = C_out; g.E = rows; g.B1h = C_in; g.ldn = hidden; g.W3 = W; g.ldw = ldw;
+    g.bnb = GateBnBwd{a, c1, c2, mean, rstd, scale, shift, dxe, rows_once};
+    return gate_pl256_launch(3, g, (hipStream_t)stream);
 }

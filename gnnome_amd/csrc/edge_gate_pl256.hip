@@ -1,0 +1,367 @@
+// Edge-tile kernel for H = 256 in the wave-specialised PLANE form (round 3; k_edge_gate_stream stays as variant 9).
+//
+// k_edge_gate_stream keeps one 64-column chunk of W3 as bf16 planes in LDS (101 KB) and lets every wave fetch, split and
+// multiply its own rows: four workgroups read and split every e row, and a wave's costs - gathers, operand split, MFMAs,
+// residual, stores - add up serially at two waves per SIMD (2.36 ms per launch at 2.5M edges against
+// ~1.3 ms of matrix-core / HBM time).  This kernel is k_edge_gate_pl's structure at K = 256:
+//   * W3 lives in REGISTERS: a compute wave holds the three bf16 planes of its 32 output columns for all 256 k
+//     (16 steps x 3 planes x 4 VGPRs = 192 of the 256 registers a wave has at two waves per SIMD); four compute waves = 128
+//     columns, so TWO workgroups (column halves, same XCD, same tile sequence) cover a row - the e rows are read and split
+//     twice, not four times;
+//   * four load / store waves in two groups: a group fetches a tile's 32 full e rows, splits them ONCE into three bf16 planes
+//     in LDS (50 KB per slot, two slots), and - while the compute waves run 96 MFMAs per tile each, pure matrix work - fetches
+//     the next tile; it then applies the epilogue (G = B1h[src] + B2h[dst], normalise, relu, residual) to the x tile the
+//     compute waves left in a separate 17 KB LDS buffer, with 16-byte row pieces;
+//   * hand-over through two LDS counters per slot (full: planes ready, 2 bumps; done: x ready, 4 bumps); the x tile has its
+//     own buffer, so the compute waves never wait for one another and no third or fourth counter is needed (cf. k_edge_gate_pl).
+// Per tile and compute wave: 16 x 6 MFMAs = 3072 matrix-pipe cycles; per CU and tile-half 16 + 16 KB of HBM traffic - the two
+// bounds coincide at ~10 B / cycle / CU, which is what this chip streams.
+// e_out must not alias e_in (the two column halves of a row are written by different workgroups while both read whole rows).
+#include "common.h"
+
+namespace gnnome {
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void flag_wait(unsigned addr, unsigned want) {
+    unsigned v, spins = 0;
+    for (;;) {
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        if (__builtin_amdgcn_readfirstlane(v) >= want) break;
+        if (++spins > (1u << 26)) __builtin_trap();   // a lost hand-over must end the launch, not hang the queue
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void flag_bump(unsigned addr, int lane) {
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+}
+// exact three-way bf16 split (see edge_gate_bf.hip): eight floats -> one MFMA operand per plane
+__device__ __forceinline__ void split8(const f32x4 lo4, const f32x4 hi4, uint4& p1, uint4& p2, uint4& p3) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? lo4[j] : hi4[j - 4];
+        h[j] = __float_as_uint(x) & 0xFFFF0000u;
+        const float r = x - __uint_as_float(h[j]);
+        m[j] = __float_as_uint(r) & 0xFFFF0000u;
+        l[j] = __float_as_uint(r - __uint_as_float(m[j]));
+    }
+    p1 = make_uint4(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u),
+                    __builtin_amdgcn_perm(h[5], h[4], 0x07060302u), __builtin_amdgcn_perm(h[7], h[6], 0x07060302u));
+    p2 = make_uint4(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u),
+                    __builtin_amdgcn_perm(m[5], m[4], 0x07060302u), __builtin_amdgcn_perm(m[7], m[6], 0x07060302u));
+    p3 = make_uint4(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u),
+                    __builtin_amdgcn_perm(l[5], l[4], 0x07060302u), __builtin_amdgcn_perm(l[7], l[6], 0x07060302u));
+}
+__device__ __forceinline__ void split4(const f32x4 x, uint2& p1, uint2& p2, uint2& p3) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = __float_as_uint(x[j]) & 0xFFFF0000u;
+        const float r = x[j] - __uint_as_float(h[j]);
+        m[j] = __float_as_uint(r) & 0xFFFF0000u;
+        l[j] = __float_as_uint(r - __uint_as_float(m[j]));
+    }
+    p1 = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+    p2 = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+    p3 = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+}
+__device__ __forceinline__ bf16x8_t as_bf8(const uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+// MODE 0: e' = relu((e W3^T + B1h[src] + B2h[dst]) * scale + shift) + e    (gated_gcn_full.py:97,104-110)
+// MODE 1: xe = e W3^T + B1h[src] + B2h[dst] and its shifted column sums (training forward; a.scale = the centres, a.stats out)
+// MODE 2: C += A W^T (A = e_in, C = e_out = the rows at B1h; the backward's d e_in = d e' + dxe W3)
+// MODE 3: MODE 2 with A = BatchNorm-backward(old C rows, xe rows at e_in) computed by the load waves and written to bnb.a_out
+template <int MODE>
+__global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
+    constexpr int H = 256, HC = 128, TM = 32, KS = H / 16, PLD = 2 * H + 16, PLANE = TM * PLD, SLOTB = 3 * PLANE, LDK = HC + 4, XT = TM * LDK;
+    constexpr int NPF = 16, NPE = 8;   // pieces per lane: fetch mapping (whole rows), epilogue mapping (this workgroup's column half)
+    __shared__ __attribute__((aligned(16))) unsigned char ring[2 * SLOTB];
+    __shared__ __attribute__((aligned(16))) float xt[2 * XT];
+    __shared__ __attribute__((aligned(16))) float norm_lds[(MODE == 3 ? 7 : 2) * (MODE == 3 ? H : HC)];
+    __shared__ unsigned flags[4];   // full[2], done[2]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned full0 = lds_addr(&flags[0]), done0 = lds_addr(&flags[2]);
+    // pairs of workgroups on one XCD (blocks b and b + 8 share b % 8) take the two column halves of the same tiles; in round r
+    // the chip works on one contiguous window of tiles, each XCD on a contiguous part of it
+    const int per_xcd = gridDim.x / kXcds, xcd = blockIdx.x % kXcds, idx = blockIdx.x / kXcds;
+    const int hh = idx & 1, first = xcd * (per_xcd / 2) + (idx >> 1), stride = gridDim.x / 2;
+    const int n = first < a.num_tiles ? (a.num_tiles - first + stride - 1) / stride : 0;
+    if (n <= 0) return;
+    auto tile_of = [&](int r) { return first + r * stride; };
+    auto tile_valid = [&](int r) { return (int)min((int64_t)TM, a.E - (int64_t)tile_of(r) * TM); };
+    const int colh = HC * hh;   // first global column of this workgroup's half
+    if (tid < 4) flags[tid] = 0;
+    if (MODE == 3) {
+        for (int i = tid; i < 7 * H; i += 512) {
+            const int q = i / H, c = i % H;
+            const float* src = q == 0 ? a.bnb.a : q == 1 ? a.bnb.c1 : q == 2 ? a.bnb.c2 : q == 3 ? a.bnb.mean : q == 4 ? a.bnb.rstd : q == 5 ? a.bnb.scale : a.bnb.shift;
+            norm_lds[i] = src[c];
+        }
+    } else if (MODE < 2) {
+        for (int i = tid; i < 2 * HC; i += 512) {
+            const int q = i / HC, c = i % HC;
+            norm_lds[i] = q == 0 ? (a.scale ? a.scale[colh + c] : 0.f) : (MODE == 0 ? a.shift[colh + c] : 0.f);   // MODE 1: the centres (NULL: none)
+        }
+    }
+    __syncthreads();
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ compute wave: 32 rows x 32 columns, all of K in registers
+        const int cl = lane & 31, half = lane >> 5, col = colh + 32 * wave + cl;
+        // k numbering of the matrix-core steps = k_edge_gate_stream's (so that the two kernels give the same bits): step 4 b + q of the
+        // lower / upper half wave takes k in [64 b + 32 half + 8 q, + 8)
+        uint4 w1[KS], w2[KS], w3[KS];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+            const float* wp = a.W3 + (int64_t)col * a.ldw + 64 * (q >> 2) + 32 * half + 8 * (q & 3);
+            split8(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4), w1[q], w2[q], w3[q]);
+        }
+        auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
+        const int lane_x = 4 * half * LDK + 32 * wave + cl;   // accumulator element r sits in tile row 4 half + crow(r)
+        long long t_wait = 0, t_loop = 0, t_x = 0, t0 = 0, t1 = 0;
+        const long long c_begin = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+        const long long r_begin = a.prof ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+        for (int i = 0; i < n; ++i) {
+            const int slot = i & 1;
+            const unsigned use = (unsigned)(i >> 1) + 1u;
+            if (a.prof) t0 = __builtin_readcyclecounter();
+            flag_wait(full0 + 4 * slot, 2u * use);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_wait += t1 - t0; t0 = t1; }
+            const unsigned char* ap = ring + slot * SLOTB + cl * PLD + 64 * half;   // + 128 b + 16 q (step 4 b + q), + PLANE * plane
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            uint4 c1 = *reinterpret_cast<const uint4*>(ap), c2 = *reinterpret_cast<const uint4*>(ap + PLANE),
+                  c3 = *reinterpret_cast<const uint4*>(ap + 2 * PLANE);
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                const int qn = q + 1 < KS ? q + 1 : q, on = 128 * (qn >> 2) + 16 * (qn & 3);
+                const uint4 n1 = *reinterpret_cast<const uint4*>(ap + on), n2 = *reinterpret_cast<const uint4*>(ap + on + PLANE),
+                            n3 = *reinterpret_cast<const uint4*>(ap + on + 2 * PLANE);
+                // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(c3), as_bf8(w1[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(c1), as_bf8(w3[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(c2), as_bf8(w2[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(c2), as_bf8(w1[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(c1), as_bf8(w2[q]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(c1), as_bf8(w1[q]), acc, 0, 0, 0);
+                c1 = n1;
+                c2 = n2;
+                c3 = n3;
+            }
+            if (a.prof) { asm volatile("" ::"v"(acc[0])); t1 = __builtin_readcyclecounter(); t_loop += t1 - t0; t0 = t1; }
+            // the x buffer of this slot is free: its group bumped `full` for this tile only after reading the previous x out of it
+            float* X = xt + slot * XT + lane_x;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[crow(r) * LDK] = acc[r];
+            flag_bump(done0 + 4 * slot, lane);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_x += t1 - t0; }
+        }
+        if (a.prof && wave == 0 && lane == 0) {   // the record layout of k_edge_gate_pl (tools/gate_phase_profile.py)
+            long long* o = a.prof + (int64_t)blockIdx.x * 8;
+            o[0] = t_wait; o[1] = 0; o[2] = t_loop; o[3] = t_x; o[4] = n;
+            o[5] = (long long)__builtin_readcyclecounter() - c_begin;
+            o[6] = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
+        }
+    } else {
+        // ------------------------------------------------------------------ load / store wave
+        const int group = (wave - 4) >> 1;
+        const int gl = ((wave - 4) & 1) * 64 + lane;        // lane index inside the group, 0..127
+        const int c4f = gl & 63, r0f = gl >> 6;             // fetch mapping: whole rows, rows r0f + 2 p
+        const int c4e = gl & 31, r0e = gl >> 5;             // epilogue mapping: this half's 128 columns, rows r0e + 4 p
+        f32x4 av[NPF], ek[NPE], gk[NPE], g1[NPE], g2[NPE];
+        f32x4 dyv[MODE == 3 ? NPF : 1];   // MODE 3: the old C rows (dy), whole rows like av
+        int si[NPE], di[NPE];
+        auto fetch_rows = [&](int r) {   // the A operand rows (MODE 3: the xe rows and the old C rows) - whole rows
+            const int64_t row0 = (int64_t)tile_of(r) * TM;
+            const int valid = tile_valid(r);
+#pragma unroll
+            for (int p = 0; p < NPF; ++p) {   // rows past the end of the list read the last valid row (never stored)
+                const int64_t row = row0 + min(r0f + 2 * p, valid - 1);
+                av[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + 4 * c4f);
+                if (MODE == 3) dyv[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * H + 4 * c4f);
+            }
+        };
+        auto fetch_index = [&](int r) {
+            if (MODE >= 2) return;
+            const int64_t row0 = (int64_t)tile_of(r) * TM;
+            const int valid = tile_valid(r);
+#pragma unroll
+            for (int p = 0; p < NPE; ++p) {
+                const int64_t row = row0 + min(r0e + 4 * p, valid - 1);
+                si[p] = a.srt_src[row];
+                di[p] = a.srt_dst[row];
+            }
+        };
+        auto fetch_side = [&](int r) {   // this half's pieces: gathers, residual / old C rows
+            const int64_t row0 = (int64_t)tile_of(r) * TM;
+            const int valid = tile_valid(r);
+#pragma unroll
+            for (int p = 0; p < NPE; ++p) {
+                const int64_t row = row0 + min(r0e + 4 * p, valid - 1);
+                if (MODE == 0) ek[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + colh + 4 * c4e);
+                if (MODE < 2) {
+                    g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + (int64_t)si[p] * a.ldn + colh + 4 * c4e);
+                    g2[p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)di[p] * a.ldn + colh + 4 * c4e);
+                } else {
+                    g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * H + colh + 4 * c4e);   // the old rows of C
+                }
+            }
+        };
+        if (group < n) {
+            fetch_index(group);
+            fetch_rows(group);
+            fetch_side(group);
+        }
+        unsigned char* S = ring + group * SLOTB;
+        const float* Xs = xt + group * XT;
+        f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1;   // MODE 1: this lane's running shifted sums of its four columns
+        long long t_top = 0, t_split = 0, t_gk = 0, t_done = 0, t_epi = 0, t0 = 0, t1 = 0;
+        for (int r = group; r < n; r += 2) {
+            const unsigned use = (unsigned)(r >> 1) + 1u;
+            if (a.prof) { t0 = __builtin_readcyclecounter(); asm volatile("" ::"v"(av[0][0]), "v"(av[NPF - 1][0])); t1 = __builtin_readcyclecounter(); t_top += t1 - t0; t0 = t1; }
+            // the planes slot is free: this group waited for `done` of its previous tile (all four compute waves had read them)
+            if (MODE == 3) {
+                // A = BatchNorm backward of (dy = the old C rows, x = the xe rows) for this lane's four columns of whole rows; this
+                // workgroup writes its own column half of it out as dxe
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4f), k1 = *reinterpret_cast<const f32x4*>(norm_lds + H + 4 * c4f);
+                const f32x4 k2 = *reinterpret_cast<const f32x4*>(norm_lds + 2 * H + 4 * c4f), km = *reinterpret_cast<const f32x4*>(norm_lds + 3 * H + 4 * c4f);
+                const f32x4 kr = *reinterpret_cast<const f32x4*>(norm_lds + 4 * H + 4 * c4f), ks = *reinterpret_cast<const f32x4*>(norm_lds + 5 * H + 4 * c4f);
+                const f32x4 kh = *reinterpret_cast<const f32x4*>(norm_lds + 6 * H + 4 * c4f);
+                const int valid3 = tile_valid(r);
+                const int64_t once3 = a.bnb.n_once - (int64_t)tile_of(r) * TM;   // rows of this tile that get the mean terms
+                float* aout = a.bnb.a_out + (int64_t)tile_of(r) * TM * H + 4 * c4f;
+                const bool mine = (c4f >> 5) == hh;
+#pragma unroll
+                for (int p = 0; p < NPF; ++p) {
+                    const int row = r0f + 2 * p;
+                    const float on = row < once3 ? 1.f : 0.f;
+                    f32x4 t;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gm = (av[p][j] * ks[j] + kh[j] > 0.f) ? dyv[p][j] : 0.f;
+                        t[j] = ka[j] * (gm - on * (k1[j] + (av[p][j] - km[j]) * kr[j] * k2[j]));
+                    }
+                    av[p] = t;
+                    if (mine && row < valid3) *reinterpret_cast<f32x4*>(aout + (int64_t)row * H) = t;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NPF; ++p) {
+                uint2 p1, p2, p3;
+                split4(av[p], p1, p2, p3);
+                unsigned char* d = S + (r0f + 2 * p) * PLD + 8 * c4f;
+                *reinterpret_cast<uint2*>(d) = p1;
+                *reinterpret_cast<uint2*>(d + PLANE) = p2;
+                *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+            }
+            flag_bump(full0 + 4 * group, lane);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_split += t1 - t0; t0 = t1; }
+#pragma unroll
+            for (int p = 0; p < NPE; ++p) {
+                gk[p] = MODE >= 2 ? g1[p] : g1[p] + g2[p];
+                asm volatile("" : "+v"(gk[p]));   // summed HERE: the wait for the gathers must not sink behind the epilogue's stores
+            }
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_gk += t1 - t0; t0 = t1; }
+            if (r + 2 < n) {
+                fetch_index(r + 2);
+                fetch_rows(r + 2);
+            }
+            flag_wait(done0 + 4 * group, 4u * use);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_done += t1 - t0; t0 = t1; }
+            const int valid = tile_valid(r);
+            const f32x4 sc4 = MODE < 2 ? *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4e) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 sh4 = MODE == 0 ? *reinterpret_cast<const f32x4*>(norm_lds + HC + 4 * c4e) : f32x4{0.f, 0.f, 0.f, 0.f};
+            float* out = a.e_out + (int64_t)tile_of(r) * TM * H + colh + 4 * c4e;
+#pragma unroll
+            for (int pb = 0; pb < NPE; pb += 4) {
+                f32x4 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(Xs + (r0e + 4 * (pb + u)) * LDK + 4 * c4e);
+                asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = pb + u, row = r0e + 4 * p;
+                    f32x4 y;
+                    if (MODE == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + gk[p][j]) * sc4[j] + sh4[j], 0.f) + ek[p][j];
+                    } else {
+                        y = x[u] + gk[p];
+                    }
+                    if (row < valid) {
+                        if (MODE == 1) {
+                            const f32x4 dlt = y - sc4;
+                            st1 += dlt;
+                            st2 += dlt * dlt;
+                        }
+                        *reinterpret_cast<f32x4*>(out + (int64_t)row * H) = y;
+                    }
+                }
+            }
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_epi += t1 - t0; }
+            if (r + 2 < n) fetch_side(r + 2);
+        }
+        if (a.prof && wave == 4 && lane == 0) {   // the first load wave's phases, after the 256 compute-wave records
+            long long* o = a.prof + (int64_t)(256 + blockIdx.x) * 8;
+            o[0] = t_top; o[1] = t_split; o[2] = t_done; o[3] = t_epi; o[4] = (n + 1) / 2; o[5] = t_gk;
+        }
+        if (MODE == 1 && a.stats != nullptr) {
+            // lanes l and l + 32 hold different rows of the same four columns: fold them, then every load wave leaves one row of partial
+            // sums for its 128 columns
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                st1[j] += __shfl_xor(st1[j], 32);
+                st2[j] += __shfl_xor(st2[j], 32);
+            }
+            if (lane < 32) {   // one row of [2 H] per load wave: (sum | sum of squares) of (x - centre), this half's columns, the rest zero
+                float* dst = a.stats + ((int64_t)blockIdx.x * 4 + (wave - 4)) * 2 * H;
+                *reinterpret_cast<f32x4*>(dst + colh + 4 * c4e) = st1;
+                *reinterpret_cast<f32x4*>(dst + H + colh + 4 * c4e) = st2;
+            }
+        }
+    }
+}
+
+int grid_pl256() {
+    int g = persistent_grid();
+    g -= g % 16;   // pairs of workgroups per XCD
+    return g < 16 ? 16 : g;
+}
+
+template <int MODE>
+int launch_pl256(const GateBfArgs& args, hipStream_t s) {
+    GateBfArgs a = args;
+    const int64_t tiles = (a.E + 31) / 32;
+    GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
+    GN_REQUIRE(a.e_out != a.e_in, "edge_gate (H = 256): the output must not alias the input rows");
+    GN_REQUIRE(MODE != 3 || a.e_out != a.B1h, "bn_bwd_dgrad (H = 256): C_out must not alias C_in (two workgroups read whole rows of it)");
+    a.num_tiles = (int)tiles;
+    a.prof = gate_profile_buffer();
+    if (MODE == 1 && a.stats != nullptr) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * (size_t)grid_pl256() * 4 * 2 * 256, s));   // idle waves / the other half
+    hipLaunchKernelGGL((k_edge_gate_pl256<MODE>), dim3(grid_pl256()), dim3(512), 0, s, a);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+}  // namespace
+
+// mode 0: the gate; mode 1: the raw gate (+ shifted column sums into a.stats[gate_pl256_stats_rows()][2 * 256] when given, a.scale = centres);
+// mode 2: C += A W^T (a.e_in = A, a.e_out = a.B1h = C); mode 3: C_out = C_in + BatchNormBackward(C_in, X) W^T with dxe written out
+// (a.e_in = X, a.B1h = C_in, a.e_out = C_out != C_in, a.bnb)
+int gate_pl256_stats_rows() { return grid_pl256() * 4; }
+int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s) {
+    if (mode == 0) return launch_pl256<0>(a, s);
+    if (mode == 1) return launch_pl256<1>(a, s);
+    if (mode == 2) return launch_pl256<2>(a, s);
+    if (mode == 3) return launch_pl256<3>(a, s);
+    set_error("edge-tile kernel (H = 256): mode %d is not built", mode);
+    return GNNOME_EINVAL;
+}
+
+}  // namespace gnnome

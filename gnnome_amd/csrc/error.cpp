@@ -15,8 +15,9 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-static int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-int tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key] : 0; }
+constexpr int kTuneSlots = 16;   // common.h: kTuneCount
+static int g_tuning[kTuneSlots] = {0};
+int tuning(int key) { return (key >= 0 && key < kTuneSlots) ? g_tuning[key] : 0; }
 
 int persistent_grid() {
     static int cached[64] = {0};
@@ -33,7 +34,7 @@ int persistent_grid() {
 }  // namespace gnnome
 
 extern "C" int gnnome_set_tuning(int key, int value) {
-    if (key < 0 || key >= 8) {
+    if (key < 0 || key >= gnnome::kTuneSlots) {
         gnnome::set_error("set_tuning: key %d out of range", key);
         return GNNOME_EINVAL;
     }

@@ -693,7 +693,12 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
         return ws_linear_acc(A, M, K, W, ldw, C, s);
     if (tuning(kTuneLinearVariant) == 0 && accumulate && bias == nullptr && K == 256 && Nout == 256 && lda == 256 && ldc == 256 && aligned_out &&
         ldw % 4 == 0 && M >= 32768 && A != C)   // the same at H = 256: the streaming edge-tile kernel (4.67 -> see DESIGN 4b)
-        return stream_linear_acc_256(A, M, W, ldw, C, s);
+    {
+        if (tuning(kTuneGateVariant) == 9) return stream_linear_acc_256(A, M, W, ldw, C, s);   // round 2's streaming kernel
+        GateBfArgs g = {};
+        g.e_in = A; g.e_out = C; g.E = M; g.B1h = C; g.ldn = 256; g.W3 = W; g.ldw = ldw;
+        return gate_pl256_launch(2, g, s);   // the plane form as a residual GEMM (edge_gate_pl256.hip)
+    }
     if (tuning(kTuneLinearVariant) == 0 && ldw % 4 == 0 && Nout % 64 == 0 && Nout >= 256 && M >= kAStationaryRows) {
         // many row blocks and a wide output: A loaded and split once per row block (measured at Nout = 5H = 640: 1.08 against
         // 1.24 ms at M = 1M; at M = 100k - three row blocks per CU - the streaming kernel below wins, 0.120 against 0.133 ms)

@@ -374,7 +374,7 @@ def edge_gate_raw_stats(e, B1h, B2h, views, W3, rows_stats=None):
     a fixed order.  Shapes the fused kernel does not take (H = 256; statistics over a prefix of the rows, as on a
     partition) go through edge_gate_raw + batch_stats."""
     H, E = e.shape[1], e.shape[0]
-    fused = H in (64, 128) and E > 0 and (rows_stats is None or rows_stats == E) and B1h.stride(0) % 4 == 0 and \
+    fused = H in (64, 128, 256) and E > 0 and (rows_stats is None or rows_stats == E) and B1h.stride(0) % 4 == 0 and \
         B1h.data_ptr() % 16 == 0 and B2h.data_ptr() % 16 == 0
     if not fused:
         xe = edge_gate_raw(e, B1h, B2h, views, W3)
@@ -487,8 +487,10 @@ def edge_gate_raw_moments(e, B1h, B2h, views, W3, storage=torch.float32):
     return out, (sums[:H], sums[H:], center, E)
 
 
-def can_fuse_gate_moments(e, B1h, B2h):
-    return (e.shape[1] in (64, 128) and e.shape[0] > 0 and B1h.stride(0) % 4 == 0 and B1h.data_ptr() % 16 == 0 and
+def can_fuse_gate_moments(e, B1h, B2h, storage=torch.float32):
+    """H = 256 (round 3: the plane form's raw mode, edge_gate_pl256.hip) with fp32 storage only."""
+    widths = (64, 128, 256) if storage == torch.float32 else (64, 128)
+    return (e.shape[1] in widths and e.shape[0] > 0 and B1h.stride(0) % 4 == 0 and B1h.data_ptr() % 16 == 0 and
             B2h.data_ptr() % 16 == 0)
 
 
@@ -675,8 +677,10 @@ def agg_edge_bwd(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de):
     return de
 
 
-def can_fuse_bn_bwd_dgrad(de, W):
-    return de.shape[1] in (64, 128) and de.shape[0] > 0 and de.is_contiguous() and W.stride(0) % 4 == 0
+def can_fuse_bn_bwd_dgrad(de, W, xe=None):
+    """H = 256 (round 3, edge_gate_pl256.hip mode 3): fp32 storage only, and the update is out of place under the hood."""
+    widths = (64, 128, 256) if xe is None or xe.dtype == torch.float32 else (64, 128)
+    return de.shape[1] in widths and de.shape[0] > 0 and de.is_contiguous() and W.stride(0) % 4 == 0
 
 
 def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None):
@@ -687,6 +691,16 @@ def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None
     Wt, ldw = _rows(Wt, "bn_bwd_dgrad.W")
     dxe = torch.empty_like(xe)     # dxe is stored the way xe is
     once = de.shape[0] if rows_once is None else int(rows_once)
+    if de.shape[1] == 256:
+        # two workgroups per row at this width: the kernel writes the updated rows to a fresh buffer, which then BECOMES de
+        # (Tensor.set_: same tensor object, new storage - the caller's `de` is updated "in place" as at the other widths)
+        if x16:
+            raise TypeError("bn_bwd_dgrad: bf16 activation storage is not built at hidden = 256")
+        out = torch.empty_like(de)
+        _call("gnnome_bn_bwd_dgrad_out_f32", de.device, _ptr(de), _ptr(out), _ptr(xe), de.shape[0], once, 256, _ptr(scale), _ptr(shift), _ptr(a),
+              _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))
+        de.set_(out)
+        return dxe
     _call("gnnome_bn_bwd_dgrad_x16" if x16 else "gnnome_bn_bwd_dgrad_f32", de.device, _ptr(de), _ptr(xe), de.shape[0], once, de.shape[1], _ptr(scale), _ptr(shift),
           _ptr(a), _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))
     return dxe

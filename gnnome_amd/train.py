@@ -176,7 +176,7 @@ class _TrainStep(torch.autograd.Function):
                 xe = ops.edge_gate_raw(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight))
                 e_new = ops.ln_relu_res(xe, d(conv.bn_e.weight), d(conv.bn_e.bias), e)
             else:
-                if _can_fuse_bn(sh, conv.bn_e) and ops.can_fuse_gate_moments(e, blk(P, "B1"), blk(P, "B2")):
+                if _can_fuse_bn(sh, conv.bn_e) and ops.can_fuse_gate_moments(e, blk(P, "B1"), blk(P, "B2"), storage):
                     xe, mom = ops.edge_gate_raw_moments(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight), storage=storage)
                     mean_e, rstd_e, sc_e, sh_e = _bn_train_fused(sh, conv.bn_e, mom, updates=2)
                 elif storage != torch.float32:
@@ -301,7 +301,7 @@ class _TrainStep(torch.autograd.Function):
                 _, g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = ops.ln_bwd(de, s["xe"], d(conv.bn_e.weight), d(conv.bn_e.bias), out=dxe)
             else:
                 W3t = d(conv.B_3.weight).t().contiguous()
-                if hasattr(ops, "bn_bwd_dgrad") and ops.can_fuse_bn_bwd_dgrad(de, W3t):
+                if hasattr(ops, "bn_bwd_dgrad") and ops.can_fuse_bn_bwd_dgrad(de, W3t, s["xe"]):
                     # BatchNorm backward and d e_in = d e' + dxe W3 in one pass over the edges (dxe computed by the load waves)
                     g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"], c1, c2 = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
                                                                                    sh.e_global, e_own, None, stats=stats_e, apply=False)

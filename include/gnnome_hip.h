@@ -60,7 +60,9 @@ const char* gnnome_last_error(void);
  *   key 4 gate experiment   : kernel-specific measurement switch (H = 256 streaming gate: tiles per workgroup piece)
  *   key 5 aggregation LDS   : KiB of unused dynamic LDS per workgroup (caps the resident workgroups per CU)
  *   key 6 aggregation hubs  : 1 = hub split path off
- *   key 7 aggregation variant: 1-5 items in flight / occupancy A/B, 6 unsplit item loop */
+ *   key 7 aggregation variant: 1-5 items in flight / occupancy A/B, 6 unsplit item loop
+ *   key 8 reference-order kernels: 0 the fp32 matrix cores (v_mfma_f32_32x32x2_f32 as a k-ascending fma chain), 1 the
+ *                             scalar-fed VALU chains of round 2 (same bits) */
 int gnnome_set_tuning(int key, int value);
 
 /* Measurement only: when set to a device buffer of 256 x 8 int64, every launch of the edge-tile kernel leaves, per
@@ -374,6 +376,11 @@ int gnnome_edge_loss_f32(const float* logits, const float* logits_rev, const flo
 int gnnome_bn_bwd_dgrad_f32(float* C, const float* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift,
                             const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
                             const float* W, int ldw, float* dxe, void* stream);
+/* the same at hidden = 256, OUT OF PLACE (C_out != C_in): there two workgroups - one per column half - read whole rows of C,
+ * so the updated rows cannot overwrite them: C_out = C_in + dxe W^T. */
+int gnnome_bn_bwd_dgrad_out_f32(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
+                                const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
+                                const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream);
 
 /* gnnome_agg_edge_bwd_f32 with the BatchNorm-backward statistics of its result gathered in the same pass:
  *   de[p,:] += s(1-s)(...)   as above, then   s1[c] = sum_p de[p,c] m,  s2[c] = sum_p de[p,c] m (xe[p,c] - mean[c]),

@@ -201,7 +201,7 @@ def edge_gate_raw_moments(e, B1h, B2h, views, W3, storage=torch.float32):
     return xe, batch_moments(xe.float())
 
 
-def can_fuse_gate_moments(e, B1h, B2h):
+def can_fuse_gate_moments(e, B1h, B2h, storage=None):
     return e.shape[0] > 0
 
 
@@ -351,7 +351,7 @@ def agg_edge_bwd_stats(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift,
     return de, s1, s2
 
 
-def can_fuse_bn_bwd_dgrad(de, W):
+def can_fuse_bn_bwd_dgrad(de, W, xe=None):
     return de.shape[0] > 0
 
 

@@ -238,14 +238,30 @@ def test_h256_streaming_gate_in_pieces_equals_one_launch():
     d = {k: v.to(dev()) for k, v in t.items()}
     args = (d["e"], d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], 0, d["scale"], d["shift"])
     try:
+        ops.set_tuning(0, 9)         # round 2's streaming kernel (the default at H = 256 is now the plane form, edge_gate_pl256.hip)
         ops.set_tuning(4, 1 << 20)   # one launch
         whole = ops.edge_gate(*args, out=torch.empty_like(d["e"]))
         ops.set_tuning(4, 3)
         pieces = ops.edge_gate(*args, out=torch.full_like(d["e"], float("nan")))
+        ops.set_tuning(4, 0)
+        stream_default = ops.edge_gate(*args, out=torch.empty_like(d["e"]))
     finally:
         ops.set_tuning(4, 0)
-    default = ops.edge_gate(*args, out=torch.empty_like(d["e"]))
-    assert torch.equal(pieces, whole) and torch.equal(default, whole)
+        ops.set_tuning(0, 0)
+    assert torch.equal(pieces, whole) and torch.equal(stream_default, whole)
+    # the wave-specialised plane form (W3 in registers, two workgroups per row) feeds the matrix cores the same k in the same order:
+    # the same bits as the streaming kernel, at a ragged 300k edges
+    default = ops.edge_gate(*args, out=torch.full_like(d["e"], float("nan")))
+    assert torch.equal(default, whole)
+    # ... and as a residual GEMM C += A W^T (the backward's d e_in = d e' + dxe W3 at H = 256)
+    A, C0 = d["e"], torch.randn_like(d["e"])
+    c_new = ops.linear(A, d["W3"], None, out=C0.clone(), accumulate=True)
+    try:
+        ops.set_tuning(0, 9)
+        c_old = ops.linear(A, d["W3"], None, out=C0.clone(), accumulate=True)
+    finally:
+        ops.set_tuning(0, 0)
+    assert torch.equal(c_new, c_old)
     want = cpu_ops.edge_gate(t["e"].double().clone(), t["P"][:, 3 * H:4 * H].double(), t["P"][:, 4 * H:].double(), cv, t["W3"].double(), 0,
                              t["scale"].double(), t["shift"].double())
     _assert_close(whole, want, scale=20.0)
@@ -759,6 +775,12 @@ def test_h256_configs3_properties(n, e):
     views = views_for(graph, dev())
     a = m(views, x, ef)
     assert a.shape == (e, 1) and torch.isfinite(a).all() and torch.equal(a, m(views, x, ef))
+    if e == 2_500_000:   # the whole forward on round 2's streaming gate (variant 9): the plane form gives the same bits at full size
+        try:
+            ops.set_tuning(0, 9)
+            assert torch.equal(a, m(views, x, ef))
+        finally:
+            ops.set_tuning(0, 0)
     b = _model(_swap_roles(sd, hidden), hidden)(views.reversed(), x, ef)
     assert _prob_diff(a, b) < PROB_TOL
     perm = torch.randperm(e, generator=torch.Generator().manual_seed(3)).to(dev())

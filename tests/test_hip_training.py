@@ -334,7 +334,7 @@ def test_training_step_is_bit_reproducible():
         assert torch.equal(runs[0][3][k], runs[1][3][k]), k
 
 
-@pytest.mark.parametrize("hidden,e", [(128, 50_001), (64, 7000), (128, 31)])
+@pytest.mark.parametrize("hidden,e", [(128, 50_001), (64, 7000), (128, 31), (256, 40_003), (256, 17)])   # 256: edge_gate_pl256.hip mode 3
 def test_fused_backward_kernels_equal_their_unfused_pairs(hidden, e):
     """gnnome_agg_edge_bwd_stats_f32 = agg_edge_bwd + bn_bwd_stats, gnnome_bn_bwd_dgrad_f32 = bn_bwd_apply + linear_acc: the
     fused passes against the two-pass forms they replace (same kernels' arithmetic, so tight tolerances)."""

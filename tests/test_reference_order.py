@@ -208,6 +208,39 @@ def test_edge_gate_ref_equals_the_reference_sequence(hidden, n, e):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hidden,e", [(64, 70_001), (128, 33_333), (64, 31)])
+def test_matrix_core_and_valu_reference_order_kernels_give_the_same_bits(hidden, e):
+    """Round 3: the chain runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 adds its two k terms as an fma chain, k0 first:
+    tools/mfma_order_probe.hip); round 2's scalar-fed VALU kernels are the same function - every bit equal, in place too."""
+    from gnnome_amd import ops
+    g = torch.Generator().manual_seed(e)
+    n = max(e // 9, 4)
+    src, dst = torch.randint(0, n, (e,), generator=g).int(), torch.randint(0, n, (e,), generator=g).int()
+    gv = ops.GraphViews(src.to(dev()), dst.to(dev()), n)
+    d = lambda t: t.to(dev())  # noqa: E731
+    A, W, b = 10 * torch.randn(n, hidden, generator=g), 0.3 * torch.randn(5 * hidden, hidden, generator=g), torch.randn(5 * hidden, generator=g)
+    W3, b3 = torch.randn(hidden, hidden, generator=g) / hidden ** 0.5, torch.randn(hidden, generator=g)
+    scale, shift = 40 * torch.rand(hidden, generator=g), torch.randn(hidden, generator=g)
+    e0, e_raw = 30 * torch.randn(e, hidden, generator=g), torch.randn(e, 2, generator=g)
+    enc = tuple(d(t) for t in (torch.randn(16, 2, generator=g), torch.randn(16, generator=g), torch.randn(hidden, 16, generator=g),
+                               torch.randn(hidden, generator=g)))
+    out = {}
+    try:
+        for variant in (0, 1):
+            ops.set_tuning(8, variant)
+            P = ops.linear_ref(d(A), d(W), d(b))
+            in_place = d(e0).clone()
+            ops.edge_gate_ref(in_place, P[:, 3 * hidden:4 * hidden], P[:, 4 * hidden:], gv, d(W3), d(b3), d(scale), d(shift))
+            fresh = ops.edge_gate_ref(None, P[:, 3 * hidden:4 * hidden], P[:, 4 * hidden:], gv, d(W3), d(b3), d(scale), d(shift),
+                                      raw_edges=(d(e_raw), enc))
+            out[variant] = (P.cpu(), in_place.cpu(), fresh.cpu())
+    finally:
+        ops.set_tuning(8, 0)
+    for a, c in zip(out[0], out[1]):
+        assert torch.equal(a, c)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["banded", "uniform"])
 def test_ecoli_sized_graph_shipped_weights(shipped_weights, kind):
     """SURVEY.md 8d's substitute for BASELINE configs[0]: the one configuration where two correct fp32 evaluations of

@@ -57,7 +57,12 @@ span_c, span_r = p[:, 5].mean().item(), p[:, 6].mean().item()
 print(f"  loop span per workgroup: {span_c:.0f} shader cycles in {span_r / 100.0:.1f} us (100 MHz counter) -> shader clock {span_c / (span_r / 100.0) / 1e3:.2f} GHz; "
       f"accounted {total * tiles / 256 / span_c:.0%} of the span")
 print(f"  {'sum':28s} {total:8.0f} cycles / tile   -> {total * tiles / 256 / (ms * 1e-3) / 1e9:.2f} GHz if the wave were busy for the whole launch")
-if a.variant == 7 and lw[:, 4].sum().item() > 0:
+if H == 256 and lw[:, 4].sum().item() > 0:   # k_edge_gate_pl256: two load groups, the first load wave's view of the tiles IT handles (one in two)
+    t = lw[:, 4].sum().item()
+    print("  first load wave, cycles per tile it handles (one in two): "
+          + ", ".join(f"{nm} {lw[:, k].sum().item() / t:.0f}" for k, nm in [(0, "fetch arrival"), (1, "split + plane stores"), (5, "gathers arrive (G sum)"),
+                                                                            (2, "next fetch issue + wait for compute"), (3, "epilogue + stores")]))
+elif a.variant == 7 and lw[:, 4].sum().item() > 0:
     t = lw[:, 4].sum().item()
     print("  first load wave, cycles per tile IT handles (one in four): "
           + ", ".join(f"{nm} {lw[:, k].sum().item() / t:.0f}" for k, nm in enumerate(["fetch arrival", "split + plane stores", "wait for compute", "epilogue + stores"])))
