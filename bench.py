@@ -710,10 +710,10 @@ def main():
                     "bf16_mfma_frac": 6.0 * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK,
                 }
             else:
-                # H = 256: the streaming gate (bf16x6, one 64-column chunk of W3 per workgroup); 6 bf16 MFMAs per K=16 = 0.79 ms
-                # per launch at the 2.5 PF peak against 0.64 ms of HBM time for this shard: the matrix cores are the bound
+                # H = 256: the wave-specialised plane form (bf16x6, W3 in registers, two workgroups per row); 6 bf16 MFMAs per K=16
+                # = 0.79 ms per launch at the 2.5 PF peak against 0.64 ms of HBM time for this shard: the matrix cores are the bound
                 res["roofline"] = {
-                    "kernel": "k_edge_gate_stream (H=256: W3 chunks as bf16 planes in LDS, e rows streamed into MFMA fragments, bf16x6)",
+                    "kernel": "k_edge_gate_pl256 (H=256: W3 as bf16 planes in registers, e tiles split once into LDS planes by the load waves, bf16x6)",
                     "bound": "mfma", "achieved": 6.0 * gate_flops / (gate_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                     "frac": 6.0 * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK, "traffic": None,
                     "avg_launch_ms": gate_ms, "launches": gate_n, "bf16_flops_per_launch": 6.0 * gate_flops,

@@ -14,8 +14,15 @@
 //     compute waves left in a separate 17 KB LDS buffer, with 16-byte row pieces;
 //   * hand-over through two LDS counters per slot (full: planes ready, 2 bumps; done: x ready, 4 bumps); the x tile has its
 //     own buffer, so the compute waves never wait for one another and no third or fourth counter is needed (cf. k_edge_gate_pl).
-// Per tile and compute wave: 16 x 6 MFMAs = 3072 matrix-pipe cycles; per CU and tile-half 16 + 16 KB of HBM traffic - the two
-// bounds coincide at ~10 B / cycle / CU, which is what this chip streams.
+// Per tile and compute wave: 16 x 6 MFMAs = 3072 matrix-pipe cycles (3560 measured at the 1.9 GHz the chip holds under this load).
+// MEASURED (tools/gate_phase_profile.py --hidden 256, profiles/r03_gate256_phases.txt): 6330 cycles per tile, the compute waves
+// busy 56 % of the time.  What binds is the CU's in-order vector-memory queue: per tile-half the four load / store waves push
+// 32 KB of e rows + 16 KB of residual + 32 KB of gathers + 16 KB of stores = 96 KB through it, and a CU moves ~16 B / cycle of
+// such (mostly HBM-missing) traffic - an epilogue's eight stores take 4300 cycles and the issue of the next tile's 42 loads 4500,
+// not because of their own cost but because the other group's requests are ahead of them in the queue.  Neither the order of the
+// phases (split-before-epilogue below: the chain done -> full is 2700 cycles, yet the period stays 6300), nor priorities, nor
+// staggering the two workgroups of a pair changed the period; fewer bytes per tile would (the residual could be rebuilt from the
+// planes in LDS - exactly, x = (x1 + x2) + x3 - instead of being fetched again: -17 %).
 // e_out must not alias e_in (the two column halves of a row are written by different workgroups while both read whole rows).
 #include "common.h"
 
@@ -81,21 +88,28 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char ring[2 * SLOTB];
     __shared__ __attribute__((aligned(16))) float xt[2 * XT];
     __shared__ __attribute__((aligned(16))) float norm_lds[(MODE == 3 ? 7 : 2) * (MODE == 3 ? H : HC)];
-    __shared__ unsigned flags[4];   // full[2], done[2]
+    __shared__ unsigned flags[6];   // full[2], done[2], drained[2]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned full0 = lds_addr(&flags[0]), done0 = lds_addr(&flags[2]);
+    const unsigned full0 = lds_addr(&flags[0]), done0 = lds_addr(&flags[2]), drained0 = lds_addr(&flags[4]);
     // pairs of workgroups on one XCD (blocks b and b + 8 share b % 8) take the two column halves of the same tiles; in round r
     // the chip works on one contiguous window of tiles, each XCD on a contiguous part of it
     const int per_xcd = gridDim.x / kXcds, xcd = blockIdx.x % kXcds, idx = blockIdx.x / kXcds;
     const int hh = idx & 1, first = xcd * (per_xcd / 2) + (idx >> 1), stride = gridDim.x / 2;
     const int n = first < a.num_tiles ? (a.num_tiles - first + stride - 1) / stride : 0;
     if (n <= 0) return;
-    auto tile_of = [&](int r) { return first + r * stride; };
+    // The two workgroups of a pair walk their common tiles in opposite order within every two: workgroup 0 takes t0, t1, t2, t3, ...,
+    // workgroup 1 takes t1, t0, t3, t2, ...  Each e row is then requested from HBM by ONE of the two and found in the XCD's L2 a tile
+    // later by the other.  In step, both miss together: the second request merges into the first in L2 but still holds its L1
+    // miss slots for the whole HBM latency, and a CU's ~32 KB of misses in flight is what bounds this kernel's fetch.
+    auto tile_of = [&](int r) {
+        const int rr = (hh == 1 && (r ^ 1) < n) ? (r ^ 1) : r;
+        return first + rr * stride;
+    };
     auto tile_valid = [&](int r) { return (int)min((int64_t)TM, a.E - (int64_t)tile_of(r) * TM); };
     const int colh = HC * hh;   // first global column of this workgroup's half
-    if (tid < 4) flags[tid] = 0;
+    if (tid < 6) flags[tid] = 0;
     if (MODE == 3) {
         for (int i = tid; i < 7 * H; i += 512) {
             const int q = i / H, c = i % H;
@@ -155,7 +169,9 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                 c3 = n3;
             }
             if (a.prof) { asm volatile("" ::"v"(acc[0])); t1 = __builtin_readcyclecounter(); t_loop += t1 - t0; t0 = t1; }
-            // the x buffer of this slot is free: its group bumped `full` for this tile only after reading the previous x out of it
+            // the x buffer of this slot must have been read out by its group's epilogue of the tile before last (the group publishes
+            // the next tile's planes BEFORE that epilogue, so this is a real wait - normally long satisfied)
+            flag_wait(drained0 + 4 * slot, 2u * (use - 1u));
             float* X = xt + slot * XT + lane_x;
 #pragma unroll
             for (int r = 0; r < 16; ++r) X[crow(r) * LDK] = acc[r];
@@ -171,12 +187,13 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
     } else {
         // ------------------------------------------------------------------ load / store wave
         const int group = (wave - 4) >> 1;
+        // (tried: s_setprio 2 for these - the younger - waves: no change, 6330 cycles per tile either way; they are not losing issue slots
+        //  to the compute waves, they are waiting on the CU's vector-memory queue - see the header)
         const int gl = ((wave - 4) & 1) * 64 + lane;        // lane index inside the group, 0..127
         const int c4f = gl & 63, r0f = gl >> 6;             // fetch mapping: whole rows, rows r0f + 2 p
         const int c4e = gl & 31, r0e = gl >> 5;             // epilogue mapping: this half's 128 columns, rows r0e + 4 p
-        f32x4 av[NPF], ek[NPE], gk[NPE], g1[NPE], g2[NPE];
+        f32x4 av[NPF], ek[NPE], g1[NPE], g2[NPE];
         f32x4 dyv[MODE == 3 ? NPF : 1];   // MODE 3: the old C rows (dy), whole rows like av
-        int si[NPE], di[NPE];
         auto fetch_rows = [&](int r) {   // the A operand rows (MODE 3: the xe rows and the old C rows) - whole rows
             const int64_t row0 = (int64_t)tile_of(r) * TM;
             const int valid = tile_valid(r);
@@ -187,16 +204,12 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                 if (MODE == 3) dyv[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * H + 4 * c4f);
             }
         };
+        int si_all = 0, di_all = 0;   // lane l: the endpoints of tile row l % 32 (two loads per wave and tile instead of sixteen)
         auto fetch_index = [&](int r) {
             if (MODE >= 2) return;
-            const int64_t row0 = (int64_t)tile_of(r) * TM;
-            const int valid = tile_valid(r);
-#pragma unroll
-            for (int p = 0; p < NPE; ++p) {
-                const int64_t row = row0 + min(r0e + 4 * p, valid - 1);
-                si[p] = a.srt_src[row];
-                di[p] = a.srt_dst[row];
-            }
+            const int64_t row = (int64_t)tile_of(r) * TM + min(lane & 31, tile_valid(r) - 1);
+            si_all = a.srt_src[row];
+            di_all = a.srt_dst[row];
         };
         auto fetch_side = [&](int r) {   // this half's pieces: gathers, residual / old C rows
             const int64_t row0 = (int64_t)tile_of(r) * TM;
@@ -206,29 +219,22 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                 const int64_t row = row0 + min(r0e + 4 * p, valid - 1);
                 if (MODE == 0) ek[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + colh + 4 * c4e);
                 if (MODE < 2) {
-                    g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + (int64_t)si[p] * a.ldn + colh + 4 * c4e);
-                    g2[p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)di[p] * a.ldn + colh + 4 * c4e);
+                    const int sp = __shfl(si_all, r0e + 4 * p), dp = __shfl(di_all, r0e + 4 * p);
+                    g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + (int64_t)sp * a.ldn + colh + 4 * c4e);
+                    g2[p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)dp * a.ldn + colh + 4 * c4e);
                 } else {
                     g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * H + colh + 4 * c4e);   // the old rows of C
                 }
             }
         };
-        if (group < n) {
-            fetch_index(group);
-            fetch_rows(group);
-            fetch_side(group);
-        }
         unsigned char* S = ring + group * SLOTB;
         const float* Xs = xt + group * XT;
         f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1;   // MODE 1: this lane's running shifted sums of its four columns
-        long long t_top = 0, t_split = 0, t_gk = 0, t_done = 0, t_epi = 0, t0 = 0, t1 = 0;
-        for (int r = group; r < n; r += 2) {
-            const unsigned use = (unsigned)(r >> 1) + 1u;
-            if (a.prof) { t0 = __builtin_readcyclecounter(); asm volatile("" ::"v"(av[0][0]), "v"(av[NPF - 1][0])); t1 = __builtin_readcyclecounter(); t_top += t1 - t0; t0 = t1; }
-            // the planes slot is free: this group waited for `done` of its previous tile (all four compute waves had read them)
+        long long t_split = 0, t_done = 0, t_epi = 0, t_issue = 0, t_x0 = 0, t_x1 = 0, t0 = 0, t1 = 0;
+        // split the rows in av (tile r) into the group's planes slot and publish them; MODE 3 first turns them into A = BatchNorm
+        // backward of (dy = the old C rows, x = the xe rows) and writes this workgroup's column half of it out as dxe
+        auto split_and_publish = [&](int r) {
             if (MODE == 3) {
-                // A = BatchNorm backward of (dy = the old C rows, x = the xe rows) for this lane's four columns of whole rows; this
-                // workgroup writes its own column half of it out as dxe
                 const f32x4 ka = *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4f), k1 = *reinterpret_cast<const f32x4*>(norm_lds + H + 4 * c4f);
                 const f32x4 k2 = *reinterpret_cast<const f32x4*>(norm_lds + 2 * H + 4 * c4f), km = *reinterpret_cast<const f32x4*>(norm_lds + 3 * H + 4 * c4f);
                 const f32x4 kr = *reinterpret_cast<const f32x4*>(norm_lds + 4 * H + 4 * c4f), ks = *reinterpret_cast<const f32x4*>(norm_lds + 5 * H + 4 * c4f);
@@ -261,19 +267,28 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                 *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
             }
             flag_bump(full0 + 4 * group, lane);
-            if (a.prof) { t1 = __builtin_readcyclecounter(); t_split += t1 - t0; t0 = t1; }
-#pragma unroll
-            for (int p = 0; p < NPE; ++p) {
-                gk[p] = MODE >= 2 ? g1[p] : g1[p] + g2[p];
-                asm volatile("" : "+v"(gk[p]));   // summed HERE: the wait for the gathers must not sink behind the epilogue's stores
+        };
+        // Software pipeline over this group's tiles r, r + 2, ...: when the compute waves are done with tile r, the group FIRST splits
+        // and publishes tile r + 2 (its rows were requested a whole period ago) and only THEN runs tile r's epilogue, so the compute
+        // waves' next-but-one tile is ready ~2600 cycles after `done`, not after epilogue + fetch latency + split (measured: 8400).
+        // With two groups the chain done(r) -> full(r + 2) has one tile's matrix time (~3600 cycles) to hide in.
+        if (group < n) {
+            fetch_index(group);
+            fetch_rows(group);
+            fetch_side(group);
+            split_and_publish(group);
+            if (group + 2 < n) {
+                fetch_index(group + 2);   // (after fetch_side(group): it consumed the previous indices as addresses)
+                fetch_rows(group + 2);
             }
-            if (a.prof) { t1 = __builtin_readcyclecounter(); t_gk += t1 - t0; t0 = t1; }
-            if (r + 2 < n) {
-                fetch_index(r + 2);
-                fetch_rows(r + 2);
-            }
-            flag_wait(done0 + 4 * group, 4u * use);
+        }
+        for (int r = group; r < n; r += 2) {
+            const unsigned use = (unsigned)(r >> 1) + 1u;
+            if (a.prof) t0 = __builtin_readcyclecounter();
+            flag_wait(done0 + 4 * group, 4u * use);   // x(r) is ready; the planes slot is free (all four compute waves have read it)
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_done += t1 - t0; t0 = t1; }
+            if (r + 2 < n) split_and_publish(r + 2);
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_split += t1 - t0; t0 = t1; }
             const int valid = tile_valid(r);
             const f32x4 sc4 = MODE < 2 ? *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4e) : f32x4{0.f, 0.f, 0.f, 0.f};
             const f32x4 sh4 = MODE == 0 ? *reinterpret_cast<const f32x4*>(norm_lds + HC + 4 * c4e) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -284,15 +299,19 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(Xs + (r0e + 4 * (pb + u)) * LDK + 4 * c4e);
                 asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+                if (a.prof && pb == 0) { t1 = __builtin_readcyclecounter(); t_x0 += t1 - t0; }
+                if (a.prof && pb == 4) { t1 = __builtin_readcyclecounter(); t_x1 += t1 - t0; }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int p = pb + u, row = r0e + 4 * p;
                     f32x4 y;
                     if (MODE == 0) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + gk[p][j]) * sc4[j] + sh4[j], 0.f) + ek[p][j];
+                        for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + (g1[p][j] + g2[p][j])) * sc4[j] + sh4[j], 0.f) + ek[p][j];
+                    } else if (MODE == 1) {
+                        y = x[u] + (g1[p] + g2[p]);
                     } else {
-                        y = x[u] + gk[p];
+                        y = x[u] + g1[p];
                     }
                     if (row < valid) {
                         if (MODE == 1) {
@@ -304,12 +323,20 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                     }
                 }
             }
-            if (a.prof) { t1 = __builtin_readcyclecounter(); t_epi += t1 - t0; }
+            flag_bump(drained0 + 4 * group, lane);   // x(r) has been read: the compute waves may write x(r + 2) over it
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_epi += t1 - t0; t0 = t1; }
+            // requests for the coming tiles, issued behind the epilogue's stores (one in-order vector-memory queue per CU): tile r + 2's
+            // gathers / residual (consumed by its epilogue, a period from now) and tile r + 4's rows (consumed by its split, a period from now)
             if (r + 2 < n) fetch_side(r + 2);
+            if (r + 4 < n) {
+                fetch_index(r + 4);
+                fetch_rows(r + 4);
+            }
+            if (a.prof) { t1 = __builtin_readcyclecounter(); t_issue += t1 - t0; }
         }
         if (a.prof && wave == 4 && lane == 0) {   // the first load wave's phases, after the 256 compute-wave records
             long long* o = a.prof + (int64_t)(256 + blockIdx.x) * 8;
-            o[0] = t_top; o[1] = t_split; o[2] = t_done; o[3] = t_epi; o[4] = (n + 1) / 2; o[5] = t_gk;
+            o[0] = t_x0; o[1] = t_split; o[2] = t_done; o[3] = t_epi; o[4] = (n + 1) / 2; o[5] = t_issue; o[6] = t_x1;
         }
         if (MODE == 1 && a.stats != nullptr) {
             // lanes l and l + 32 hold different rows of the same four columns: fold them, then every load wave leaves one row of partial
@@ -319,10 +346,10 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                 st1[j] += __shfl_xor(st1[j], 32);
                 st2[j] += __shfl_xor(st2[j], 32);
             }
-            if (lane < 32) {   // one row of [2 H] per load wave: (sum | sum of squares) of (x - centre), this half's columns, the rest zero
-                float* dst = a.stats + ((int64_t)blockIdx.x * 4 + (wave - 4)) * 2 * H;
-                *reinterpret_cast<f32x4*>(dst + colh + 4 * c4e) = st1;
-                *reinterpret_cast<f32x4*>(dst + H + colh + 4 * c4e) = st2;
+            if (lane < 32) {   // one row per load wave in each of two [rows][H] matrices: sums and sums of squares of (x - centre), this half's columns, the rest zero
+                const int64_t srow = (int64_t)blockIdx.x * 4 + (wave - 4), srows = (int64_t)gridDim.x * 4;
+                *reinterpret_cast<f32x4*>(a.stats + srow * H + colh + 4 * c4e) = st1;              // [0][row][H]: sums
+                *reinterpret_cast<f32x4*>(a.stats + (srows + srow) * H + colh + 4 * c4e) = st2;    // [1][row][H]: sums of squares
             }
         }
     }
@@ -351,7 +378,7 @@ int launch_pl256(const GateBfArgs& args, hipStream_t s) {
 
 }  // namespace
 
-// mode 0: the gate; mode 1: the raw gate (+ shifted column sums into a.stats[gate_pl256_stats_rows()][2 * 256] when given, a.scale = centres);
+// mode 0: the gate; mode 1: the raw gate (+ shifted column sums into a.stats[2][gate_pl256_stats_rows()][256] when given, a.scale = centres);
 // mode 2: C += A W^T (a.e_in = A, a.e_out = a.B1h = C); mode 3: C_out = C_in + BatchNormBackward(C_in, X) W^T with dxe written out
 // (a.e_in = X, a.B1h = C_in, a.e_out = C_out != C_in, a.bnb)
 int gate_pl256_stats_rows() { return grid_pl256() * 4; }

@@ -393,7 +393,7 @@ def edge_gate_raw_stats(e, B1h, B2h, views, W3, rows_stats=None):
     out = torch.empty_like(e)
     _call("gnnome_edge_gate_raw_stats_f32", e.device, _ptr(e), _ptr(out), E, H, _ptr(B1h), _ptr(B2h), ldn, _ptr(views.srt_src),
           _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(center), _ptr(partial))
-    sums = colsum2(partial)[0]
+    sums = _partial_sums(partial, H)
     m1 = sums[:H] / E
     return out, (center + m1).contiguous(), (sums[H:] / E - m1 * m1).clamp_min_(0.0)
 
@@ -483,8 +483,18 @@ def edge_gate_raw_moments(e, B1h, B2h, views, W3, storage=torch.float32):
     out = torch.empty_like(e, dtype=torch.bfloat16 if x16 else torch.float32)
     _call("gnnome_edge_gate_raw_stats_x16" if x16 else "gnnome_edge_gate_raw_stats_f32", e.device, _ptr(e), _ptr(out), E, H, _ptr(B1h),
           _ptr(B2h), ldn, _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(center), _ptr(partial))
-    sums = colsum2(partial)[0]
+    sums = _partial_sums(partial, H)
     return out, (sums[:H], sums[H:], center, E)
+
+
+def _partial_sums(partial, H):
+    """[2H] = (sum | sum of squares) from the edge-tile kernel's per-wave rows: [rows][2H] at H <= 128, two stacked [rows][H]
+    matrices at H = 256 (edge_gate_pl256.hip); added up by the deterministic column-sum kernel."""
+    if H == 256:
+        rows = partial.shape[0]
+        stacked = partial.view(2, rows, H)
+        return torch.cat([colsum2(stacked[0])[0], colsum2(stacked[1])[0]])
+    return colsum2(partial)[0]
 
 
 def can_fuse_gate_moments(e, B1h, B2h, storage=torch.float32):

@@ -218,9 +218,11 @@ int gnnome_edge_gate_raw_f32(const float* e_in, float* x_out, int64_t num_edges,
                              const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
                              const float* W3, int ldw, void* stream);
 
-/* The same, with the BatchNorm batch statistics gathered on the way (hidden in {64,128}): every workgroup writes
+/* The same, with the BatchNorm batch statistics gathered on the way (hidden in {64,128,256}): every workgroup writes
  * its shifted column sums  stats_partial[w][c] = sum (x - center[c]),  stats_partial[w][hidden + c] = sum (x - center[c])^2
- * over the rows it produced; w < gnnome_edge_gate_raw_stats_rows(hidden).  Summing the rows of stats_partial (in any
+ * over the rows it produced; w < R = gnnome_edge_gate_raw_stats_rows(hidden).  (hidden = 256: two stacked matrices instead,
+ * stats_partial[0][w][c] the sums and stats_partial[1][w][c] the sums of squares, 2 * R * 256 floats in all, and x_out
+ * must not alias e_in.)  Summing the rows of stats_partial (in any
  * FIXED order, e.g. gnnome_colsum2_f32) gives the sums the statistics need without a second pass over x_out.
  * center: any per-column value near the column mean (row 0 of x_out is one) - the shift keeps the second moment
  * free of cancellation. */
