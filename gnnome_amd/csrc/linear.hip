@@ -324,13 +324,20 @@ struct LinBF2 {
     static_assert(NC * (K / 8) % NT == 0, "piece count");
 };
 
-template <int K, int NW = 4>
+// ROWST: the output leaves through a wave-private 32 x 32 LDS tile and is stored ROW-major, 16 bytes per lane (eight lanes to a
+// 128-byte row segment): 8 vector-memory stores per 32 x 64 block instead of 32 dword ones.  The projection writes 5 x the
+// bytes it reads, and a CU's vector-memory queue takes instructions, not bytes (round 3: edge_gate_pl256.hip's header) - at
+// N = 100k the 4-byte form issues 1M store instructions next to 0.5M loads.  Costs 18 KB of LDS per workgroup (two per CU
+// instead of three at K = 128).  C rows must be 16-byte aligned (ldc % 4 == 0).
+template <int K, int NW = 4, int ROWST = 0>
 __global__ __launch_bounds__(64 * NW) void k_linear_bf2(const float* __restrict__ A, int64_t M, int lda, const float* __restrict__ W,
                                                     int ldw, const float* __restrict__ bias, float* __restrict__ C, int ldc,
                                                     int num_tiles, int tiles_per_group, int accumulate) {
     using P = LinBF2<K, NW>;
     constexpr int PLD = P::PLD, PB = P::kPlaneBytes, KS = K / 16, HS = 2;   // fragments are fetched two K = 16 steps at a time
+    constexpr int TLD = 36;   // floats per row of the epilogue tile: 16-byte aligned rows, the two half waves' rows 4 apart
     __shared__ __attribute__((aligned(16))) unsigned char Wp[3 * PB];
+    __shared__ __attribute__((aligned(16))) float Tt[ROWST == 1 ? NW * 32 * TLD : 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 31, half = lane >> 5;
@@ -410,6 +417,62 @@ __global__ __launch_bounds__(64 * NW) void k_linear_bf2(const float* __restrict_
                 x[q][0] = nx[q][0];
                 x[q][1] = nx[q][1];
             }
+        }
+        if (ROWST == 2) {
+            // the same row-major stores WITHOUT LDS: 4 x 4 transposes inside lane quads (two butterfly stages of v_mov_dpp quad_perm
+            // + v_cndmask, 16 VALU operations per four registers): lane (quad q, j) ends up with row 8 g + 4 half + j, columns 4 q .. + 3
+            const int j = lane & 3, q4 = 4 * ((lane & 31) >> 2);
+            const bool odd = j & 1, hi = j & 2;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = cb == 0 ? acc0[4 * g + i] : acc1[4 * g + i];
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {   // exchange with lane ^ 1
+                        const float send = odd ? v[i] : v[i + 1];
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+                        v[i] = odd ? recv : v[i];
+                        v[i + 1] = odd ? v[i + 1] : recv;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {      // exchange with lane ^ 2
+                        const float send = hi ? v[i] : v[i + 2];
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));
+                        v[i] = hi ? recv : v[i];
+                        v[i + 2] = hi ? v[i + 2] : recv;
+                    }
+                    const int64_t row = row0 + 8 * g + 4 * half + j;
+                    if (row < M) {
+                        f32x4* o = reinterpret_cast<f32x4*>(C + row * ldc + col0 + 32 * cb + q4);
+                        const f32x4 y = {v[0], v[1], v[2], v[3]};
+                        *o = accumulate ? *o + y : y;
+                    }
+                }
+            }
+            continue;
+        }
+        if (ROWST == 1) {
+            float* tile = Tt + wave * 32 * TLD;
+            const int er = lane >> 3, ec = 4 * (lane & 7);   // row-major: lane -> rows er + 8 it, columns ec .. ec + 3
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tile[cd_row(r, lane) * TLD + cl] = cb == 0 ? acc0[r] : acc1[r];
+                __builtin_amdgcn_wave_barrier();   // the tile is this wave's own: LDS keeps a wave's accesses in order
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (er + 8 * it) * TLD + ec);
+                    if (row0 + er + 8 * it < M) {
+                        f32x4* o = reinterpret_cast<f32x4*>(C + (row0 + er + 8 * it) * ldc + col0 + 32 * cb + ec);
+                        *o = accumulate ? *o + v : v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
         }
         float* out = C + row0 * ldc + col0 + cl;
 #pragma unroll
@@ -550,7 +613,7 @@ static int launch_linear_as(const float* A, int64_t M, int lda, const float* W, 
     return GNNOME_OK;
 }
 
-template <int K, int NW = 4, int WGS_PER_CU = 3>
+template <int K, int NW = 4, int WGS_PER_CU = 3, int ROWST = 0>
 static int launch_linear_bf2(const float* A, int64_t M, int lda, const float* W, int ldw, const float* bias, int Nout, float* C,
                              int ldc, hipStream_t s, int accumulate) {
     using P = LinBF2<K, NW>;
@@ -563,7 +626,7 @@ static int launch_linear_bf2(const float* A, int64_t M, int lda, const float* W,
     if (groups < 1) groups = 1;
     if (groups > tiles) groups = (int)tiles;
     const int tpg = (int)((tiles + groups - 1) / groups);
-    hipLaunchKernelGGL((k_linear_bf2<K, NW>), dim3(groups, n_chunks), dim3(P::NT), 0, s, A, M, lda, W, ldw, bias, C, ldc, (int)tiles, tpg,
+    hipLaunchKernelGGL((k_linear_bf2<K, NW, ROWST>), dim3(groups, n_chunks), dim3(P::NT), 0, s, A, M, lda, W, ldw, bias, C, ldc, (int)tiles, tpg,
                        accumulate);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
@@ -707,9 +770,20 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
     }
     if (tuning(kTuneLinearVariant) == 0 && ldw % 4 == 0 && Nout % 64 == 0) {   // the shipped default: bf16x6, barrier-free streaming
         if (K == 128) return launch_linear_bf2<128>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+        // K = 64: row-major 16-byte stores through a wave-private LDS tile (0.0398 against 0.0471 ms at N = 100k, Nout = 320; the
+        // same at K = 128 costs the third resident workgroup per CU and measures 0.122 against 0.121 - variant 7)
+        if (K == 64 && aligned_out) return launch_linear_bf2<64, 4, 3, 1>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
         if (K == 64) return launch_linear_bf2<64>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
         // (K = 256: 101 KB of W planes leave one 8-wave workgroup per CU, too few waves to hide the fragment fetches:
         //  1.06 ms against 0.91 ms for the tile kernel at N = 250k, Nout = 1280 - measured, so K = 256 falls through)
+    }
+    if (tuning(kTuneLinearVariant) == 7 && ldw % 4 == 0 && Nout % 64 == 0 && aligned_out) {   // 7: the streaming kernel with row-major 16-byte stores
+        if (K == 128) return launch_linear_bf2<128, 4, 2, 1>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+        if (K == 64) return launch_linear_bf2<64, 4, 3, 1>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+    }
+    if (tuning(kTuneLinearVariant) == 8 && ldw % 4 == 0 && Nout % 64 == 0 && aligned_out) {   // 8: row-major stores by in-register quad transposes (no LDS)
+        if (K == 128) return launch_linear_bf2<128, 4, 3, 2>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
+        if (K == 64) return launch_linear_bf2<64, 4, 3, 2>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);
     }
     if (tuning(kTuneLinearVariant) == 6 && ldw % 4 == 0 && Nout % 64 == 0) {   // 6: A-stationary (see k_linear_as)
         if (K == 128) return launch_linear_as<128>(A, M, lda, W, ldw, bias, Nout, C, ldc, s, accumulate);

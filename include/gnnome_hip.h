@@ -55,7 +55,8 @@ const char* gnnome_last_error(void);
  *                             4 no e loads, 8 no MFMA, 16 nontemporal e loads / e' stores
  *   key 2 linear variant    : 0 shipped default (bf16x6 streaming kernel, A-stationary from 400k rows), 1 tile kernel,
  *                             2 exact-fp32 weight-stationary, 3 bf16x6 with A staged through LDS, 4 8-wave workgroups,
- *                             5 2-wave workgroups, 6 A-stationary at every size
+ *                             5 2-wave workgroups, 6 A-stationary at every size, 7 streaming kernel with row-major 16-byte
+ *                             stores (the default at K = 64)
  *   key 3 gate tile order   : 1 contiguous run per workgroup (default: interleaved, XCD-contiguous)
  *   key 4 gate experiment   : kernel-specific measurement switch (H = 256 streaming gate: tiles per workgroup piece)
  *   key 5 aggregation LDS   : KiB of unused dynamic LDS per workgroup (caps the resident workgroups per CU)
