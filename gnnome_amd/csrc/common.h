@@ -53,6 +53,7 @@ struct GateBfArgs {
     int abl;                  // measurement-only ablation mask (gnnome_set_tuning key 1), 0 in normal use
     long long* prof;          // measurement only: per-workgroup phase cycle counters [gridDim][8] (NULL in normal use)
     int xp;                   // experiment knob (key 4): producers' poll interval 0..3 = s_sleep 1/4/16/64
+    int num_cblocks, ld_out;  // edge_gate_pl256.hip mode 4 (C = A W^T + bias): 128-column blocks of the output, its row stride
     GateEnc enc;              // mode 0 with the folded edge encoder
     GateBnBwd bnb;            // mode 3
 };

@@ -81,6 +81,8 @@ __device__ __forceinline__ bf16x8_t as_bf8(const uint4 v) { return __builtin_bit
 // MODE 1: xe = e W3^T + B1h[src] + B2h[dst] and its shifted column sums (training forward; a.scale = the centres, a.stats out)
 // MODE 2: C += A W^T (A = e_in, C = e_out = the rows at B1h; the backward's d e_in = d e' + dxe W3)
 // MODE 3: MODE 2 with A = BatchNorm-backward(old C rows, xe rows at e_in) computed by the load waves and written to bnb.a_out
+// MODE 4: C[M, 128 * num_cblocks] = A[M,256] W^T + bias (a.e_in = A with row stride a.ldn, a.e_out = C with row stride a.ld_out, a.scale = bias):
+//         the node projection [N,256] -> [N,1280] and the scorer's node halves at this width
 template <int MODE>
 __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
     constexpr int H = 256, HC = 128, TM = 32, KS = H / 16, PLD = 2 * H + 16, PLANE = TM * PLD, SLOTB = 3 * PLANE, LDK = HC + 4, XT = TM * LDK;
@@ -96,15 +98,21 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
     // pairs of workgroups on one XCD (blocks b and b + 8 share b % 8) take the two column halves of the same tiles; in round r
     // the chip works on one contiguous window of tiles, each XCD on a contiguous part of it
     const int per_xcd = gridDim.x / kXcds, xcd = blockIdx.x % kXcds, idx = blockIdx.x / kXcds;
-    const int hh = idx & 1, first = xcd * (per_xcd / 2) + (idx >> 1), stride = gridDim.x / 2;
+    // MODE 4 (C = A W^T + bias with Nout = 128 * a.num_cblocks columns): a workgroup keeps ONE 128-column block of W for the whole
+    // launch; the a.num_cblocks workgroups of an XCD that share (idx / num_cblocks) walk the same tiles, so an A row comes from
+    // HBM once per XCD and from its L2 for the other column blocks
+    const int ncb = MODE == 4 ? a.num_cblocks : 2, streams = per_xcd / ncb;
+    if (idx >= streams * ncb) return;   // (32 workgroups per XCD, e.g. 10 column blocks: 3 streams, 2 idle workgroups)
+    const int hh = idx % ncb, first = xcd * streams + idx / ncb, stride = kXcds * streams;
     const int n = first < a.num_tiles ? (a.num_tiles - first + stride - 1) / stride : 0;
     if (n <= 0) return;
+    const int lda = MODE == 4 ? a.ldn : H, ldo = MODE == 4 ? a.ld_out : H;   // row strides of the A rows / of the output
     // The two workgroups of a pair walk their common tiles in opposite order within every two: workgroup 0 takes t0, t1, t2, t3, ...,
     // workgroup 1 takes t1, t0, t3, t2, ...  Each e row is then requested from HBM by ONE of the two and found in the XCD's L2 a tile
     // later by the other.  In step, both miss together: the second request merges into the first in L2 but still holds its L1
     // miss slots for the whole HBM latency, and a CU's ~32 KB of misses in flight is what bounds this kernel's fetch.
     auto tile_of = [&](int r) {
-        const int rr = (hh == 1 && (r ^ 1) < n) ? (r ^ 1) : r;
+        const int rr = (MODE != 4 && hh == 1 && (r ^ 1) < n) ? (r ^ 1) : r;
         return first + rr * stride;
     };
     auto tile_valid = [&](int r) { return (int)min((int64_t)TM, a.E - (int64_t)tile_of(r) * TM); };
@@ -116,6 +124,8 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
             const float* src = q == 0 ? a.bnb.a : q == 1 ? a.bnb.c1 : q == 2 ? a.bnb.c2 : q == 3 ? a.bnb.mean : q == 4 ? a.bnb.rstd : q == 5 ? a.bnb.scale : a.bnb.shift;
             norm_lds[i] = src[c];
         }
+    } else if (MODE == 4) {
+        for (int i = tid; i < HC; i += 512) norm_lds[i] = a.scale ? a.scale[colh + i] : 0.f;   // the bias of this column block
     } else if (MODE < 2) {
         for (int i = tid; i < 2 * HC; i += 512) {
             const int q = i / HC, c = i % HC;
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
 #pragma unroll
             for (int p = 0; p < NPF; ++p) {   // rows past the end of the list read the last valid row (never stored)
                 const int64_t row = row0 + min(r0f + 2 * p, valid - 1);
-                av[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + 4 * c4f);
+                av[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * lda + 4 * c4f);
                 if (MODE == 3) dyv[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * H + 4 * c4f);
             }
         };
@@ -212,6 +222,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
             di_all = a.srt_dst[row];
         };
         auto fetch_side = [&](int r) {   // this half's pieces: gathers, residual / old C rows
+            if (MODE == 4) return;
             const int64_t row0 = (int64_t)tile_of(r) * TM;
             const int valid = tile_valid(r);
 #pragma unroll
@@ -290,9 +301,9 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
             if (r + 2 < n) split_and_publish(r + 2);
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_split += t1 - t0; t0 = t1; }
             const int valid = tile_valid(r);
-            const f32x4 sc4 = MODE < 2 ? *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4e) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 sc4 = (MODE < 2 || MODE == 4) ? *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4e) : f32x4{0.f, 0.f, 0.f, 0.f};   // MODE 4: the bias
             const f32x4 sh4 = MODE == 0 ? *reinterpret_cast<const f32x4*>(norm_lds + HC + 4 * c4e) : f32x4{0.f, 0.f, 0.f, 0.f};
-            float* out = a.e_out + (int64_t)tile_of(r) * TM * H + colh + 4 * c4e;
+            float* out = a.e_out + (int64_t)tile_of(r) * TM * ldo + colh + 4 * c4e;
 #pragma unroll
             for (int pb = 0; pb < NPE; pb += 4) {
                 f32x4 x[4];
@@ -310,6 +321,8 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                         for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + (g1[p][j] + g2[p][j])) * sc4[j] + sh4[j], 0.f) + ek[p][j];
                     } else if (MODE == 1) {
                         y = x[u] + (g1[p] + g2[p]);
+                    } else if (MODE == 4) {
+                        y = x[u] + sc4;
                     } else {
                         y = x[u] + g1[p];
                     }
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                             st1 += dlt;
                             st2 += dlt * dlt;
                         }
-                        *reinterpret_cast<f32x4*>(out + (int64_t)row * H) = y;
+                        *reinterpret_cast<f32x4*>(out + (int64_t)row * ldo) = y;
                     }
                 }
             }
@@ -367,6 +380,8 @@ int launch_pl256(const GateBfArgs& args, hipStream_t s) {
     const int64_t tiles = (a.E + 31) / 32;
     GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
     GN_REQUIRE(a.e_out != a.e_in, "edge_gate (H = 256): the output must not alias the input rows");
+    GN_REQUIRE(MODE != 4 || (a.num_cblocks >= 1 && a.num_cblocks <= grid_pl256() / kXcds && a.ldn >= 256 && a.ldn % 4 == 0 && a.ld_out % 4 == 0),
+               "linear (K = 256): %d column blocks / strides %d, %d", a.num_cblocks, a.ldn, a.ld_out);
     GN_REQUIRE(MODE != 3 || a.e_out != a.B1h, "bn_bwd_dgrad (H = 256): C_out must not alias C_in (two workgroups read whole rows of it)");
     a.num_tiles = (int)tiles;
     a.prof = gate_profile_buffer();
@@ -387,6 +402,7 @@ int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s) {
     if (mode == 1) return launch_pl256<1>(a, s);
     if (mode == 2) return launch_pl256<2>(a, s);
     if (mode == 3) return launch_pl256<3>(a, s);
+    if (mode == 4) return launch_pl256<4>(a, s);
     set_error("edge-tile kernel (H = 256): mode %d is not built", mode);
     return GNNOME_EINVAL;
 }

@@ -762,6 +762,14 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
         g.e_in = A; g.e_out = C; g.E = M; g.B1h = C; g.ldn = 256; g.W3 = W; g.ldw = ldw;
         return gate_pl256_launch(2, g, s);   // the plane form as a residual GEMM (edge_gate_pl256.hip)
     }
+    if (tuning(kTuneLinearVariant) == 0 && !accumulate && K == 256 && Nout % 128 == 0 && Nout / 128 <= 16 && lda % 4 == 0 && ldw % 4 == 0 && aligned_out &&
+        M >= 8192 && (const void*)A != (const void*)C) {
+        // K = 256 (the node projection and the scorer's node halves of configs[3] / [4]): the plane-form edge-tile kernel with W in
+        // registers as a plain GEMM (edge_gate_pl256.hip mode 4); the tile kernel it replaces: 1.03 ms at N = 250k, Nout = 1280
+        GateBfArgs g = {};
+        g.e_in = A; g.e_out = C; g.E = M; g.ldn = lda; g.ld_out = ldc; g.W3 = W; g.ldw = ldw; g.scale = bias; g.num_cblocks = Nout / 128;
+        return gate_pl256_launch(4, g, s);
+    }
     if (tuning(kTuneLinearVariant) == 0 && ldw % 4 == 0 && Nout % 64 == 0 && Nout >= 256 && M >= kAStationaryRows) {
         // many row blocks and a wide output: A loaded and split once per row block (measured at Nout = 5H = 640: 1.08 against
         // 1.24 ms at M = 1M; at M = 100k - three row blocks per CU - the streaming kernel below wins, 0.120 against 0.133 ms)

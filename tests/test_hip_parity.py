@@ -122,7 +122,8 @@ def test_encode_wide_hidden_ne_and_features():
 
 
 @pytest.mark.parametrize("m,k,nout", [(1000, 64, 320), (333, 128, 640), (129, 256, 1280), (128, 64, 64), (5, 128, 32), (2000, 128, 96),
-                                      (40_000, 128, 640), (33_333, 64, 320), (70_001, 128, 128)])
+                                      (40_000, 128, 640), (33_333, 64, 320), (70_001, 128, 128),
+                                      (20_001, 256, 1280), (9000, 256, 128)])   # K = 256 from 8192 rows: edge_gate_pl256.hip mode 4
 def test_linear(m, k, nout):
     g = torch.Generator().manual_seed(m + k + nout)
     A, W, b = torch.randn(m, k, generator=g), torch.randn(nout, k, generator=g), torch.randn(nout, generator=g)
@@ -138,9 +139,11 @@ def test_linear(m, k, nout):
     acc = ops.linear(A.to(dev()), W.to(dev()), b.to(dev()), out=base.to(dev()).clone(), accumulate=True)
     _assert_close(acc, want + base.double(), scale=float(k) ** 0.5 * 4)
     try:  # other kernels behind the same entry point: tile kernel (1), exact-fp32 weight-stationary (2), bf16x6 with LDS-staged A (3)
-        for variant in (1, 2, 3):
+        for variant in (1, 2, 3, 7, 8):   # 7 / 8: row-major 16-byte stores through an LDS tile / by in-register quad transposes
             ops.set_tuning(2, variant)
             _assert_close(ops.linear(A.to(dev()), W.to(dev()), b.to(dev())), want, scale=float(k) ** 0.5 * 4)
+            if variant in (7, 8) and k in (64, 128) and nout % 64 == 0:   # the same arithmetic as the default kernel: the same bits
+                assert torch.equal(ops.linear(A.to(dev()), W.to(dev()), b.to(dev())), got)
     finally:
         ops.set_tuning(2, 0)
 
