@@ -55,6 +55,32 @@ def test_gfa_similarity_sources(tmp_path):
     assert torch.equal(g["src"], c["src"]) and torch.allclose(g["overlap_similarity"].double(), c["overlap_similarity"].double(), atol=1e-7)
 
 
+def test_dgl_graph_converter_and_missing_dgl(tmp_path):
+    """SURVEY 8f rank 1's ".dgl converter when DGL is importable": a DGLGraph-shaped object (the goldens' test double; a real
+    DGLGraph has the same surface) converts to read_gfa's dict; without the dgl package load_dgl_file says what is missing."""
+    import sys
+    from conftest import GOLDEN as golden_dir
+    from gnnome_amd import dgl_io
+    c = load_golden("g10_gfa.pt")["cases"][0]
+    sys.path.insert(0, os.path.join(golden_dir, "_dgl_shim"))
+    try:
+        import dgl as shim
+        g = shim.DGLGraph(c["src"], c["dst"], c["num_nodes"])
+        g.edata.update(overlap_length=c["overlap_length"], overlap_similarity=c["overlap_similarity"], prefix_length=c["prefix_length"])
+        g.ndata.update(read_length=c["read_length"])
+        out = dgl_io.from_dgl_graph(g)
+    finally:
+        sys.path.pop(0)
+        sys.modules.pop("dgl", None), sys.modules.pop("dgl.function", None), sys.modules.pop("dgl.nn", None)
+    want = gfa.read_gfa(os.path.join(GOLDEN, c["gfa"]), similarity=_similarity)
+    for key in ("src", "dst", "overlap_length", "prefix_length", "read_length"):
+        assert torch.equal(out[key], want[key]), key
+    assert out["num_nodes"] == want["num_nodes"] and torch.allclose(out["overlap_similarity"], want["overlap_similarity"], atol=1e-7)
+    assert out["y"] is None
+    with pytest.raises(ImportError, match="dgl==0.8.1"):
+        dgl_io.load_dgl_file(tmp_path / "0.dgl")
+
+
 def dev():
     return torch.device("cuda", 0)
 
