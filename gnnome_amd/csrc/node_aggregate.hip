@@ -329,7 +329,10 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
             }
         }
     } else {
-        if (SPLIT == 1)
+        if (SPLIT == 2)   // MEASUREMENT ONLY (variant 7, wrong results): the out-edges alone - what the aggregation would cost if the in-edge half
+                          // were done elsewhere (inside the gate's store waves); see DESIGN.md, round 3
+            accumulate_items_split<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, 0, ob, 0, cnt - din, lane, group, c, nf, df, nb, db);
+        else if (SPLIT == 1)
             accumulate_items_split<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
         else
             accumulate_items<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
@@ -453,6 +456,7 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
             case 4: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 8, 0, blocks); break;
             case 5: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 2, 0, blocks); break;
             case 6: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 0); break;   // the unsplit item loop (in-edge rows requested after the index wait)
+            case 7: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 2); break;   // measurement only: out-edges alone
             default: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks); break;
         }
         if (hub_pass) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, true, UD, 0, kFinGrid);
