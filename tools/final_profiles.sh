@@ -3,7 +3,7 @@
 # every kernel of one forward, bench lines for every workload.   usage: tools/final_profiles.sh <tag, e.g. r02>
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
 for mode in infer train; do
   timeout 500 rocprofv3 --kernel-trace --stats -d $O/prof_$mode -o r -- python bench.py --mode $mode --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-extras > $O/prof_$mode.bench.json 2> $O/prof_$mode.err
@@ -27,8 +27,19 @@ timeout 600 python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline
 timeout 600 python bench.py --mode train > $O/${TAG}_bench_c3_train_step.json 2>/dev/null
 timeout 600 python bench.py --mode train --storage bf16 --no-cpu-baseline > $O/${TAG}_bench_c3_train_bf16_storage.json 2>/dev/null
 timeout 600 python bench.py --mode train --symmetry --no-cpu-baseline > $O/${TAG}_bench_c3_train_symmetry.json 2>/dev/null
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --one-gpu-gloo --workload c2 --steps 5 --warmup 2 > $O/${TAG}_bench_n2_plumbing.json 2>/dev/null
-for f in c2 10m parity64 c4shard c4_one_gpu c5_one_gpu c2_uniform c3_train_step c3_train_bf16_storage c3_train_symmetry n2_plumbing; do python - "$f" "$TAG" <<'PY'
+timeout 300 python bench.py --gpus 2 --one-gpu-gloo --workload c2 --steps 5 --warmup 2 > $O/${TAG}_bench_n2_plumbing.json 2>/dev/null   # (spawns its own two ranks)
+timeout 400 python bench.py --gpus 2 --one-gpu-gloo --mode train --workload c2 --steps 5 --warmup 2 > $O/${TAG}_bench_n2_train_plumbing.json 2>/dev/null
+timeout 400 python bench.py --gpus 2 --one-gpu-gloo --mode train --workload c4shard --steps 3 --warmup 1 > $O/${TAG}_bench_n2_train_h256_plumbing.json 2>/dev/null
+timeout 400 python bench.py --workload c4shard --mode train --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_train_c4shard_h256.json 2>/dev/null
+# what inference.py users run: E. coli-sized graph, shipped checkpoint, auto arithmetic (layer 0 in the reference's order) + its kernel table
+timeout 400 python bench.py --workload ecoli > $O/${TAG}_bench_ecoli.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_ecoli -o r -- python bench.py --workload ecoli --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-extras > /dev/null 2> $O/prof_ecoli.err
+python tools/rocpd_summary.py "$(find $O/prof_ecoli -name '*.db' | head -1)" > $O/${TAG}_ecoli.kernel_stats.md 2>&1; rm -rf $O/prof_ecoli
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c4 -o r -- python bench.py --workload c4shard --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-extras > /dev/null 2> $O/prof_c4.err
+python tools/rocpd_summary.py "$(find $O/prof_c4 -name '*.db' | head -1)" > $O/${TAG}_c4shard_infer.kernel_stats.md 2>&1; rm -rf $O/prof_c4
+timeout 200 python tools/gate_phase_profile.py --hidden 256 --edges 2500000 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gate256_phases.txt
+timeout 200 python tools/forward_ab.py 0,7 7 2>&1 | grep -v amdgpu.ids > $O/${TAG}_aggregation_without_in_edges.txt
+for f in c2 10m parity64 c4shard c4_one_gpu c5_one_gpu c2_uniform c3_train_step c3_train_bf16_storage c3_train_symmetry n2_plumbing n2_train_plumbing n2_train_h256_plumbing train_c4shard_h256 ecoli; do python - "$f" "$TAG" <<'PY'
 import json,sys
 f,tag=sys.argv[1],sys.argv[2]
 try:
