@@ -15,21 +15,34 @@
 //   * hand-over through two LDS counters per slot (full: planes ready, 2 bumps; done: x ready, 4 bumps); the x tile has its
 //     own buffer, so the compute waves never wait for one another and no third or fourth counter is needed (cf. k_edge_gate_pl).
 // Per tile and compute wave: 16 x 6 MFMAs = 3072 matrix-pipe cycles (3560 measured at the 1.9 GHz the chip holds under this load).
-// MEASURED (tools/gate_phase_profile.py --hidden 256, profiles/r03_gate256_phases.txt): 6330 cycles per tile, the compute waves
-// busy 56 % of the time.  What binds is the CU's in-order vector-memory queue: per tile-half the four load / store waves push
-// 32 KB of e rows + 16 KB of residual + 32 KB of gathers + 16 KB of stores = 96 KB through it, and a CU moves ~16 B / cycle of
-// such (mostly HBM-missing) traffic - an epilogue's eight stores take 4300 cycles and the issue of the next tile's 42 loads 4500,
-// not because of their own cost but because the other group's requests are ahead of them in the queue.  Neither the order of the
-// phases (split-before-epilogue below: the chain done -> full is 2700 cycles, yet the period stays 6300), nor priorities, nor
-// staggering the two workgroups of a pair changed the period; fewer bytes per tile would (the residual could be rebuilt from the
-// planes in LDS - exactly, x = (x1 + x2) + x3 - instead of being fetched again: -17 %).
+// MEASURED (tools/gate_phase_profile.py --hidden 256, profiles/r03_gate256_phases.txt): 5700 cycles per tile, the compute waves
+// busy 63 % of the time; the load / store waves are the long pole - per tile a wave handles (every second one) 3100 cycles of
+// split + plane stores (352 VALU operations and 48 ds_write_b64 per lane; one VALU-issuing wave per SIMD retires an instruction
+// every ~5 cycles), 3600 of epilogue (residual rebuilt from the planes, G, normalise, eight 16-byte stores) and 3100 issuing the
+// next requests.  What was learned on the way (each measured on the box):
+//   * with ALL global traffic compiled out the kernel still took 1.57 ms: the load waves' own instruction streams bound it, not HBM;
+//   * the hipcc waitcnt pass turns a wait that sits between CONDITIONAL stores into s_waitcnt vmcnt(0) - the wave then sits out
+//     the HBM write latency of its own stores (500 cycles per epilogue piece): every operand that came through the vector-memory
+//     queue is awaited before the first store, and whole tiles store unconditionally;
+//   * a register copy of a value whose load was just issued (the destination-row reuse below, first version) serialises the
+//     gathers - vmcnt(1) after every pair, 4800 cycles of "issue" - so the reuse is resolved in the epilogue, a period later;
+//   * loads issued BEFORE the wait for the compute waves make the epilogue's stores queue behind HBM misses (3760 cycles);
+//   * the split of tile r + 2 goes BEFORE the epilogue of tile r (chain done -> full 3100 cycles instead of 8400);
+//   * B2h[dst] is fetched once per run of equal destinations (a lane's pieces are consecutive, destination-sorted rows) and the
+//     residual is rebuilt from the planes ((x1 + x2) + x3 is exact) instead of being read again: 96 -> ~69 KB per tile-half
+//     through the CU's vector-memory queue;
+//   * no effect: s_setprio for the load waves, the two workgroups of a pair walking their tiles in opposite order.
+// 2.36 ms (k_edge_gate_stream) -> 1.98 ms per launch at the 2.5M-edge shard; the matrix-pipe floor of this form is 1.25 ms.
 // e_out must not alias e_in (the two column halves of a row are written by different workgroups while both read whole rows).
 #include "common.h"
+
+#include <type_traits>
 
 namespace gnnome {
 namespace {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr bool kResidualFromPlanes = true;   // the epilogue's residual rebuilt from the LDS planes (true; 5724 cycles per tile) or fetched again (false; 5949)
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
 __device__ __forceinline__ void flag_wait(unsigned addr, unsigned want) {
@@ -83,7 +96,7 @@ __device__ __forceinline__ bf16x8_t as_bf8(const uint4 v) { return __builtin_bit
 // MODE 3: MODE 2 with A = BatchNorm-backward(old C rows, xe rows at e_in) computed by the load waves and written to bnb.a_out
 // MODE 4: C[M, 128 * num_cblocks] = A[M,256] W^T + bias (a.e_in = A with row stride a.ldn, a.e_out = C with row stride a.ld_out, a.scale = bias):
 //         the node projection [N,256] -> [N,1280] and the scorer's node halves at this width
-template <int MODE>
+template <int MODE, int PROBE = 0>   // PROBE (measurement only, wrong results): 1 = no MFMAs, 2 = no plane reads either
 __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
     constexpr int H = 256, HC = 128, TM = 32, KS = H / 16, PLD = 2 * H + 16, PLANE = TM * PLD, SLOTB = 3 * PLANE, LDK = HC + 4, XT = TM * LDK;
     constexpr int NPF = 16, NPE = 8;   // pieces per lane: fetch mapping (whole rows), epilogue mapping (this workgroup's column half)
@@ -167,6 +180,11 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                 const int qn = q + 1 < KS ? q + 1 : q, on = 128 * (qn >> 2) + 16 * (qn & 3);
                 const uint4 n1 = *reinterpret_cast<const uint4*>(ap + on), n2 = *reinterpret_cast<const uint4*>(ap + on + PLANE),
                             n3 = *reinterpret_cast<const uint4*>(ap + on + 2 * PLANE);
+                if (PROBE >= 1) {
+                    acc[q & 15] += __uint_as_float(c1.x ^ c2.y ^ c3.z ^ w1[q].x ^ w2[q].y ^ w3[q].z);
+                    c1 = n1, c2 = n2, c3 = n3;
+                    continue;
+                }
                 // smallest terms first
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(c3), as_bf8(w1[q]), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(c1), as_bf8(w3[q]), acc, 0, 0, 0);
@@ -200,8 +218,11 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
         // (tried: s_setprio 2 for these - the younger - waves: no change, 6330 cycles per tile either way; they are not losing issue slots
         //  to the compute waves, they are waiting on the CU's vector-memory queue - see the header)
         const int gl = ((wave - 4) & 1) * 64 + lane;        // lane index inside the group, 0..127
-        const int c4f = gl & 63, r0f = gl >> 6;             // fetch mapping: whole rows, rows r0f + 2 p
-        const int c4e = gl & 31, r0e = gl >> 5;             // epilogue mapping: this half's 128 columns, rows r0e + 4 p
+        const int c4f = gl & 63, r0f = gl >> 6;             // fetch mapping: whole rows, rows 16 r0f + p: a wave splits AND post-processes
+                                                            // the same sixteen rows, so it may read tile r's planes while its sibling already writes tile r + 2's
+        const int c4e = gl & 31, r0e = gl >> 5;             // epilogue mapping: this half's 128 columns, rows 8 r0e + p (CONSECUTIVE rows
+                                                            // per lane: the rows are destination-sorted, so B2h[dst] repeats from piece to piece)
+        auto erow = [&](int p) { return 8 * r0e + p; };
         f32x4 av[NPF], ek[NPE], g1[NPE], g2[NPE];
         f32x4 dyv[MODE == 3 ? NPF : 1];   // MODE 3: the old C rows (dy), whole rows like av
         auto fetch_rows = [&](int r) {   // the A operand rows (MODE 3: the xe rows and the old C rows) - whole rows
@@ -209,11 +230,12 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
             const int valid = tile_valid(r);
 #pragma unroll
             for (int p = 0; p < NPF; ++p) {   // rows past the end of the list read the last valid row (never stored)
-                const int64_t row = row0 + min(r0f + 2 * p, valid - 1);
+                const int64_t row = row0 + min(16 * r0f + p, valid - 1);
                 av[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * lda + 4 * c4f);
                 if (MODE == 3) dyv[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * H + 4 * c4f);
             }
         };
+        unsigned g2_fresh = 0;        // (wave-uniform) bit p: B2h[dst] was fetched for piece p of the tile whose epilogue comes next
         int si_all = 0, di_all = 0;   // lane l: the endpoints of tile row l % 32 (two loads per wave and tile instead of sixteen)
         auto fetch_index = [&](int r) {
             if (MODE >= 2) return;
@@ -221,18 +243,30 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
             si_all = a.srt_src[row];
             di_all = a.srt_dst[row];
         };
-        auto fetch_side = [&](int r) {   // this half's pieces: gathers, residual / old C rows
+        auto fetch_side = [&](int r) {   // this half's pieces: gathers / old C rows (the residual comes back out of the planes, see below)
             if (MODE == 4) return;
             const int64_t row0 = (int64_t)tile_of(r) * TM;
             const int valid = tile_valid(r);
+            int dprev = -1;
+            g2_fresh = 0;
 #pragma unroll
             for (int p = 0; p < NPE; ++p) {
-                const int64_t row = row0 + min(r0e + 4 * p, valid - 1);
-                if (MODE == 0) ek[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + colh + 4 * c4e);
+                const int64_t row = row0 + min(erow(p), valid - 1);
+                if (MODE == 0 && !kResidualFromPlanes) ek[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * H + colh + 4 * c4e);
                 if (MODE < 2) {
-                    const int sp = __shfl(si_all, r0e + 4 * p), dp = __shfl(di_all, r0e + 4 * p);
+                    const int lr = min(erow(p), valid - 1);
+                    const int sp = __shfl(si_all, lr), dp = __shfl(di_all, lr);
                     g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + (int64_t)sp * a.ldn + colh + 4 * c4e);
-                    g2[p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)dp * a.ldn + colh + 4 * c4e);
+                    // B2h[dst]: a run of equal destinations is ~10 rows long, a lane's pieces are consecutive rows - the row is fetched again
+                    // only when some lane of the wave needs a new one (a wave-uniform branch: ~2.3 of 8 loads survive on assembly graphs)
+                    // (the skipped pieces are filled in from their predecessors in the epilogue, when everything has arrived: a register
+                    //  copy HERE would wait for the load just issued and serialise the gathers - measured: 4800 cycles of issue)
+                    const bool fresh = p == 0 || dp != dprev;
+                    if (__builtin_amdgcn_ballot_w64(fresh) != 0) {
+                        g2[p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)dp * a.ldn + colh + 4 * c4e);
+                        g2_fresh |= 1u << p;
+                    }
+                    dprev = dp;
                 } else {
                     g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * H + colh + 4 * c4e);   // the old rows of C
                 }
@@ -241,7 +275,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
         unsigned char* S = ring + group * SLOTB;
         const float* Xs = xt + group * XT;
         f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1;   // MODE 1: this lane's running shifted sums of its four columns
-        long long t_split = 0, t_done = 0, t_epi = 0, t_issue = 0, t_x0 = 0, t_x1 = 0, t0 = 0, t1 = 0;
+        long long t_split = 0, t_done = 0, t_epi = 0, t_issue = 0, t0 = 0, t1 = 0;
         // split the rows in av (tile r) into the group's planes slot and publish them; MODE 3 first turns them into A = BatchNorm
         // backward of (dy = the old C rows, x = the xe rows) and writes this workgroup's column half of it out as dxe
         auto split_and_publish = [&](int r) {
@@ -256,7 +290,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                 const bool mine = (c4f >> 5) == hh;
 #pragma unroll
                 for (int p = 0; p < NPF; ++p) {
-                    const int row = r0f + 2 * p;
+                    const int row = 16 * r0f + p;
                     const float on = row < once3 ? 1.f : 0.f;
                     f32x4 t;
 #pragma unroll
@@ -272,7 +306,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
             for (int p = 0; p < NPF; ++p) {
                 uint2 p1, p2, p3;
                 split4(av[p], p1, p2, p3);
-                unsigned char* d = S + (r0f + 2 * p) * PLD + 8 * c4f;
+                unsigned char* d = S + (16 * r0f + p) * PLD + 8 * c4f;
                 *reinterpret_cast<uint2*>(d) = p1;
                 *reinterpret_cast<uint2*>(d + PLANE) = p2;
                 *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
@@ -298,44 +332,82 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
             if (a.prof) t0 = __builtin_readcyclecounter();
             flag_wait(done0 + 4 * group, 4u * use);   // x(r) is ready; the planes slot is free (all four compute waves have read it)
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_done += t1 - t0; t0 = t1; }
+            if (MODE == 0 && kResidualFromPlanes) {
+                // the residual e[row, this half] is NOT fetched a second time: the planes of tile r are still in the slot, and the
+                // three-way split is exact - x = (x1 + x2) + x3 bit for bit (x1 + x2 = x with its low mantissa bits cleared) - so
+                // 24 ds_read_b64 + 20 VALU operations per piece replace 16 KB per tile through the vector-memory queue
+#pragma unroll
+                for (int p = 0; p < NPE; ++p) {
+                    const unsigned char* q = S + erow(p) * PLD + 2 * (colh + 4 * c4e);
+                    const uint2 u1 = *reinterpret_cast<const uint2*>(q), u2 = *reinterpret_cast<const uint2*>(q + PLANE),
+                                u3 = *reinterpret_cast<const uint2*>(q + 2 * PLANE);
+                    auto lo = [](unsigned v) { return __uint_as_float(v << 16); };
+                    auto hi = [](unsigned v) { return __uint_as_float(v & 0xFFFF0000u); };
+                    ek[p] = f32x4{(lo(u1.x) + lo(u2.x)) + lo(u3.x), (hi(u1.x) + hi(u2.x)) + hi(u3.x), (lo(u1.y) + lo(u2.y)) + lo(u3.y),
+                                  (hi(u1.y) + hi(u2.y)) + hi(u3.y)};
+                }
+            }
             if (r + 2 < n) split_and_publish(r + 2);
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_split += t1 - t0; t0 = t1; }
             const int valid = tile_valid(r);
             const f32x4 sc4 = (MODE < 2 || MODE == 4) ? *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4e) : f32x4{0.f, 0.f, 0.f, 0.f};   // MODE 4: the bias
             const f32x4 sh4 = MODE == 0 ? *reinterpret_cast<const f32x4*>(norm_lds + HC + 4 * c4e) : f32x4{0.f, 0.f, 0.f, 0.f};
             float* out = a.e_out + (int64_t)tile_of(r) * TM * ldo + colh + 4 * c4e;
+            // Every operand that came through the vector-memory queue is awaited HERE, before the first store: loads and stores share
+            // one in-order counter, and a wait that the compiler places between (conditional) stores becomes s_waitcnt vmcnt(0) - the
+            // wave then sits out the HBM write latency of its own stores (measured: 500 cycles per piece; ISA: vmcnt(0) before piece 7)
+            if (MODE != 4) {
+                if (MODE < 2) {
 #pragma unroll
-            for (int pb = 0; pb < NPE; pb += 4) {
-                f32x4 x[4];
+                    for (int p = 0; p < NPE; ++p) asm volatile("" : "+v"(g2[p]));
+                    const unsigned fresh_r = __builtin_amdgcn_readfirstlane(g2_fresh);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(Xs + (r0e + 4 * (pb + u)) * LDK + 4 * c4e);
-                asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-                if (a.prof && pb == 0) { t1 = __builtin_readcyclecounter(); t_x0 += t1 - t0; }
-                if (a.prof && pb == 4) { t1 = __builtin_readcyclecounter(); t_x1 += t1 - t0; }
+                    for (int p = 1; p < NPE; ++p)
+                        if (!((fresh_r >> p) & 1u)) g2[p] = g2[p - 1];   // same destination as the row above: the same B2h row
+                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int p = pb + u, row = r0e + 4 * p;
-                    f32x4 y;
-                    if (MODE == 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + (g1[p][j] + g2[p][j])) * sc4[j] + sh4[j], 0.f) + ek[p][j];
-                    } else if (MODE == 1) {
-                        y = x[u] + (g1[p] + g2[p]);
-                    } else if (MODE == 4) {
-                        y = x[u] + sc4;
-                    } else {
-                        y = x[u] + g1[p];
-                    }
-                    if (row < valid) {
-                        if (MODE == 1) {
-                            const f32x4 dlt = y - sc4;
-                            st1 += dlt;
-                            st2 += dlt * dlt;
-                        }
-                        *reinterpret_cast<f32x4*>(out + (int64_t)row * ldo) = y;
-                    }
+                for (int p = 0; p < NPE; ++p) {
+                    if (MODE < 2) g1[p] += g2[p];   // G = B1h[src] + B2h[dst]
+                    asm volatile("" : "+v"(g1[p]));
+                    if (MODE == 0) asm volatile("" : "+v"(ek[p]));
                 }
             }
+            // whole tiles (all but the last of an edge list) store unconditionally: no branch per piece, the store count is static
+            auto pieces = [&](auto full_tile) {
+                constexpr bool FULL = decltype(full_tile)::value;
+#pragma unroll
+                for (int pb = 0; pb < NPE; pb += 4) {
+                    f32x4 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(Xs + erow(pb + u) * LDK + 4 * c4e);
+                    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int p = pb + u, row = erow(p);
+                        f32x4 y;
+                        if (MODE == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + g1[p][j]) * sc4[j] + sh4[j], 0.f) + ek[p][j];
+                        } else if (MODE == 4) {
+                            y = x[u] + sc4;
+                        } else {
+                            y = x[u] + g1[p];
+                        }
+                        if (FULL || row < valid) {
+                            if (MODE == 1) {
+                                const f32x4 dlt = y - sc4;
+                                st1 += dlt;
+                                st2 += dlt * dlt;
+                            }
+                            *reinterpret_cast<f32x4*>(out + (int64_t)row * ldo) = y;
+                        }
+                    }
+                }
+            };
+            if (valid == TM)
+                pieces(std::true_type{});
+            else
+                pieces(std::false_type{});
             flag_bump(drained0 + 4 * group, lane);   // x(r) has been read: the compute waves may write x(r + 2) over it
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_epi += t1 - t0; t0 = t1; }
             // requests for the coming tiles, issued behind the epilogue's stores (one in-order vector-memory queue per CU): tile r + 2's
@@ -349,7 +421,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
         }
         if (a.prof && wave == 4 && lane == 0) {   // the first load wave's phases, after the 256 compute-wave records
             long long* o = a.prof + (int64_t)(256 + blockIdx.x) * 8;
-            o[0] = t_x0; o[1] = t_split; o[2] = t_done; o[3] = t_epi; o[4] = (n + 1) / 2; o[5] = t_issue; o[6] = t_x1;
+            o[0] = 0; o[1] = t_split; o[2] = t_done; o[3] = t_epi; o[4] = (n + 1) / 2; o[5] = t_issue;
         }
         if (MODE == 1 && a.stats != nullptr) {
             // lanes l and l + 32 hold different rows of the same four columns: fold them, then every load wave leaves one row of partial
@@ -374,7 +446,7 @@ int grid_pl256() {
     return g < 16 ? 16 : g;
 }
 
-template <int MODE>
+template <int MODE, int PROBE = 0>
 int launch_pl256(const GateBfArgs& args, hipStream_t s) {
     GateBfArgs a = args;
     const int64_t tiles = (a.E + 31) / 32;
@@ -386,7 +458,7 @@ int launch_pl256(const GateBfArgs& args, hipStream_t s) {
     a.num_tiles = (int)tiles;
     a.prof = gate_profile_buffer();
     if (MODE == 1 && a.stats != nullptr) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * (size_t)grid_pl256() * 4 * 2 * 256, s));   // idle waves / the other half
-    hipLaunchKernelGGL((k_edge_gate_pl256<MODE>), dim3(grid_pl256()), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((k_edge_gate_pl256<MODE, PROBE>), dim3(grid_pl256()), dim3(512), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
@@ -398,6 +470,7 @@ int launch_pl256(const GateBfArgs& args, hipStream_t s) {
 // (a.e_in = X, a.B1h = C_in, a.e_out = C_out != C_in, a.bnb)
 int gate_pl256_stats_rows() { return grid_pl256() * 4; }
 int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s) {
+    if (mode == 0 && tuning(kTuneGateAblation) == 8) return launch_pl256<0, 1>(a, s);   // measurement only: the kernel without its MFMAs
     if (mode == 0) return launch_pl256<0>(a, s);
     if (mode == 1) return launch_pl256<1>(a, s);
     if (mode == 2) return launch_pl256<2>(a, s);

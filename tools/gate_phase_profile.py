@@ -61,7 +61,7 @@ if H == 256 and lw[:, 4].sum().item() > 0:   # k_edge_gate_pl256: two load group
     t = lw[:, 4].sum().item()
     print("  first load wave, cycles per tile it handles (one in two): "
           + ", ".join(f"{nm} {lw[:, k].sum().item() / t:.0f}" for k, nm in [(2, "wait for compute (done)"), (1, "split + publish the tile after next"),
-                                                                            (3, "epilogue + stores"), (5, "issue of the next requests"), (0, "[epilogue: until the first four x pieces are there"), (6, "until the second four]")]))
+                                                                            (3, "epilogue + stores"), (5, "issue of the next requests")]))
 elif a.variant == 7 and lw[:, 4].sum().item() > 0:
     t = lw[:, 4].sum().item()
     print("  first load wave, cycles per tile IT handles (one in four): "
