@@ -69,6 +69,7 @@ int stream_linear_acc_256(const float* A, int64_t M, const float* W, int ldw, fl
 // H = 256 in the wave-specialised plane form (edge_gate_pl256.hip): modes 0 (gate), 1 (raw gate, optional statistics), 2 (C += A W^T)
 int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s);
 int gate_pl256_stats_rows();
+void hub_cache_invalidate();        // node_aggregate.hip: forget the hub list of the previous graph (called when views are built)
 long long* gate_profile_buffer();   // gnnome_debug_gate_profile's buffer (edge_gate_bf.hip), NULL in normal use
 // reference-order kernels on the fp32 matrix cores (reference_order_mfma.hip); K / hidden in {64, 128}
 int linear_refm_launch(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias, int Nout, float* C, int ldc,

@@ -86,6 +86,7 @@ extern "C" int gnnome_build_graph_views(const int32_t* src, const int32_t* dst, 
     GN_REQUIRE(num_nodes >= 0 && num_edges >= 0 && num_nodes < (1ll << 31) && num_edges < (1ll << 31),
                "graph_views: N=%lld E=%lld out of int32 range", (long long)num_nodes, (long long)num_edges);
     GN_REQUIRE(in_ptr && out_ptr, "graph_views: null pointer");
+    hub_cache_invalidate();   // the aggregation's per-device hub list belongs to the graph whose views were built before
     hipStream_t s = (hipStream_t)stream;
     const int64_t N = num_nodes, E = num_edges;
     if (E == 0) {

@@ -42,6 +42,13 @@ struct HubScratch {
     int* count = nullptr;       // [1]
     int* nodes = nullptr;       // [kHubCap]
     float* partials = nullptr;  // [kHubCap][kHubChunks][4][H]
+    // The hub count of the graph the list was last built for, read back WITHOUT a host sync: an asynchronous copy into pinned memory
+    // behind k_find_hubs, polled with hipEventQuery on later calls.  Once it is known to be zero - every assembly graph without a
+    // repeat-induced hub - the two hub launches (8 layers x 2 x ~4.7 us: 9 % of an E. coli-sized forward) are skipped.
+    int* host_count = nullptr;  // pinned
+    hipEvent_t ready = nullptr;
+    bool pending = false;
+    int known = -1;             // -1: not known yet
 };
 
 // Per-device scratch of the hub path, allocated on first use (never inside a stream capture: the first call of any
@@ -51,9 +58,24 @@ struct HubScratch {
 // be in flight on two streams of one device at once (this package launches all its work on torch's current stream; the
 // optional second stream of engine.aggregate_then_project runs projections only).  The host-side table is guarded by a
 // mutex, and the first use never allocates inside a stream capture: it reports an error instead (warm up eagerly first).
+static HubScratch g_hub_table[64];
+static std::mutex g_hub_guard;
+
+// gnnome_build_graph_views calls this: new CSR arrays may land at the addresses of freed ones (torch's caching allocator does
+// that routinely), and the list - and the "this graph has no hubs" fact - of the previous graph must not outlive it.
+void hub_cache_invalidate() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lock(g_hub_guard);
+    g_hub_table[dev].key_in = g_hub_table[dev].key_out = nullptr;
+    g_hub_table[dev].key_n = -1;
+    g_hub_table[dev].known = -1;
+    g_hub_table[dev].pending = false;
+}
+
 static HubScratch* hub_scratch(hipStream_t s, bool* capturing_unallocated) {
-    static HubScratch table[64];
-    static std::mutex guard;
+    HubScratch* table = g_hub_table;
+    std::mutex& guard = g_hub_guard;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(guard);
@@ -67,6 +89,8 @@ static HubScratch* hub_scratch(hipStream_t s, bool* capturing_unallocated) {
         if (h.count == nullptr && hipMalloc(&h.count, sizeof(int)) != hipSuccess) return nullptr;
         if (h.nodes == nullptr && hipMalloc(&h.nodes, sizeof(int) * kHubCap) != hipSuccess) return nullptr;
         if (hipMalloc(&h.partials, sizeof(float) * (size_t)kHubCap * kHubChunks * 4 * kHubMaxH) != hipSuccess) return nullptr;
+        if (hipHostMalloc(&h.host_count, sizeof(int), hipHostMallocDefault) != hipSuccess) h.host_count = nullptr;   // (optional: without it the count stays unknown)
+        if (h.host_count && hipEventCreateWithFlags(&h.ready, hipEventDisableTiming) != hipSuccess) h.ready = nullptr;
     }
     return &h;
 }
@@ -405,6 +429,15 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
     HubScratch* hub = tuning(kTuneAggHubs) == 1 ? nullptr : hub_scratch(s, &capturing_unallocated);
     GN_REQUIRE(!capturing_unallocated, "node_aggregate: first call on this device inside a stream capture - run one eager call first "
                                        "(the hub scratch is allocated on first use)");
+    if (hub != nullptr && hub->key_in == in_ptr && hub->key_out == out_ptr && hub->key_n == n_out) {
+        hipStreamCaptureStatus capq = hipStreamCaptureStatusNone;
+        const bool capturing = hub->pending && (hipStreamIsCapturing(s, &capq) != hipSuccess || capq != hipStreamCaptureStatusNone);
+        if (hub->pending && !capturing && hipEventQuery(hub->ready) == hipSuccess) {   // (an event query is not allowed inside a stream capture)
+            hub->known = *hub->host_count;
+            hub->pending = false;
+        }
+        if (hub->known == 0) hub = nullptr;   // this graph has no node above the threshold: the plain launch is the whole aggregation
+    }
     const bool hub_pass = hub != nullptr && node_begin == 0;
     const int* hub_count = hub ? hub->count : nullptr;
     const int* hub_nodes = hub ? hub->nodes : nullptr;
@@ -420,6 +453,13 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
             GN_HIP(hipMemsetAsync(hub->count, 0, sizeof(int), s));
             hipLaunchKernelGGL(k_find_hubs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, in_ptr, out_ptr, n_out, hub->count, hub->nodes);
             hub->key_in = in_ptr, hub->key_out = out_ptr, hub->key_n = n_out;
+            hub->known = -1, hub->pending = false;
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hub->ready != nullptr && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {   // (not inside a capture)
+                if (hipMemcpyAsync(hub->host_count, hub->count, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipEventRecord(hub->ready, s) == hipSuccess)
+                    hub->pending = true;
+            }
         }
         hipLaunchKernelGGL((k_hub_partials<H>), dim3(kHubChunks / (kAggThreads / 64)), dim3(kAggThreads), 0, s, e, A2h, A3h, ldn, in_ptr, ss, out_ptr,
                            out_pos, od, n_out, hub->count, hub->nodes, hub->partials);

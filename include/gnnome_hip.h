@@ -82,6 +82,8 @@ int gnnome_debug_gate_profile(void* counters);
  *   out_pos      int32[E]   for each node, the sorted positions of its out-edges (ascending)
  *   out_dst      int32[E]   out_dst[q] = srt_dst[out_pos[q]], the far endpoint of that out-edge
  */
+/* Building views also resets the aggregation's per-device hub cache: the list of nodes with more than 4096 incident edges is
+ * keyed by the addresses of in_ptr / out_ptr; a caller that rewrites such arrays in place must call this entry (or use new arrays). */
 int gnnome_graph_views_workspace_bytes(int64_t num_nodes, int64_t num_edges, size_t* bytes_host);
 int gnnome_build_graph_views(const int32_t* src, const int32_t* dst, int64_t num_nodes, int64_t num_edges,
                              int32_t* in_ptr, int32_t* srt_src, int32_t* srt_dst, int32_t* srt_eid,
