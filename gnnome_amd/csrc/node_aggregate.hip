@@ -182,7 +182,9 @@ __device__ __forceinline__ void accumulate_items(const float* __restrict__ e, co
 // before the wave waits for its index loads: the in-items and the out-items of a 64-item batch run as two loops (the step that
 // straddles the boundary is cut in two; the two directions have separate accumulators, so the order within each is unchanged),
 // and inside the in-loop all row loads go out first, then the neighbour indices are awaited and the table rows gathered.
-template <int H, int U = (H == 256 ? 8 : 4)>
+// NOBR: the accumulation of a dead item (past the end of its list: its loads were clamped to a live one) is masked arithmetically
+// instead of being branched around - every live item still adds the same values in the same order (a dead one adds +0): same bits.
+template <int H, int U = (H == 256 ? 8 : 4), bool NOBR = false>
 __device__ __forceinline__ void accumulate_items_split(const float* __restrict__ e, const float* __restrict__ A2h, const float* __restrict__ A3h,
                                                        int ldn, const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_pos,
                                                        const int32_t* __restrict__ out_dst, int ib, int din, int ob, int lo, int hi, int lane,
@@ -216,7 +218,13 @@ __device__ __forceinline__ void accumulate_items_split(const float* __restrict__
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (live[u]) {
+                if (NOBR) {
+                    f32x4 s;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] = live[u] ? sigmoidf_(x[u][k]) : 0.f;
+                    nf += s * a[u];
+                    df += s;
+                } else if (live[u]) {
                     f32x4 s;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) s[k] = sigmoidf_(x[u][k]);
@@ -239,7 +247,13 @@ __device__ __forceinline__ void accumulate_items_split(const float* __restrict__
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (live[u]) {
+                if (NOBR) {
+                    f32x4 s;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] = live[u] ? sigmoidf_(x[u][k]) : 0.f;
+                    nb += s * a[u];
+                    db += s;
+                } else if (live[u]) {
                     f32x4 s;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) s[k] = sigmoidf_(x[u][k]);
@@ -356,6 +370,8 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
         if (SPLIT == 2)   // MEASUREMENT ONLY (variant 7, wrong results): the out-edges alone - what the aggregation would cost if the in-edge half
                           // were done elsewhere (inside the gate's store waves); see DESIGN.md, round 3
             accumulate_items_split<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, 0, ob, 0, cnt - din, lane, group, c, nf, df, nb, db);
+        else if (SPLIT == 3)   // variant 8: the split loop without branches around dead items
+            accumulate_items_split<H, U, true>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
         else if (SPLIT == 1)
             accumulate_items_split<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
         else
@@ -497,6 +513,7 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
             case 5: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, 2, 0, blocks); break;
             case 6: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 0); break;   // the unsplit item loop (in-edge rows requested after the index wait)
             case 7: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 2); break;   // measurement only: out-edges alone
+            case 8: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 3); break;   // no branches around dead items
             default: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks); break;
         }
         if (hub_pass) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, true, UD, 0, kFinGrid);
