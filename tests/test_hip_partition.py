@@ -153,7 +153,7 @@ def _check_partitioned_step(outs, om, want, want_loss, rtol):
         for k, b in om.named_buffers():
             assert torch.allclose(o["buffers"][k].float(), b.float(), atol=1e-5, rtol=1e-4), k
     for k in outs[0]["grads"]:   # every rank holds the same bits: per-rank optimizers stay in step
-        assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k
+        assert all(torch.equal(outs[0]["grads"][k], o["grads"][k]) for o in outs[1:]), k
 
 
 def test_two_ranks_training_step_h256_matches_oracle_autograd(tmp_path):
@@ -174,9 +174,10 @@ def test_two_ranks_training_step_h256_matches_oracle_autograd(tmp_path):
     _check_partitioned_step(outs, om, want, want_loss, rtol=3e-2)
 
 
-def test_two_ranks_training_step_h128_on_a_mostly_cut_graph(tmp_path):
-    """uniform graph at H = 128: half of the edges live on both ranks, so most gradient rows are assembled from partial sums
-    (the fused BatchNorm-backward + data-gradient pass with rows_once < rows, halo gradients both ways)."""
+def test_three_ranks_training_step_h128_on_a_mostly_cut_graph(tmp_path):
+    """uniform graph at H = 128 on THREE ranks sharing the GPU: two thirds of the edges are cut (live on two ranks), so most gradient
+    rows are assembled from partial sums (the fused BatchNorm-backward + data-gradient pass with rows_once < rows, halo gradients
+    every way) - VERDICT r2 item 1(d)."""
     from gnnome_amd.synth import make_graph
     from oracle.symgated_oracle import degree_features
     n, e, hidden = 3000, 30_000, 128
@@ -186,6 +187,6 @@ def test_two_ranks_training_step_h128_on_a_mostly_cut_graph(tmp_path):
     om, want, want_loss = _oracle_step(gr, x, n, sd, hidden)
     case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], y=gr["y"], pos_weight=gr["pos_weight"], hidden=hidden, layers=8,
                 state_dict=sd, train=True, device="cuda")
-    outs = _run(2, case, tmp_path)
-    assert sum(o["e_local"] for o in outs) > 1.45 * e      # > 45 % of the edges are replicated (cut)
+    outs = _run(3, case, tmp_path)
+    assert sum(o["e_local"] for o in outs) > 1.6 * e       # > 60 % of the edges are cut: replicated on a second rank
     _check_partitioned_step(outs, om, want, want_loss, rtol=3e-2)
