@@ -456,6 +456,7 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the target_10m / train sub-records (N = 1) and the scaling reference (N > 1)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--tuning", default="", help="A/B measurement only: gnnome_set_tuning pairs 'key=value,key=value' (include/gnnome_hip.h); recorded in the line")
     ap.add_argument("--one-gpu-gloo", action="store_true",
                     help="plumbing check of the N>1 path on a 1-GPU box: all ranks share cuda:0, collectives go over gloo "
                          "(host-staged); the numbers it prints are NOT a multi-GPU measurement")
@@ -487,6 +488,8 @@ def main():
 
     import gnnome_amd
     from gnnome_amd import _lib, ops
+    for pair in filter(None, args.tuning.split(",")):
+        ops.set_tuning(*(int(v) for v in pair.split("=")))
     from gnnome_amd.synth import make_graph, random_state_dict
     _lib.load()
 
@@ -697,6 +700,8 @@ def main():
                         f"{chunks_timed} node ranges (engine.aggregate_then_project)") if chunks_timed > 1 else "1",
         }
         res.update(extras)
+        if args.tuning:
+            res["tuning"] = args.tuning   # not the shipped defaults
         if "scaling_reference" in extras:
             res["speedup_over_one_gpu_same_graph"] = extras["scaling_reference"]["ms_per_step"] / ms
         if timed and kt.events[timed[0]]:

@@ -443,9 +443,13 @@ __device__ __forceinline__ void split4_planes(const f32x4 x, uint2& p1, uint2& p
 // MODE 0: the inference gate.  MODE 1: raw gate + shifted column sums (training forward; a.scale = the centres).  MODE 3: the
 // BatchNorm backward + data gradient of k_edge_gate_bf's mode 3 (A computed by the load waves from the old C rows and the rows at
 // e_in, written to bnb.a_out; C += A W^T).  X16: xe / dxe stored as bf16 (see common.h).  Modes 1 and 3 hold no e rows for a residual.
+// MODE 4 (round 3): C[M, 128 * a.num_cblocks] = A[M,128] W^T + bias - the node projection [N,H] -> [N,5H] on this kernel: a workgroup keeps
+// ONE 128-column block of W in its compute waves' registers for the whole launch, the a.num_cblocks workgroups of an XCD that share a
+// tile stream read an A row from HBM once (the others find it in that XCD's L2); no gathers, bias instead of the epilogue.  A has row
+// stride a.ldn, C row stride a.ld_out, a.scale = bias (NULL: none).
 template <bool ENC, int MODE = 0, bool X16 = false>
 __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
-    static_assert(MODE == 0 || MODE == 1 || MODE == 3, "modes of the plane form");
+    static_assert(MODE == 0 || MODE == 1 || MODE == 3 || MODE == 4, "modes of the plane form");
     static_assert(!ENC || MODE == 0, "the folded encoder belongs to the inference gate");
     constexpr int H = 128, TM = 32, RING = 4, KS = H / 16, LDK = H + 4, PLD = 2 * H + 16, PLANE = TM * PLD, SLOTB = 3 * PLANE;
     constexpr int NP = 8, RSTEP = 4, NT = 768;
@@ -465,10 +469,19 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
     const unsigned full0 = lds_addr_bf(&flags[0]), rd0 = lds_addr_bf(&flags[RING]), done0 = lds_addr_bf(&flags[2 * RING]),
                    drained0 = lds_addr_bf(&flags[3 * RING]);
     const int per_xcd = gridDim.x / kXcds;
-    const int first = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
-    const int stride = (int)gridDim.x;
+    int first = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
+    int stride = (int)gridDim.x;
+    int cbk = 0;   // MODE 4: this workgroup's 128-column block of the output
+    if (MODE == 4) {
+        const int idx = blockIdx.x / kXcds, streams = per_xcd / a.num_cblocks;
+        if (idx >= streams * a.num_cblocks) return;   // (32 workgroups per XCD, 5 column blocks: 6 tile streams, 2 idle workgroups)
+        cbk = idx % a.num_cblocks;
+        first = (int)(blockIdx.x % kXcds) * streams + idx / a.num_cblocks;
+        stride = kXcds * streams;
+    }
     const int n = first < a.num_tiles ? (a.num_tiles - first + stride - 1) / stride : 0;
     if (n <= 0) return;
+    const int lda = MODE == 4 ? a.ldn : H, ldo = MODE == 4 ? a.ld_out : H;
     auto tile_of = [&](int r) { return first + r * stride; };
     auto tile_valid = [&](int r) { return (int)min((int64_t)TM, a.E - (int64_t)tile_of(r) * TM); };
     if (ENC) {
@@ -480,6 +493,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
     if (tid < 4 * RING) flags[tid] = 0;
     for (int i = tid; i < 7 * H; i += NT) {
         const int q = i / H, c = i % H;
+        if (MODE == 4 && q < 1) norm_lds[i] = a.scale ? a.scale[H * cbk + c] : 0.f;   // the bias of this column block
         if (MODE == 0 && q < 2) norm_lds[i] = q == 0 ? a.scale[c] : a.shift[c];
         if (MODE == 1 && q < 1) norm_lds[i] = a.scale[c];   // the columns' centres
         if (MODE == 3) {
@@ -495,7 +509,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
         uint4 w1[KS], w2[KS], w3[KS];
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-            const float* wp = a.W3 + (int64_t)col * a.ldw + 16 * q + 8 * half;
+            const float* wp = a.W3 + (int64_t)(H * cbk + col) * a.ldw + 16 * q + 8 * half;
             split3(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4), w1[q], w2[q], w3[q]);
         }
         auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {   // rows past the end of the list read the last valid row (never stored)
                 const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
-                if (MODE != 3) {
+                if (MODE != 3 && MODE != 4) {
                     si[p] = a.srt_src[row];
                     di[p] = a.srt_dst[row];
                 }
@@ -578,12 +592,12 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
-                av[p] = load4_as<(X16 && MODE == 3)>(a.e_in, row * H + 4 * c4);   // mode 3: the xe rows
+                av[p] = load4_as<(X16 && MODE == 3)>(a.e_in, row * lda + 4 * c4);   // mode 3: the xe rows; mode 4: the A rows
                 if (MODE == 3) g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * a.ldn + 4 * c4);   // the old rows of C
             }
         };
         auto issue_late = [&](int) {
-            if (MODE == 3) return;
+            if (MODE == 3 || MODE == 4) return;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 if (ENC) {
@@ -659,10 +673,10 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                 *reinterpret_cast<uint2*>(d + PLANE) = p2;
                 *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
                 if (MODE == 0) ek[p] = av[p];
-                gk[p] = MODE == 3 ? g1[p] : g1[p] + g2[p];
+                if (MODE != 4) gk[p] = MODE == 3 ? g1[p] : g1[p] + g2[p];
                 // G is summed HERE, not where it is used: sunk into the epilogue, the sum would drag the wait for the gathers
                 // behind that epilogue's own stores (one in-order counter for loads and stores) and stall on their completion
-                asm volatile("" : "+v"(gk[p]));
+                if (MODE != 4) asm volatile("" : "+v"(gk[p]));
             }
             flag_bump_bf(full0 + 4 * group, lane);
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_split += t1 - t0; t0 = t1; }
@@ -674,6 +688,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
             const f32x4 sc4 = *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4), sh4 = *reinterpret_cast<const f32x4*>(norm_lds + H + 4 * c4);
             float* out = a.e_out + (int64_t)tile_of(r) * TM * H;
             const int64_t obase = (int64_t)tile_of(r) * TM * H;
+            float* out4 = a.e_out + (int64_t)tile_of(r) * TM * ldo + H * cbk + 4 * c4;   // MODE 4: row stride ldo, this column block
             // four x pieces are read together, BEFORE the row-validity branches: one LDS round trip (~400 cycles with the compute
             // waves reading planes flat out) per four pieces instead of one per piece
 #pragma unroll
@@ -690,6 +705,9 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + gk[p][j]) * sc4[j] + sh4[j], 0.f) + ek[p][j];
                         if (row < valid) *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
+                    } else if (MODE == 4) {
+                        y = x[u] + sc4;   // + bias
+                        if (row < valid) *reinterpret_cast<f32x4*>(out4 + (int64_t)row * ldo) = y;
                     } else {
                         y = x[u] + gk[p];
                         if (MODE == 1 && X16) y = unpack_bf16x4(pack_bf16x4(y));   // the statistics are those of the stored values
@@ -745,6 +763,8 @@ static int launch_pl(const GateBfArgs& args, hipStream_t s) {
     a.xp = tuning(kTuneGateExperiment);
     a.prof = g_gate_prof;
     if (MODE == 1) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * kNumCUs * 8 * 2 * 128, s));   // idle waves leave zeros
+    GN_REQUIRE(MODE != 4 || (a.num_cblocks >= 1 && a.num_cblocks <= persistent_grid() / kXcds && a.ldn >= 128 && a.ldn % 4 == 0 && a.ld_out % 4 == 0),
+               "linear (K = 128): %d column blocks / strides %d, %d", a.num_cblocks, a.ldn, a.ld_out);
     hipLaunchKernelGGL((k_edge_gate_pl<ENC, MODE, X16>), dim3(persistent_grid()), dim3(768), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
@@ -991,6 +1011,7 @@ int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStrea
         if (mode == 0 && tuning(kTuneGateVariant) != 8) return enc ? launch_pl<true>(a, s) : launch_pl<false>(a, s);
         if (mode == 1 && planes) return launch_pl<false, 1>(a, s);
         if (mode == 3 && planes) return launch_pl<false, 3>(a, s);
+        if (mode == 4) return launch_pl<false, 4>(a, s);
         if (mode == 0) return enc ? launch_bf<4, 1, 0, true>(a, s) : launch_bf<4, 1, 0, false>(a, s);
         if (mode == 3) return launch_bf<4, 1, 3, false>(a, s);
         return mode == 1 ? launch_bf<4, 1, 1, false>(a, s) : launch_bf<4, 1, 2, false>(a, s);

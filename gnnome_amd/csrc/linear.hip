@@ -770,6 +770,16 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
         g.e_in = A; g.e_out = C; g.E = M; g.ldn = lda; g.ld_out = ldc; g.W3 = W; g.ldw = ldw; g.scale = bias; g.num_cblocks = Nout / 128;
         return gate_pl256_launch(4, g, s);
     }
+    if ((tuning(kTuneLinearVariant) == 0 || tuning(kTuneLinearVariant) == 9) && !accumulate && K == 128 && Nout % 128 == 0 && Nout >= 256 && Nout / 128 <= 16 &&
+        lda % 4 == 0 && ldw % 4 == 0 && aligned_out && (const void*)A != (const void*)C &&
+        M >= 1) {   // at every row count (12 us at 100 rows like the streaming kernel, level with k_linear_as from 400k): one kernel, so a
+                    // row's bits do not depend on how the caller cuts the node range (engine.aggregate_then_project, dist.py)
+        // wide K = 128 products (the node projection [N,128] -> [N,640]): the plane-form edge-tile kernel as a plain GEMM (mode 4) -
+        // W in the compute waves' registers, A split once per tile by the load waves, bias + 16-byte row stores in the store waves
+        GateBfArgs g = {};
+        g.e_in = A; g.e_out = C; g.E = M; g.ldn = lda; g.ld_out = ldc; g.W3 = W; g.ldw = ldw; g.scale = bias; g.num_cblocks = Nout / 128;
+        return gate_bf_launch(128, 4, false, g, s);
+    }
     if (tuning(kTuneLinearVariant) == 0 && ldw % 4 == 0 && Nout % 64 == 0 && Nout >= 256 && M >= kAStationaryRows) {
         // many row blocks and a wide output: A loaded and split once per row block (measured at Nout = 5H = 640: 1.08 against
         // 1.24 ms at M = 1M; at M = 100k - three row blocks per CU - the streaming kernel below wins, 0.120 against 0.133 ms)

@@ -139,10 +139,18 @@ def test_linear(m, k, nout):
     acc = ops.linear(A.to(dev()), W.to(dev()), b.to(dev()), out=base.to(dev()).clone(), accumulate=True)
     _assert_close(acc, want + base.double(), scale=float(k) ** 0.5 * 4)
     try:  # other kernels behind the same entry point: tile kernel (1), exact-fp32 weight-stationary (2), bf16x6 with LDS-staged A (3)
-        for variant in (1, 2, 3, 7, 8):   # 7 / 8: row-major 16-byte stores through an LDS tile / by in-register quad transposes
-            ops.set_tuning(2, variant)
+        ops.set_tuning(2, 5 if k == 128 else 4)   # the streaming kernel at any size
+        stream = ops.linear(A.to(dev()), W.to(dev()), b.to(dev()))
+        for variant in (1, 2, 3, 7, 8, 9):   # 7 / 8: row-major 16-byte stores through an LDS tile / by in-register quad transposes
+            ops.set_tuning(2, variant)       # 9: at K = 128 the plane-form kernel (edge_gate_bf.hip mode 4) at any row count
             _assert_close(ops.linear(A.to(dev()), W.to(dev()), b.to(dev())), want, scale=float(k) ** 0.5 * 4)
-            if variant in (7, 8) and k in (64, 128) and nout % 64 == 0:   # the same arithmetic as the default kernel: the same bits
+            if variant in (7, 8) and k in (64, 128) and nout % 64 == 0:   # the same arithmetic as the streaming kernel: the same bits
+                assert torch.equal(ops.linear(A.to(dev()), W.to(dev()), b.to(dev())), stream)
+            if variant == 9 and k == 128 and nout % 128 == 0 and nout >= 256:
+                wide = torch.full((m, nout + 64), 7.0, device=dev())   # strided output, no bias; the default route at this shape
+                ops.linear(A.to(dev()), W.to(dev()), None, out=wide[:, 64:])
+                _assert_close(wide[:, 64:], want - b.double(), scale=float(k) ** 0.5 * 4)
+                assert (wide[:, :64] == 7.0).all()
                 assert torch.equal(ops.linear(A.to(dev()), W.to(dev()), b.to(dev())), got)
     finally:
         ops.set_tuning(2, 0)
@@ -168,7 +176,10 @@ def test_linear_a_stationary_kernel(m, k, nout):
     finally:
         ops.set_tuning(2, 0)
     assert torch.equal(got, ref) and torch.equal(wide[:, 64:], ref_nb) and not wide[:, :64].any()
-    assert torch.equal(ops.linear(A, W, b), ref)      # the default route (A-stationary from 400k rows) agrees either way
+    if k == 64 or nout % 128:
+        assert torch.equal(ops.linear(A, W, b), ref)  # the default route (A-stationary from 400k rows) agrees either way
+    else:   # K = 128 and whole 128-column blocks: the default is the plane-form kernel at every size (its own order of the same products)
+        assert (ops.linear(A, W, b) - ref).abs().max() <= 1e-4
     rows = torch.randint(0, m, (2000,), generator=g)
     want = A[rows].double().cpu() @ W.double().cpu().t() + b.double().cpu()
     _assert_close(got[rows], want, scale=float(k) ** 0.5 * 4)
