@@ -449,7 +449,7 @@ __device__ __forceinline__ void split4_planes(const f32x4 x, uint2& p1, uint2& p
 // stride a.ldn, C row stride a.ld_out, a.scale = bias (NULL: none).
 template <bool ENC, int MODE = 0, bool X16 = false>
 __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
-    static_assert(MODE == 0 || MODE == 1 || MODE == 3 || MODE == 4, "modes of the plane form");
+    static_assert(MODE >= 0 && MODE <= 4, "modes of the plane form");   // 2: C += A W^T (the residual GEMM; mode 3 without the BatchNorm step)
     static_assert(!ENC || MODE == 0, "the folded encoder belongs to the inference gate");
     constexpr int H = 128, TM = 32, RING = 4, KS = H / 16, LDK = H + 4, PLD = 2 * H + 16, PLANE = TM * PLD, SLOTB = 3 * PLANE;
     constexpr int NP = 8, RSTEP = 4, NT = 768;
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {   // rows past the end of the list read the last valid row (never stored)
                 const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
-                if (MODE != 3 && MODE != 4) {
+                if (MODE < 2) {
                     si[p] = a.srt_src[row];
                     di[p] = a.srt_dst[row];
                 }
@@ -593,11 +593,11 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
             for (int p = 0; p < NP; ++p) {
                 const int64_t row = row0 + min(r0 + p * RSTEP, valid - 1);
                 av[p] = load4_as<(X16 && MODE == 3)>(a.e_in, row * lda + 4 * c4);   // mode 3: the xe rows; mode 4: the A rows
-                if (MODE == 3) g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * a.ldn + 4 * c4);   // the old rows of C
+                if (MODE == 2 || MODE == 3) g1[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * a.ldn + 4 * c4);   // the old rows of C
             }
         };
         auto issue_late = [&](int) {
-            if (MODE == 3 || MODE == 4) return;
+            if (MODE >= 2) return;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 if (ENC) {
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                 *reinterpret_cast<uint2*>(d + PLANE) = p2;
                 *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
                 if (MODE == 0) ek[p] = av[p];
-                if (MODE != 4) gk[p] = MODE == 3 ? g1[p] : g1[p] + g2[p];
+                if (MODE != 4) gk[p] = MODE >= 2 ? g1[p] : g1[p] + g2[p];
                 // G is summed HERE, not where it is used: sunk into the epilogue, the sum would drag the wait for the gathers
                 // behind that epilogue's own stores (one in-order counter for loads and stores) and stall on their completion
                 if (MODE != 4) asm volatile("" : "+v"(gk[p]));
@@ -1012,6 +1012,7 @@ int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStrea
         if (mode == 1 && planes) return launch_pl<false, 1>(a, s);
         if (mode == 3 && planes) return launch_pl<false, 3>(a, s);
         if (mode == 4) return launch_pl<false, 4>(a, s);
+        if (mode == 2 && planes) return launch_pl<false, 2>(a, s);
         if (mode == 0) return enc ? launch_bf<4, 1, 0, true>(a, s) : launch_bf<4, 1, 0, false>(a, s);
         if (mode == 3) return launch_bf<4, 1, 3, false>(a, s);
         return mode == 1 ? launch_bf<4, 1, 1, false>(a, s) : launch_bf<4, 1, 2, false>(a, s);

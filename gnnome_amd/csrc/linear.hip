@@ -714,6 +714,9 @@ __global__ __launch_bounds__(kGemmThreads) void k_linear_blocks(ABlocks ab, int6
 
 }  // namespace gnnome
 
+static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias, int Nout,
+                       float* C, int ldc, void* stream, int accumulate);
+
 // C[M,Nout] (+)= [A_0 | A_1 | ...] W^T with the column blocks of A in separate buffers (all [M, block_width], row stride lda)
 extern "C" int gnnome_linear_blocks_f32(const float* const* A_blocks, int num_blocks, int block_width, int64_t M, int lda, const float* W,
                                         int ldw, int Nout, float* C, int ldc, int accumulate, void* stream) {
@@ -731,6 +734,17 @@ extern "C" int gnnome_linear_blocks_f32(const float* const* A_blocks, int num_bl
         ab.blk[k] = A_blocks[k];
     }
     ab.width = block_width;
+    if (tuning(kTuneLinearVariant) == 0 && block_width == Nout && (Nout == 128 || Nout == 256) && lda == Nout && ldc == Nout && (uintptr_t)C % 16 == 0 &&
+        M >= 32768) {
+        // square blocks over many rows (dh += sum_b dP_b W_b at H = 128 / 256): one residual GEMM per block on the wave-specialised edge-tile
+        // kernels (W_b in registers, A_b split once per tile) - C is read and written once per block (2.5 x this kernel's bytes) and it is
+        // still ahead: 0.18 -> see DESIGN 4b
+        for (int k = 0; k < num_blocks; ++k) {
+            const int rc = linear_impl(ab.blk[k], M, block_width, lda, W + (int64_t)k * block_width, ldw, nullptr, Nout, C, ldc, stream, k ? 1 : accumulate);
+            if (rc != GNNOME_OK) return rc;
+        }
+        return GNNOME_OK;
+    }
     const int n_tiles = (Nout + 127) / 128;
     const int64_t total = (M + kTileM - 1) / kTileM * n_tiles;
     GN_REQUIRE(total < (1ll << 31), "linear_blocks: too many tiles");

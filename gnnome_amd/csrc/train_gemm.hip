@@ -36,7 +36,7 @@ struct WgradA {
     int width;   // >= Ka for a single buffer
 };
 
-template <bool X16>   // X16: A is stored as bf16 (the dxe rows of the bf16-storage training step)
+template <bool X16, int ABL = 0>   // X16: A is stored as bf16 (the dxe rows of the bf16-storage training step); ABL: measurement only
 __global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, int Ka, const float* __restrict__ B,
                                                           int ldb, int Kb, int64_t R, int64_t rows_per_chunk,
                                                           float* __restrict__ partial, float* __restrict__ colsum_part) {
@@ -99,13 +99,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, 
     const unsigned char* bp = Bp + (64 * wj + (lane & 31)) * kWgColBytes + 16 * (lane >> 5);
     fetch(r_begin);
     for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
-        stage(Ap, av);
-        stage(Bp, bv);
+        if (!(ABL & 4) || r0 == r_begin) {
+            stage(Ap, av);
+            stage(Bp, bv);
+        }
         if (sums) cs += (av[0] + av[1]) + (av[2] + av[3]);
         __syncthreads();
-        if (r0 + kWgRows < r_end) fetch(r0 + kWgRows);
+        if (r0 + kWgRows < r_end && !(ABL & 1)) fetch(r0 + kWgRows);
 #pragma unroll
-        for (int s = 0; s < kWgRows / 16; ++s) {
+        for (int s = 0; s < ((ABL & 2) ? 0 : kWgRows / 16); ++s) {
             uint4 a1[2], a2[2], a3[2], b1[2], b2[2], b3[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -347,6 +349,14 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
     const dim3 grid((Ka + kWgTile - 1) / kWgTile, (Kb + kWgTile - 1) / kWgTile, (unsigned)chunks);
     if (x16)
         hipLaunchKernelGGL(k_wgrad_partial<true>, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
+    else if (tuning(kTuneGateAblation) == 1)
+        hipLaunchKernelGGL((k_wgrad_partial<false, 1>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
+    else if (tuning(kTuneGateAblation) == 2)
+        hipLaunchKernelGGL((k_wgrad_partial<false, 2>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
+    else if (tuning(kTuneGateAblation) == 4)
+        hipLaunchKernelGGL((k_wgrad_partial<false, 4>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
+    else if (tuning(kTuneGateAblation) == 5)
+        hipLaunchKernelGGL((k_wgrad_partial<false, 5>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
     else
         hipLaunchKernelGGL(k_wgrad_partial<false>, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
     GN_LAUNCH_CHECK();

@@ -76,7 +76,8 @@ def test_wgrad(rows, ka, kb):
     close(ops.wgrad(wide[:, 64:], B.to(dev())), wide[:, 64:].double().cpu().t() @ B.double(), tol=2e-5, scale=rows ** 0.5 * 4)
 
 
-@pytest.mark.parametrize("rows,width,nblocks,kb", [(5000, 128, 5, 128), (777, 64, 5, 64), (3001, 256, 5, 256), (1, 32, 3, 32), (4099, 64, 8, 128)])
+@pytest.mark.parametrize("rows,width,nblocks,kb", [(5000, 128, 5, 128), (777, 64, 5, 64), (3001, 256, 5, 256), (1, 32, 3, 32), (4099, 64, 8, 128),
+                                                   (40_001, 128, 5, 128), (33_000, 256, 5, 256)])   # from 32768 rows: one residual GEMM per block
 def test_wgrad_and_linear_over_column_blocks(rows, width, nblocks, kb):
     """gnnome_wgrad_blocks_f32 / gnnome_linear_blocks_f32: the concatenation-free forms equal the calls on torch.cat of the blocks
     (same kernels, same chunking: bit for bit), and the column sums are the bias gradients."""
