@@ -2,6 +2,7 @@
 // backward of the score predictor tail and of the gated aggregation, and two tiny helpers for the encoders.
 // The backward of the path is restated in gnnome_amd/train.py (autograd of models/full_graph.py:22-30 as
 // driven by train.py:138-145, 328-330); each kernel's contract is in include/gnnome_hip.h.
+#include <algorithm>
 #include "gemm_tile.h"
 
 namespace gnnome {
@@ -156,6 +157,203 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, 
             for (int k = 0; k < 8; ++k) t += red[k * kWgTile + tid];
             colsum_part[(int64_t)blockIdx.z * Ka + i0 + tid] = t;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same product for operands that are whole multiples of 256 columns wide (H = 256: dW3 = dxe^T e over 2.5M+ rows, the
+// [5H, H] projection gradient): one workgroup = one 256 x 256 output tile, wave (wi, wj) a 128 x 128 quadrant as 4 x 4
+// accumulators (256 registers per lane: the accumulation half of the register file, one wave per SIMD).  Against the 128 x 128
+// kernel above at these widths (measured at 2.5M rows, tools/wgrad_time.py: 2.25 ms, of which 1.30 matrix work + fragment reads
+// and 1.38 loads + splits, adding up instead of overlapping) every row of A and B is fetched, split and staged ONCE, a fragment
+// read from LDS feeds four MFMA chains instead of two, and the slab pipeline is explicit: 16-row slabs, two LDS buffers, one
+// barrier per slab - a wave splits and stages slab s + 1 into the other buffer and requests slab s + 2 in the same straight-line
+// block as its 96 MFMAs on slab s, so that the scheduler can put the VALU work into the shadow of the matrix pipe.
+// Measured (tools/wgrad_time.py, wgrad_phase.py; 2.5M rows x 256 x 256): 1.68 ms (2.25), 4330 cycles per slab of which 3816 are the
+// MFMAs + fragment reads + barrier alone (39.8 cycles per MFMA; the chip holds ~1.65 GHz under this body); [250k x 1280]^T [250k x 256]:
+// 0.85 ms (1.52).
+// Column c of a 256-wide operand tile lives in slot 64 (c % 4) + c / 4; fragment f covers slots 32 f .. 32 f + 31.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kW2Tile = 256, kW2Rows = 16;
+constexpr int kW2ColBytes = 2 * kW2Rows + 16;        // one column of one bf16 plane: 16 rows + 16 bytes of pad (48 B: conflict-free b128 reads)
+constexpr int kW2Plane = kW2Tile * kW2ColBytes;      // 12 KB; A and B, three planes each = 72 KB per buffer, two buffers
+
+template <int ABL = 0>   // ABL: measurement only (1 = no re-fetch, 2 = no MFMAs, 4 = no staging)
+__global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int lda, int Ka, const float* __restrict__ B, int ldb, int Kb,
+                                                             int64_t R, int64_t rows_per_chunk, float* __restrict__ partial,
+                                                             float* __restrict__ colsum_part, long long* prof) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i0 = blockIdx.x * kW2Tile, j0 = blockIdx.y * kW2Tile;
+    const int64_t r_begin = (int64_t)blockIdx.z * rows_per_chunk, r_end = min(R, r_begin + rows_per_chunk);
+    const int wi = wave & 1, wj = wave >> 1;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int c4 = tid & 63, rr = tid >> 6;   // 64 float4 per 256-wide row; rows 4 rr .. 4 rr + 3 of the slab
+    const float* a_col = a_op.blk[0];
+    {
+        const int ca = i0 + 4 * c4, which = ca / a_op.width;
+#pragma unroll
+        for (int k = 1; k < kWgBlocks; ++k)
+            if (which == k) a_col = a_op.blk[k];
+        a_col += ca - which * a_op.width;
+    }
+    const float* b_col = B + j0 + 4 * c4;
+    const bool sums = colsum_part != nullptr && blockIdx.y == 0;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    // two register sets of slab rows: set X is staged while the loads of the slab after next land in set Y (requested a whole slab
+    // of matrix work before they are used)
+    f32x4 av0[4], bv0[4], av1[4], bv1[4];
+    long long t_bar = 0;
+    // One row of a slab into a register set.  The row index is wave-uniform (a wave stages four whole rows), so the clamp to the last
+    // row of the chunk - slabs past its end read that row and are zeroed by mask_rows - is scalar arithmetic, no branch.
+    const int rr_s = __builtin_amdgcn_readfirstlane(rr);
+    auto fetch_row = [&](int64_t r0, int t, f32x4& a_dst, f32x4& b_dst) {
+        const int64_t rc = min(r0 + 4 * rr_s + t, r_end - 1);
+        a_dst = *reinterpret_cast<const f32x4*>(a_col + rc * lda);
+        b_dst = *reinterpret_cast<const f32x4*>(b_col + rc * ldb);
+    };
+    auto fetch = [&](int64_t r0, f32x4 (&av)[4], f32x4 (&bv)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fetch_row(r0, t, av[t], bv[t]);
+    };
+    auto mask_rows = [&](int64_t r0, f32x4 (&av)[4], f32x4 (&bv)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float keep = r0 + 4 * rr + t < r_end ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                av[t][j] = keep != 0.f ? av[t][j] : 0.f;
+                bv[t][j] = keep != 0.f ? bv[t][j] : 0.f;
+            }
+        }
+    };
+    auto stage_col = [&](unsigned char* planes, const f32x4 (&v)[4], int j) {
+        uint2 p1, p2, p3;
+        tile_split4(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]}, p1, p2, p3);
+        unsigned char* d = planes + (64 * j + c4) * kW2ColBytes + 8 * rr;
+        *reinterpret_cast<uint2*>(d) = p1;
+        *reinterpret_cast<uint2*>(d + kW2Plane) = p2;
+        *reinterpret_cast<uint2*>(d + 2 * kW2Plane) = p3;
+    };
+    auto bf = [](const uint4 v) { return __builtin_bit_cast(tile_bf16x8, v); };
+    // fragment a of this wave's half: slots 32 (4 w + a) + (lane & 31), rows 8 (lane >> 5) .. + 7
+    const int frag_off_a = (128 * wi + (lane & 31)) * kW2ColBytes + 16 * (lane >> 5);
+    const int frag_off_b = (128 * wj + (lane & 31)) * kW2ColBytes + 16 * (lane >> 5);
+    constexpr int kBuf = 6 * kW2Plane;
+    // One slab: MFMAs on buffer `cur` (slab at r0), the rows of slab r0 + 16 (set S, requested a slab ago) split and staged into the other
+    // buffer one column group per accumulator column, the rows of slab r0 + 32 requested into set F first.  Straight-line: a slab past
+    // the end of the chunk is staged as zeros into a buffer nobody reads.
+    auto slab = [&](int64_t r0, int cur, f32x4 (&avS)[4], f32x4 (&bvS)[4], f32x4 (&avF)[4], f32x4 (&bvF)[4]) {
+        const unsigned char* Ac = lds2 + cur * kBuf;
+        const unsigned char* Bc = Ac + 3 * kW2Plane;
+        unsigned char* An = lds2 + (cur ^ 1) * kBuf;
+        unsigned char* Bn = An + 3 * kW2Plane;
+        mask_rows(r0 + kW2Rows, avS, bvS);
+        if (sums) cs += (avS[0] + avS[1]) + (avS[2] + avS[3]);
+        uint4 a1[4], a2[4], a3[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const unsigned char* pa = Ac + frag_off_a + 32 * a * kW2ColBytes;
+            a1[a] = *reinterpret_cast<const uint4*>(pa);
+            a2[a] = *reinterpret_cast<const uint4*>(pa + kW2Plane);
+            a3[a] = *reinterpret_cast<const uint4*>(pa + 2 * kW2Plane);
+        }
+        // the B fragments of column step b + 1 are requested BEFORE the MFMAs of step b (one wave per SIMD: nobody else hides an LDS round
+        // trip; read just in time they cost ~200 cycles three times per step - measured 60 cycles per MFMA instead of 32)
+        uint4 bq[2][3];
+        {
+            const unsigned char* pb = Bc + frag_off_b;
+            bq[0][0] = *reinterpret_cast<const uint4*>(pb);
+            bq[0][1] = *reinterpret_cast<const uint4*>(pb + kW2Plane);
+            bq[0][2] = *reinterpret_cast<const uint4*>(pb + 2 * kW2Plane);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b < 3) {
+                const unsigned char* pb = Bc + frag_off_b + 32 * (b + 1) * kW2ColBytes;
+                bq[(b + 1) & 1][0] = *reinterpret_cast<const uint4*>(pb);
+                bq[(b + 1) & 1][1] = *reinterpret_cast<const uint4*>(pb + kW2Plane);
+                bq[(b + 1) & 1][2] = *reinterpret_cast<const uint4*>(pb + 2 * kW2Plane);
+            }
+            const uint4 b1 = bq[b & 1][0], b2 = bq[b & 1][1], b3 = bq[b & 1][2];
+            // one row pair of the slab after next per column step: eight 1 KB requests at once block the wave at the CU's memory
+            // pipeline (~10 B / cycle / CU) and its MFMAs behind them - measured 4985 against 4330 cycles per slab.  (Touching the
+            // slab four or three ahead with one dword per line, so that these loads hit L2, made it slower: 5680 cycles.)
+            if (!(ABL & 1)) fetch_row(r0 + 2 * kW2Rows, b, avF[b], bvF[b]);
+            if (!(ABL & 4)) {
+                stage_col(An, avS, b);
+                stage_col(Bn, bvS, b);
+            }
+            // the four accumulators of this column step take each term in turn: with ONE wave per SIMD a chain of dependent MFMAs would
+            // leave the matrix pipe idle for the latency of each (measured: 67 cycles per MFMA instead of 32)
+            if (!(ABL & 2)) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a3[a]), bf(b1), acc[a][b], 0, 0, 0);   // smallest terms first
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[a]), bf(b3), acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2[a]), bf(b2), acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a2[a]), bf(b1), acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[a]), bf(b2), acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a1[a]), bf(b1), acc[a][b], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // nothing moves between the four column steps: the scheduler otherwise hoists every split and spills accumulators
+        }
+        long long tb = 0;
+        if (prof) tb = __builtin_readcyclecounter();
+        __syncthreads();
+        if (prof) t_bar += (long long)__builtin_readcyclecounter() - tb;
+    };
+    fetch(r_begin, av0, bv0);
+    fetch(r_begin + kW2Rows, av1, bv1);
+    mask_rows(r_begin, av0, bv0);
+    if (sums) cs += (av0[0] + av0[1]) + (av0[2] + av0[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        stage_col(lds2, av0, j);
+        stage_col(lds2 + 3 * kW2Plane, bv0, j);
+    }
+    __syncthreads();
+    const long long t_loop0 = prof ? (long long)__builtin_readcyclecounter() : 0;
+    const long long t_real0 = prof ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * kW2Rows) {
+        slab(r0, 0, av1, bv1, av0, bv0);
+        slab(r0 + kW2Rows, 1, av0, bv0, av1, bv1);   // (past the end of an odd chunk: a slab of zeros - a branch here would double the accumulators' live ranges)
+    }
+    if (prof && lane == 0) {   // measurement only: [workgroup][wave][4] = loop cycles, barrier cycles, slabs, 100 MHz ticks
+        long long* o = prof + ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + wave * 4;
+        o[0] = (long long)__builtin_readcyclecounter() - t_loop0;
+        o[1] = t_bar;
+        o[2] = (r_end - r_begin + kW2Rows - 1) / kW2Rows;
+        o[3] = (long long)__builtin_amdgcn_s_memrealtime() - t_real0;
+    }
+    float* out = partial + ((int64_t)blockIdx.z * Ka + i0) * Kb + j0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // slot 32 f + m holds column 128 (f % 2) + 4 m + f / 2 of the tile; f = 4 w + a
+                const int fa = 4 * wi + a, fb = 4 * wj + b;
+                const int i = 128 * (fa & 1) + 4 * cd_row(r, lane) + (fa >> 1), j = 128 * (fb & 1) + 4 * (lane & 31) + (fb >> 1);
+                out[(int64_t)i * Kb + j] = acc[a][b][r];
+            }
+    if (sums) {   // the four row groups of a column, added in a fixed order (the loop ended on a barrier)
+        float* red = reinterpret_cast<float*>(lds2);
+        *reinterpret_cast<f32x4*>(red + rr * kW2Tile + 4 * c4) = cs;
+        __syncthreads();
+        if (tid < kW2Tile) colsum_part[(int64_t)blockIdx.z * Ka + i0 + tid] = ((red[tid] + red[kW2Tile + tid]) + red[2 * kW2Tile + tid]) + red[3 * kW2Tile + tid];
     }
 }
 
@@ -319,9 +517,21 @@ static int64_t wgrad_chunks(int64_t rows, int Ka, int Kb, int64_t* rows_per_chun
     return rows > 0 ? (rows + rpc - 1) / rpc : 1;
 }
 
+// The 256 x 256 tile kernel: one workgroup per CU, chunks a whole number of 16-row slabs (0: the shape does not take that kernel).
+static int64_t wgrad256_chunks(int64_t rows, int Ka, int Kb, int64_t* rows_per_chunk) {
+    if (Ka % kW2Tile || Kb % kW2Tile || rows < 16384) return 0;
+    const int64_t tiles = (int64_t)(Ka / kW2Tile) * (Kb / kW2Tile);
+    int64_t ch = kNumCUs / tiles > 0 ? kNumCUs / tiles : 1;
+    int64_t rp = (rows + ch - 1) / ch;
+    rp = (rp + kW2Rows - 1) / kW2Rows * kW2Rows;
+    if (rows_per_chunk) *rows_per_chunk = rp;
+    return (rows + rp - 1) / rp;
+}
+
 extern "C" int gnnome_wgrad_workspace_bytes(int64_t rows, int Ka, int Kb, size_t* bytes_host) {
     GN_REQUIRE(bytes_host && rows >= 0 && Ka > 0 && Kb > 0, "wgrad: bad arguments");
-    *bytes_host = (size_t)wgrad_chunks(rows, Ka, Kb, nullptr) * ((size_t)Ka * Kb + Ka) * sizeof(float);   // partial tiles + partial column sums
+    const int64_t chunks = std::max(wgrad_chunks(rows, Ka, Kb, nullptr), wgrad256_chunks(rows, Ka, Kb, nullptr));
+    *bytes_host = (size_t)chunks * ((size_t)Ka * Kb + Ka) * sizeof(float);   // partial tiles + partial column sums
     return GNNOME_OK;
 }
 
@@ -345,6 +555,43 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
         return GNNOME_EWORKSPACE;
     }
     float* partial = (float*)workspace;
+    if (!x16 && wgrad256_chunks(rows, Ka, Kb, nullptr) > 0 && (a_op.width % kW2Tile == 0) && tuning(kTuneGateExperiment) != 78) {
+        // whole 256-column tiles over many rows: the 256 x 256 kernel, one workgroup per CU (fewer, longer chunks than the workspace was sized for)
+        int64_t rp = 0;
+        const int64_t ch = wgrad256_chunks(rows, Ka, Kb, &rp);
+        const size_t need2 = (size_t)ch * ((size_t)Ka * Kb + Ka) * sizeof(float);
+        if (workspace_bytes < need2) {
+            set_error("wgrad: workspace %zu < %zu bytes", workspace_bytes, need2);
+            return GNNOME_EWORKSPACE;
+        }
+        float* cpart = colsum ? partial + (size_t)ch * Ka * Kb : nullptr;
+#define GN_W256(ABLV)                                                                                                                        \
+    {                                                                                                                                       \
+        static bool attr_set = false;                                                                                                       \
+        if (!attr_set) {                                                                                                                    \
+            GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad256_partial<ABLV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       12 * kW2Plane));                                                                                     \
+            attr_set = true;                                                                                                                \
+        }                                                                                                                                   \
+        hipLaunchKernelGGL(k_wgrad256_partial<ABLV>, dim3(Ka / kW2Tile, Kb / kW2Tile, (unsigned)ch), dim3(256), 12 * kW2Plane, s, a_op, lda, \
+                           Ka, B, ldb, Kb, rows, rp, partial, cpart, gate_profile_buffer());                                                \
+    }
+        switch (tuning(kTuneGateAblation)) {
+            case 1: GN_W256(1); break;
+            case 2: GN_W256(2); break;
+            case 4: GN_W256(4); break;
+            case 5: GN_W256(5); break;
+            default: GN_W256(0); break;
+        }
+#undef GN_W256
+        GN_LAUNCH_CHECK();
+        const int64_t elems2 = (int64_t)Ka * Kb;
+        const int cb2 = (int)((elems2 + 63) / 64), sb2 = colsum ? (Ka + 63) / 64 : 0;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(cb2 + sb2)), dim3(256), 0, s, (const float*)partial, elems2, (int)ch, C, ldc, Kb, cb2,
+                           (const float*)cpart, Ka, colsum);
+        GN_LAUNCH_CHECK();
+        return GNNOME_OK;
+    }
     float* colsum_part = colsum ? partial + (size_t)chunks * Ka * Kb : nullptr;
     const dim3 grid((Ka + kWgTile - 1) / kWgTile, (Kb + kWgTile - 1) / kWgTile, (unsigned)chunks);
     if (x16)

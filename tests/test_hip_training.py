@@ -65,7 +65,8 @@ def test_colsum_and_bn_kernels(rows, H):
     close(ops.relu_bwd(dy.to(dev()), x.to(dev())), dy.double() * (x.double() > 0))
 
 
-@pytest.mark.parametrize("rows,ka,kb", [(1000, 64, 64), (70_001, 640, 128), (5000, 32, 64), (4097, 16, 4), (300, 128, 16), (9000, 1280, 256)])
+@pytest.mark.parametrize("rows,ka,kb", [(1000, 64, 64), (70_001, 640, 128), (5000, 32, 64), (4097, 16, 4), (300, 128, 16), (9000, 1280, 256),
+                                        (20_011, 256, 256), (16_385, 512, 256), (50_000, 1280, 256)])   # from 16384 rows: the 256 x 256 tile kernel
 def test_wgrad(rows, ka, kb):
     g = torch.Generator().manual_seed(rows + ka)
     A, B = torch.randn(rows, ka, generator=g), torch.randn(rows, kb, generator=g)
