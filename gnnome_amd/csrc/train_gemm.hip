@@ -433,6 +433,82 @@ __global__ __launch_bounds__(256) void k_score_tail_bwd(const float* __restrict_
     }
 }
 
+// The same contract with every global access coalesced (round 3; the kernel above reads and writes a row per LANE: 0.76 ms at 1M
+// edges for 768 MB, its 4-byte stores of dz2 / u touch 64 lines per instruction).  A workgroup of 128 threads owns 128 edges per step:
+// the z1 tile comes in as 16-byte pieces of consecutive rows, is transposed through LDS (row stride HS + 1: a thread reads ITS row
+// without bank conflicts), every thread runs the two small products of its edge with W2 rows fetched by the scalar unit (the k loop
+// is uniform), and dz2, u, dz1 go back through LDS the same way.
+template <int HS>
+__global__ __launch_bounds__(128) void k_score_tail_bwd_tiles(const float* __restrict__ z1, const float* __restrict__ ds,
+                                                              const int32_t* __restrict__ srt_eid, int64_t E,
+                                                              const float* __restrict__ W2, const float* __restrict__ b2,
+                                                              const float* __restrict__ W3, float* __restrict__ dz1,
+                                                              float* __restrict__ dz2, float* __restrict__ u) {
+    constexpr int TE = 128, LZ = HS + 1, LO = 33, C4 = HS / 4;
+    __shared__ float zt[TE * LZ];   // z1 tile, later the u tile [TE][LO], later the dz1 tile
+    __shared__ float ot[TE * LO];   // dz2 tile
+    const int t = threadIdx.x;
+    const int64_t tiles = (E + TE - 1) / TE;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t p0 = tile * TE;
+        const int valid = (int)min((int64_t)TE, E - p0);
+#pragma unroll 4
+        for (int i = 0; i < C4; ++i) {   // TE * C4 pieces, 128 per pass
+            const int f = t + TE * i, row = f / C4, c4 = f % C4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < valid) v = *reinterpret_cast<const f32x4*>(z1 + (p0 + row) * HS + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zt[row * LZ + 4 * c4 + j] = v[j];
+        }
+        const int64_t p = p0 + min(t, valid - 1);
+        const float g = ds[srt_eid != nullptr ? (int64_t)srt_eid[p] : p];
+        __syncthreads();
+        float z[HS], d1[HS];
+#pragma unroll
+        for (int j = 0; j < HS; ++j) {
+            z[j] = zt[t * LZ + j];
+            d1[j] = 0.f;
+        }
+        __syncthreads();   // every row is in registers: the z tile's space becomes the u tile
+        for (int k = 0; k < 32; ++k) {
+            const float* w = W2 + k * HS;   // uniform: scalar loads
+            float a = b2[k];
+#pragma unroll
+            for (int j = 0; j < HS; ++j) a += w[j] * z[j];
+            const float z2 = fmaxf(a, 0.f);
+            const float d2 = a > 0.f ? g * W3[k] : 0.f;
+            ot[t * LO + k] = d2;
+            zt[t * LO + k] = g * z2;
+#pragma unroll
+            for (int j = 0; j < HS; ++j) d1[j] += w[j] * d2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {   // TE * 8 pieces of dz2 and of u
+            const int f = t + TE * i, row = f / 8, c4 = f % 8;
+            if (row < valid) {
+                const float* a = ot + row * LO + 4 * c4;
+                const float* b = zt + row * LO + 4 * c4;
+                *reinterpret_cast<f32x4*>(dz2 + (p0 + row) * 32 + 4 * c4) = f32x4{a[0], a[1], a[2], a[3]};
+                *reinterpret_cast<f32x4*>(u + (p0 + row) * 32 + 4 * c4) = f32x4{b[0], b[1], b[2], b[3]};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < HS; ++j) zt[t * LZ + j] = z[j] > 0.f ? d1[j] : 0.f;
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < C4; ++i) {
+            const int f = t + TE * i, row = f / C4, c4 = f % C4;
+            if (row < valid) {
+                const float* a = zt + row * LZ + 4 * c4;
+                *reinterpret_cast<f32x4*>(dz1 + (p0 + row) * HS + 4 * c4) = f32x4{a[0], a[1], a[2], a[3]};
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // gated aggregation, backward, per edge (gated_gcn_full.py:111-114,124-127).  With s = sigmoid(e'),
 //   hf_i = sum s A2h[src] / (sum s + eps)  =>  d s_p (forward part)  = Tf[dst] * A2h[src] - Uf[dst]
@@ -656,6 +732,17 @@ extern "C" int gnnome_score_tail_bwd_f32(const float* z1, const float* dscore, c
     GN_REQUIRE(z1 && dscore && W2 && b2 && W3 && dz1 && dz2 && u, "score_tail_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(grid_for_items(num_edges)), block(256);
+    if (tuning(kTuneGateExperiment) != 79 && (hidden_edge_scores == 32 || hidden_edge_scores == 64) && (uintptr_t)z1 % 16 == 0 &&
+        (uintptr_t)dz1 % 16 == 0 && (uintptr_t)dz2 % 16 == 0 && (uintptr_t)u % 16 == 0) {   // (79: the row-per-lane kernel, for A/B runs)
+        const int64_t tiles = (num_edges + 127) / 128;
+        const dim3 g2((unsigned)std::min<int64_t>(tiles, (int64_t)kNumCUs * 3));
+        if (hidden_edge_scores == 32)
+            hipLaunchKernelGGL(k_score_tail_bwd_tiles<32>, g2, dim3(128), 0, s, z1, dscore, srt_eid, num_edges, W2, b2, W3, dz1, dz2, u);
+        else
+            hipLaunchKernelGGL(k_score_tail_bwd_tiles<64>, g2, dim3(128), 0, s, z1, dscore, srt_eid, num_edges, W2, b2, W3, dz1, dz2, u);
+        GN_LAUNCH_CHECK();
+        return GNNOME_OK;
+    }
     switch (hidden_edge_scores) {
         case 32: hipLaunchKernelGGL(k_score_tail_bwd<32>, grid, block, 0, s, z1, dscore, srt_eid, num_edges, W2, b2, W3, dz1, dz2, u); break;
         case 64: hipLaunchKernelGGL(k_score_tail_bwd<64>, grid, block, 0, s, z1, dscore, srt_eid, num_edges, W2, b2, W3, dz1, dz2, u); break;

@@ -195,7 +195,7 @@ def test_edge_sized_residual_gemm(H):
 
 @pytest.mark.parametrize("hs", [32, 64])
 def test_score_tail_bwd_and_saved_z1(hs):
-    n, e, H = 300, 2000, 64
+    n, e, H = 300, 2000 + hs + 3, 64   # (a ragged last 128-edge tile)
     src, dst, gv, cv = _views(n, e, hs)
     g = torch.Generator().manual_seed(hs)
     z1 = torch.relu(torch.randn(e, hs, generator=g))
@@ -211,6 +211,13 @@ def test_score_tail_bwd_and_saved_z1(hs):
     close(ops.wgrad(dz2, z1.to(dev())), W2r.grad, tol=2e-5, scale=50.0)
     close(ops.colsum2(dz2)[0], b2r.grad, tol=2e-5, scale=50.0)
     close(ops.colsum2(u)[0], W3r.grad, tol=2e-5, scale=50.0)
+    try:   # the row-per-lane kernel behind the same entry point (tuning key 4 = 79)
+        ops.set_tuning(4, 79)
+        old = ops.score_tail_bwd(z1.to(dev()), ds.to(dev()), gv, W2.to(dev()), b2.to(dev()), W3.to(dev()))
+    finally:
+        ops.set_tuning(4, 0)
+    for a, b in zip((dz1, dz2, u), old):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
     # the forward scorer hands back relu(z1) when asked
     e_t, PQ, W1 = torch.randn(e, H, generator=g), torch.randn(n, 2 * hs, generator=g), torch.randn(hs, 3 * H, generator=g) / H ** 0.5
     z1_out = torch.zeros(e, hs, device=dev())
