@@ -69,6 +69,8 @@ SIGNATURES = {
     "gnnome_bn_bwd_dgrad_x16": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_agg_edge_bwd_stats_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_agg_edge_bwd_stats_x16": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gnnome_bn_bwd_terms_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p],
+    "gnnome_pack_layer_f32": [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p],
     "gnnome_bn_train_finish_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _i, _p, _p, _p, _p, _p],
     "gnnome_gate_center_f32": [_p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p],
     "gnnome_greedy_walks_workspace_bytes": [_l, _i, ctypes.POINTER(_sz)],
@@ -79,7 +81,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

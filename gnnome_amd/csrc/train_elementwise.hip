@@ -700,3 +700,95 @@ extern "C" int gnnome_segment_sum2_x16(const uint16_t* X, int width, const int32
                                        int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream) {
     return segment_sum2_impl(X, true, width, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, stream);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small per-channel / per-weight bookkeeping of the training step, each in ONE launch instead of several torch operators
+// (the step replays ~480 launches from a hipGraph; every one of these cost a graph node of a few microseconds).
+namespace gnnome {
+// BatchNorm backward, the three per-channel vectors between the statistics pass and the apply pass (train.py `_bn_bwd`, one rank):
+// s2h = rstd * s2,  c1 = s1 / rows,  c2 = s2h / rows   (the same fp32 operations torch performs for them)
+__global__ __launch_bounds__(256) void k_bn_bwd_terms(const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ rstd,
+                                                      float inv_rows, int H, float* __restrict__ s2h, float* __restrict__ c1, float* __restrict__ c2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    const float t = rstd[c] * s2[c];
+    s2h[c] = t;
+    c1[c] = s1[c] * inv_rows;   // (torch divides a tensor by a host scalar as a product with its fp32 reciprocal)
+    c2[c] = t * inv_rows;
+}
+
+struct PackLayer {
+    const float* w[5];   // A_1, A_2, A_3, B_1, B_2 weights [H,H]
+    const float* b[5];   // their biases [H]
+    const float* w3;     // B_3 weight [H,H]
+    const float* b3;     // B_3 bias [H]
+};
+// Wcat[5H,H] = the five weights stacked, bcat[5H] = the five biases (B_2's plus B_3's: the gate adds both), WcatT[H,5H] and W3T[H,H]
+// the transposes the backward's data-gradient products read (gated_gcn_full.py:91-97 as one projection, train.py `_cat_layer`)
+__global__ __launch_bounds__(256) void k_pack_layer(PackLayer p, int H, float* __restrict__ Wcat, float* __restrict__ bcat,
+                                                    float* __restrict__ WcatT, float* __restrict__ W3T) {
+    __shared__ float tile[32][33];
+    const int blocks_per_mat = (H / 32) * (H / 32);
+    const int mat = blockIdx.x / blocks_per_mat, blk = blockIdx.x % blocks_per_mat;   // mat 0..4: the stacked weights, 5: B_3
+    const int r0 = (blk / (H / 32)) * 32, c0 = (blk % (H / 32)) * 32;
+    const float* src = p.w[0];
+#pragma unroll
+    for (int k = 1; k < 5; ++k)
+        if (mat == k) src = p.w[k];
+    if (mat == 5) src = p.w3;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i;
+        const float v = src[(int64_t)r * H + c0 + tx];
+        tile[ty + 8 * i][tx] = v;
+        if (mat < 5) Wcat[((int64_t)mat * H + r) * H + c0 + tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i;   // row of the transpose
+        const float v = tile[tx][ty + 8 * i];
+        if (mat < 5) WcatT[(int64_t)c * (5 * H) + mat * H + r0 + tx] = v;
+        else W3T[(int64_t)c * H + r0 + tx] = v;
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 5 * H; i += 256) {
+            const int k = i / H, c = i % H;
+            const float* bsrc = p.b[0];
+#pragma unroll
+            for (int q = 1; q < 5; ++q)
+                if (k == q) bsrc = p.b[q];
+            bcat[i] = k == 4 ? bsrc[c] + p.b3[c] : bsrc[c];
+        }
+}
+}  // namespace gnnome
+
+extern "C" int gnnome_bn_bwd_terms_f32(const float* s1, const float* s2, const float* rstd, int64_t rows, int hidden, float* s2h, float* c1,
+                                       float* c2, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(s1 && s2 && rstd && s2h && c1 && c2 && rows >= 1 && hidden >= 1, "bn_bwd_terms: bad arguments");
+    hipLaunchKernelGGL(k_bn_bwd_terms, dim3((hidden + 255) / 256), dim3(256), 0, (hipStream_t)stream, s1, s2, rstd, 1.0f / (float)rows, hidden, s2h, c1, c2);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_pack_layer_f32(const float* const* weights5, const float* const* biases5, const float* B3_weight, const float* B3_bias,
+                                     int hidden, float* Wcat, float* bcat, float* WcatT, float* W3T, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(weights5 && biases5 && B3_weight && B3_bias && Wcat && bcat && WcatT && W3T && hidden >= 32 && hidden % 32 == 0,
+               "pack_layer: bad arguments (hidden must be a multiple of 32)");
+    PackLayer p = {};
+    for (int k = 0; k < 5; ++k) {
+        GN_REQUIRE(weights5[k] && biases5[k], "pack_layer: null weight %d", k);
+        p.w[k] = weights5[k];
+        p.b[k] = biases5[k];
+    }
+    p.w3 = B3_weight;
+    p.b3 = B3_bias;
+    const int blocks = 6 * (hidden / 32) * (hidden / 32);
+    hipLaunchKernelGGL(k_pack_layer, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, hidden, Wcat, bcat, WcatT, W3T);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}

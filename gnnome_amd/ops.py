@@ -516,6 +516,30 @@ def bn_train_finish(moments, weight, bias, running_mean, running_var, num_batche
     return mean, rstd, scale, shift
 
 
+def bn_bwd_terms(s1, s2, rstd, rows):
+    """(rstd * s2, s1 / rows, rstd * s2 / rows) in one launch: the per-channel vectors of BatchNorm's backward (one rank)."""
+    H = s1.numel()
+    s2h, c1, c2 = (torch.empty(H, dtype=torch.float32, device=s1.device) for _ in range(3))
+    _call("gnnome_bn_bwd_terms_f32", s1.device, _ptr(s1), _ptr(s2), _ptr(rstd), int(rows), H, _ptr(s2h), _ptr(c1), _ptr(c2))
+    return s2h, c1, c2
+
+
+def pack_layer(weights5, biases5, B3_weight, B3_bias):
+    """(Wcat[5H,H], bcat[5H], WcatT[H,5H], W3T[H,H]) of one SymGatedGCN layer in one launch (see gnnome_pack_layer_f32)."""
+    H, dev = B3_weight.shape[0], B3_weight.device
+    ws = [_dense(w.detach(), "pack_layer.weight") for w in weights5]
+    bs = [_dense(b.detach(), "pack_layer.bias") for b in biases5]
+    w3, b3 = _dense(B3_weight.detach(), "pack_layer.B3_weight"), _dense(B3_bias.detach(), "pack_layer.B3_bias")
+    wt = (ctypes.c_void_p * 5)(*[w.data_ptr() for w in ws])
+    bt = (ctypes.c_void_p * 5)(*[b.data_ptr() for b in bs])
+    Wcat = torch.empty((5 * H, H), dtype=torch.float32, device=dev)
+    bcat = torch.empty(5 * H, dtype=torch.float32, device=dev)
+    WcatT = torch.empty((H, 5 * H), dtype=torch.float32, device=dev)
+    W3T = torch.empty((H, H), dtype=torch.float32, device=dev)
+    _call("gnnome_pack_layer_f32", dev, wt, bt, _ptr(w3), _ptr(b3), H, _ptr(Wcat), _ptr(bcat), _ptr(WcatT), _ptr(W3T))
+    return Wcat, bcat, WcatT, W3T
+
+
 def bn_relu_res(x, scale, shift, res, out=None):
     (x, x16), res = _act(x, "bn_relu_res.x"), _dense(res, "bn_relu_res.res")
     out = torch.empty_like(res) if out is None else _dense(out, "bn_relu_res.out")

@@ -65,10 +65,16 @@ def dropout_mask(rows, cols, p, device):
     return torch.empty((rows, cols), dtype=torch.float32, device=device).bernoulli_(1.0 - p).div_(1.0 - p)
 
 
-def _cat_layer(conv):
-    Wcat = torch.cat([conv.A_1.weight, conv.A_2.weight, conv.A_3.weight, conv.B_1.weight, conv.B_2.weight], 0).detach().contiguous()
+def _cat_layer(conv, ops=None):
+    """(Wcat, bcat, WcatT, W3T): the stacked projection weight / bias of a layer and the two transposes its backward reads.  One
+    launch where the backend packs them (gnnome_pack_layer_f32), otherwise torch operators (the transposes then come lazily: None)."""
+    lins = (conv.A_1, conv.A_2, conv.A_3, conv.B_1, conv.B_2)
+    H = conv.B_3.weight.shape[0]
+    if ops is not None and hasattr(ops, "pack_layer") and H % 32 == 0 and conv.B_3.weight.is_cuda:
+        return ops.pack_layer([m.weight for m in lins], [m.bias for m in lins], conv.B_3.weight, conv.B_3.bias)
+    Wcat = torch.cat([m.weight for m in lins], 0).detach().contiguous()
     bcat = torch.cat([conv.A_1.bias, conv.A_2.bias, conv.A_3.bias, conv.B_1.bias, conv.B_2.bias + conv.B_3.bias], 0).detach().contiguous()
-    return Wcat, bcat
+    return Wcat, bcat, None, None
 
 
 def _roles(transposed):
@@ -113,12 +119,15 @@ def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out, stats=None, 
     first n_once rows only (the owned ones)."""
     ops = sh.ops
     s1, s2 = ops.bn_bwd_stats(dy, x, scale, shift, mean) if stats is None else stats   # (stats: gathered by the producer of dy)
-    s2h = rstd * s2                                     # sum dy*m*xhat
-    t1, t2 = sh.sum_ranks([s1, s2h])
+    if sh.world == 1 and hasattr(ops, "bn_bwd_terms"):
+        s2h, c1, c2 = ops.bn_bwd_terms(s1, s2, rstd, rows)   # the three vectors below in one launch
+    else:
+        s2h = rstd * s2                                     # sum dy*m*xhat
+        t1, t2 = sh.sum_ranks([s1, s2h])
+        c1, c2 = (t1 / rows).contiguous(), (t2 / rows).contiguous()
     if not apply:   # the caller fuses the apply pass into its consumer (ops.bn_bwd_dgrad): hand back the two mean terms
-        return s2h, s1, (t1 / rows).contiguous(), (t2 / rows).contiguous()
-    ops.bn_bwd_apply(dy[:n_once], x[:n_once], scale, shift, scale, (t1 / rows).contiguous(), (t2 / rows).contiguous(), mean, rstd,
-                     out=out[:n_once])
+        return s2h, s1, c1, c2
+    ops.bn_bwd_apply(dy[:n_once], x[:n_once], scale, shift, scale, c1, c2, mean, rstd, out=out[:n_once])
     if n_once < x.shape[0]:
         zero = torch.zeros_like(mean)
         ops.bn_bwd_apply(dy[n_once:], x[n_once:], scale, shift, scale, zero, zero, mean, rstd, out=out[n_once:])
@@ -161,7 +170,7 @@ class _TrainStep(torch.autograd.Function):
                        d(model.linear2_edge.bias), gather=views.srt_eid, rows=e_local)
         saved = []
         for li, conv in enumerate(model.gnn.convs):
-            Wcat, bcat = _cat_layer(conv)
+            Wcat, bcat, WcatT, W3T = _cat_layer(conv, ops)
             if li > 0:
                 sh.halo_start(h)        # layer 0's halo rows come straight from the input features
             P = new(n_local, 5 * H)
@@ -202,7 +211,7 @@ class _TrainStep(torch.autograd.Function):
                 mask = dropout_mask(n_own, H, conv.dropout, x.device)
                 h_next[:n_own].copy_(ops.mul23(h_next[:n_own], mask, mask)[0])
             saved.append(dict(h=h, P=P, e=e, xe=xe, e_new=e_new, mean_e=mean_e, rstd_e=rstd_e, v=v, hf=hf, rdf=rdf, hb=hb, rdb=rdb,
-                              mean_h=mean_h, rstd_h=rstd_h, mask=mask, Wcat=Wcat, sc_e=sc_e, sh_e=sh_e, sc_h=sc_h, sh_h=sh_h))
+                              mean_h=mean_h, rstd_h=rstd_h, mask=mask, Wcat=Wcat, WcatT=WcatT, W3T=W3T, sc_e=sc_e, sh_e=sh_e, sc_h=sc_h, sh_h=sh_h))
             h, e = h_next, e_new
 
         pred = model.predictor
@@ -300,7 +309,7 @@ class _TrainStep(torch.autograd.Function):
                 dxe = torch.empty_like(de)
                 _, g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = ops.ln_bwd(de, s["xe"], d(conv.bn_e.weight), d(conv.bn_e.bias), out=dxe)
             else:
-                W3t = d(conv.B_3.weight).t().contiguous()
+                W3t = s["W3T"] if s["W3T"] is not None else d(conv.B_3.weight).t().contiguous()
                 if hasattr(ops, "bn_bwd_dgrad") and ops.can_fuse_bn_bwd_dgrad(de, W3t, s["xe"]):
                     # BatchNorm backward and d e_in = d e' + dxe W3 in one pass over the edges (dxe computed by the load waves)
                     g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"], c1, c2 = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
@@ -315,7 +324,8 @@ class _TrainStep(torch.autograd.Function):
                                                                            sh.e_global, e_own, dxe, stats=stats_e)
             g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"])
             if s["sc_e"] is None or W3t is not None:
-                ops.linear(dxe, d(conv.B_3.weight).t().contiguous(), None, out=de, accumulate=True)   # d e_in = d e' + dxe W3
+                ops.linear(dxe, s["W3T"] if s["W3T"] is not None else d(conv.B_3.weight).t().contiguous(), None, out=de,
+                           accumulate=True)   # d e_in = d e' + dxe W3
             if hasattr(ops, "segment_sum2"):   # both gathers' transposes in one launch (the out-edge pass then hits L2)
                 dB2, dB1 = ops.segment_sum2(dxe, views, n_local)
             else:
@@ -324,7 +334,7 @@ class _TrainStep(torch.autograd.Function):
             parts = [None] * 5
             parts[r["A1"]], parts[r["A2"]], parts[r["A3"]], parts[r["B1"]], parts[r["B2"]] = dv, sum_out, sum_in, dB1, dB2
             names = ("A_1", "A_2", "A_3", "B_1", "B_2")
-            WcatT = s["Wcat"].t().contiguous()
+            WcatT = s["WcatT"] if s["WcatT"] is not None else s["Wcat"].t().contiguous()
             if hasattr(ops, "wgrad_blocks") and ops.can_use_blocks(parts):
                 # the five [N,H] gradients stay where their kernels left them: weight gradients, bias gradients (column sums of
                 # the same slabs) and dh += dP Wcat read them as column blocks

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 7
+#define GNNOME_ABI_VERSION 8
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -405,6 +405,17 @@ int gnnome_bn_train_finish_f32(const float* d1, const float* d2, const float* ce
                                const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                float momentum, float eps, int updates, float* mean, float* rstd, float* scale, float* shift,
                                void* stream);
+/* BatchNorm backward, one rank: the per-channel vectors between the statistics pass and the apply pass in one launch -
+ * s2h = rstd * s2, c1 = s1 / rows, c2 = s2h / rows (what torch autograd derives for nn.BatchNorm1d in train mode,
+ * gated_gcn_full.py:106,119,132; the reference spends three elementwise operators on them). */
+int gnnome_bn_bwd_terms_f32(const float* s1, const float* s2, const float* rstd, int64_t rows, int hidden, float* s2h, float* c1,
+                            float* c2, void* stream);
+/* One layer's weights as the kernels read them, in one launch (gated_gcn_full.py:91-97: the five node projections run as ONE
+ * product with the stacked weight): Wcat[5H,H] = A_1|A_2|A_3|B_1|B_2 weights stacked, bcat[5H] = their biases with B_3's added
+ * to B_2's, WcatT[H,5H] and W3T[H,H] = the transposes the backward's data-gradient products read.  weights5 / biases5 are HOST
+ * arrays of five device pointers; hidden a multiple of 32. */
+int gnnome_pack_layer_f32(const float* const* weights5, const float* const* biases5, const float* B3_weight, const float* B3_bias,
+                          int hidden, float* Wcat, float* bcat, float* WcatT, float* W3T, void* stream);
 /* center[:] = B1h[srt_src[0],:] + B2h[srt_dst[0],:] + e[0,:] W3^T: row 0 of the raw gate, the shift of its batch statistics. */
 int gnnome_gate_center_f32(const float* e, int64_t num_edges, int hidden, const float* B1h, const float* B2h, int ld_node,
                            const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw, float* center, void* stream);

@@ -65,6 +65,25 @@ def test_colsum_and_bn_kernels(rows, H):
     close(ops.relu_bwd(dy.to(dev()), x.to(dev())), dy.double() * (x.double() > 0))
 
 
+@pytest.mark.parametrize("hidden", [64, 128, 256])
+def test_pack_layer_and_bn_bwd_terms_equal_the_torch_operators(hidden):
+    """gnnome_pack_layer_f32 / gnnome_bn_bwd_terms_f32: one launch each for what train.py otherwise builds from torch.cat, add,
+    transpose-copies, a product and two divisions - the same bits."""
+    from gnnome_amd.layers import SymGatedGCN
+    torch.manual_seed(hidden)
+    conv = SymGatedGCN(hidden, hidden, "batch").to(dev())
+    lins = (conv.A_1, conv.A_2, conv.A_3, conv.B_1, conv.B_2)
+    Wcat, bcat, WcatT, W3T = ops.pack_layer([m.weight for m in lins], [m.bias for m in lins], conv.B_3.weight, conv.B_3.bias)
+    want_W = torch.cat([m.weight for m in lins], 0).detach()
+    assert torch.equal(Wcat, want_W) and torch.equal(WcatT, want_W.t().contiguous()) and torch.equal(W3T, conv.B_3.weight.detach().t().contiguous())
+    assert torch.equal(bcat, torch.cat([conv.A_1.bias, conv.A_2.bias, conv.A_3.bias, conv.B_1.bias, conv.B_2.bias + conv.B_3.bias]).detach())
+    g = torch.Generator().manual_seed(hidden + 1)
+    s1, s2, rstd = (torch.randn(hidden, generator=g).to(dev()) for _ in range(3))
+    rows = 1_000_003
+    s2h, c1, c2 = ops.bn_bwd_terms(s1, s2, rstd, rows)
+    assert torch.equal(s2h, rstd * s2) and torch.equal(c1, s1 / rows) and torch.equal(c2, (rstd * s2) / rows)
+
+
 @pytest.mark.parametrize("rows,ka,kb", [(1000, 64, 64), (70_001, 640, 128), (5000, 32, 64), (4097, 16, 4), (300, 128, 16), (9000, 1280, 256),
                                         (20_011, 256, 256), (16_385, 512, 256), (50_000, 1280, 256)])   # from 16384 rows: the 256 x 256 tile kernel
 def test_wgrad(rows, ka, kb):
