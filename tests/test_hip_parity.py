@@ -122,7 +122,7 @@ def test_encode_wide_hidden_ne_and_features():
 
 
 @pytest.mark.parametrize("m,k,nout", [(1000, 64, 320), (333, 128, 640), (129, 256, 1280), (128, 64, 64), (5, 128, 32), (2000, 128, 96),
-                                      (40_000, 128, 640), (33_333, 64, 320), (70_001, 128, 128),
+                                      (40_000, 128, 640), (33_333, 64, 320), (70_001, 128, 128), (1, 128, 256), (3, 128, 640), (31, 128, 1280),
                                       (20_001, 256, 1280), (9000, 256, 128)])   # K = 256 from 8192 rows: edge_gate_pl256.hip mode 4
 def test_linear(m, k, nout):
     g = torch.Generator().manual_seed(m + k + nout)
