@@ -16,6 +16,7 @@ ap.add_argument("--hidden", type=int, default=128)
 ap.add_argument("--edges", type=int, default=1_000_000)
 ap.add_argument("--ablation", type=int, default=0)
 ap.add_argument("--variant", type=int, default=0, help="gnnome_set_tuning(0, v): 0 = k_edge_gate_bf, 7 = k_edge_gate_pl (slot 2 = waiting for the other compute waves)")
+ap.add_argument("--linear", action="store_true", help="profile the node projection [N,128] -> [N,640] on the same kernel (mode 4) instead of the gate; --edges = rows")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 n, e, H = a.edges // 10, a.edges, a.hidden
@@ -29,14 +30,20 @@ W3 = torch.randn(H, H, device=dev, generator=gen) / H ** 0.5
 sc, sh = torch.rand(H, device=dev, generator=gen) * 0.1, torch.randn(H, device=dev, generator=gen)
 ops.set_tuning(1, a.ablation)
 ops.set_tuning(0, a.variant)
+if a.linear:
+    hrows = torch.randn(e, H, device=dev, generator=gen)
+    Wc, bc, Pout = torch.randn(5 * H, H, device=dev, generator=gen), torch.randn(5 * H, device=dev, generator=gen), torch.empty(e, 5 * H, device=dev)
+    launch = lambda: ops.linear(hrows, Wc, bc, out=Pout)  # noqa: E731
+else:
+    launch = lambda: ops.edge_gate(ee, P[:, 3 * H:4 * H], P[:, 4 * H:], views, W3, 0, sc, sh, out=out)  # noqa: E731
 for _ in range(3):
-    ops.edge_gate(ee, P[:, 3 * H:4 * H], P[:, 4 * H:], views, W3, 0, sc, sh, out=out)
+    launch()
 prof = torch.zeros(2 * 256 * 8, dtype=torch.int64, device=dev)   # [256 compute-wave records | 256 load-wave records (variant 7)]
 lib = _lib.load()
 lib.gnnome_debug_gate_profile(prof.data_ptr())
 s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
-ops.edge_gate(ee, P[:, 3 * H:4 * H], P[:, 4 * H:], views, W3, 0, sc, sh, out=out)
+launch()
 t.record()
 torch.cuda.synchronize()
 lib.gnnome_debug_gate_profile(None)
@@ -45,9 +52,10 @@ ops.set_tuning(0, 0)
 p = prof[:256 * 8].view(256, 8).cpu().double()
 lw = prof[256 * 8:].view(256, 8).cpu().double()
 tiles = p[:, 4].sum().item()
+active = int((p[:, 4] > 0).sum().item())
 names = ["wait for slot", "prologue (first fragment)", "MFMA loop", "x write-back"]
 ms = s.elapsed_time(t)
-print(f"H={H} E={e} ablation={a.ablation}: launch {ms:.4f} ms (with counters), {tiles:.0f} tiles, {tiles / 256:.1f} per workgroup")
+print(f"H={H} E={e} ablation={a.ablation}: launch {ms:.4f} ms (with counters), {tiles:.0f} tiles, {tiles / max(active, 1):.1f} per workgroup ({active} active)")
 total = 0.0
 for k, name in enumerate(names):
     per = p[:, k].sum().item() / tiles
