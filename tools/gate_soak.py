@@ -30,8 +30,42 @@ for it in range(launches):
     W3 = (torch.randn(H, H, generator=gen) / H ** 0.5).to(dev)
     sc, sh = (0.5 + torch.rand(H, generator=gen)).to(dev), torch.randn(H, generator=gen).to(dev)
     B1, B2 = P[:, 3 * H:4 * H], P[:, 4 * H:]
-    mode = it % 3
-    if mode == 0:    # the gate, in place and out of place
+    mode = it % 6
+    if mode == 3 and H == 128:   # the node projection on the plane form (mode 4 of k_edge_gate_pl): every row count, strided output
+        rows = E
+        A = (3.0 * torch.randn(rows, H, generator=gen)).to(dev)
+        nb = int(torch.randint(2, 11, (1,), generator=gen))
+        W = (torch.randn(nb * H, H, generator=gen) / H ** 0.5).to(dev)
+        b = torch.randn(nb * H, generator=gen).to(dev)
+        wide = torch.full((rows, nb * H + 64), 7.0, device=dev)
+        got = ops.linear(A, W, b, out=wide[:, 64:])
+        assert (wide[:, :64] == 7.0).all(), (it, rows, "columns outside the output written")
+        want = A.double() @ W.double().t() + b.double()
+        got = got.double()
+    elif mode == 4 and H == 128:   # dh += sum_b dP_b W_b: one residual GEMM per block (mode 2) from 32768 rows, the tile kernel below
+        rows = E if kind < 7 else E + 32768
+        blocks = [(2.0 * torch.randn(rows, H, generator=gen)).to(dev) for _ in range(5)]
+        W = (torch.randn(H, 5 * H, generator=gen) / H ** 0.5).to(dev)
+        C = torch.randn(rows, H, generator=gen).to(dev)
+        want = C.double() + torch.cat(blocks, 1).double() @ W.double().t()
+        got = ops.linear_blocks(blocks, W, C, accumulate=True).double()
+    elif mode == 5:   # score predictor's tail backward on tiles against the row-per-lane kernel
+        hs = (32, 64)[int(torch.randint(0, 2, (1,), generator=gen))]
+        z1 = torch.relu(torch.randn(E, hs, generator=gen)).to(dev)
+        ds = torch.randn(E, generator=gen).to(dev)
+        W2, b2, W3s = (torch.randn(32, hs, generator=gen) / hs ** 0.5).to(dev), torch.randn(32, generator=gen).to(dev), torch.randn(32, generator=gen).to(dev)
+        got = torch.cat(ops.score_tail_bwd(z1, ds, views, W2, b2, W3s), 1)
+        ops.set_tuning(4, 79)
+        want = torch.cat(ops.score_tail_bwd(z1, ds, views, W2, b2, W3s), 1)
+        ops.set_tuning(4, 0)
+    elif mode >= 3:   # (H = 64 draws of the modes above): the weight gradient, 256-wide operands take the 256 x 256 tile kernel from 16384 rows
+        rows = E if kind < 7 else E + 16384
+        ka = 256 * int(torch.randint(1, 4, (1,), generator=gen))
+        A = torch.randn(rows, ka, generator=gen).to(dev)
+        Bm = torch.randn(rows, 256, generator=gen).to(dev)
+        got = ops.wgrad(A, Bm).double() / rows ** 0.5
+        want = (A.double().t() @ Bm.double()) / rows ** 0.5
+    elif mode == 0:    # the gate, in place and out of place
         got = ops.edge_gate(e.clone(), B1, B2, views, W3, 0, sc, sh)
         ops.set_tuning(0, 6)
         want = ops.edge_gate(e.clone(), B1, B2, views, W3, 0, sc, sh)
@@ -45,9 +79,14 @@ for it in range(launches):
         C = torch.randn(E, H, generator=gen).to(dev)
         want = C + e @ W3.t()
         got = ops.linear(e, W3, None, out=C, accumulate=True)
-    err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+    dev_rel = (got - want).abs() / max(1.0, want.abs().max().item())
+    if mode == 5:   # relu'(a) is a step: an `a` within rounding of zero may land on either side in the two kernels - a handful of (edge, k) pairs per launch
+        flips = int((dev_rel > 2e-5).sum().item())
+        assert flips <= 400, (it, E, H, mode, flips)   # (one flipped (edge, k) moves dz2[p, k] and the whole row dz1[p, :])
+        dev_rel = dev_rel.clamp(max=2e-5) if flips else dev_rel
+    err = dev_rel.max().item()
     worst = max(worst, err)
-    assert err < 2e-5, (it, E, H, mode, err)
+    assert err < 2.5e-5, (it, E, H, mode, err)
     if it % 200 == 199:
         torch.cuda.synchronize()
         print(f"{it + 1} launches ok, worst relative deviation {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
