@@ -631,7 +631,8 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
         return GNNOME_EWORKSPACE;
     }
     float* partial = (float*)workspace;
-    if (!x16 && wgrad256_chunks(rows, Ka, Kb, nullptr) > 0 && (a_op.width % kW2Tile == 0) && tuning(kTuneGateExperiment) != 78) {
+    if (!x16 && wgrad256_chunks(rows, Ka, Kb, nullptr) > 0 && (a_op.width % kW2Tile == 0) && tuning(kTuneGateExperiment) != 78 &&
+        tuning(kTuneLinearVariant) == 0) {   // (key 4 = 78 or any non-default key 2: the 128 x 128 tile kernel, for A/B runs and cross-checks)
         // whole 256-column tiles over many rows: the 256 x 256 kernel, one workgroup per CU (fewer, longer chunks than the workspace was sized for)
         int64_t rp = 0;
         const int64_t ch = wgrad256_chunks(rows, Ka, Kb, &rp);

@@ -518,6 +518,31 @@ def test_training_step_full_size_properties():
     for k in runs[0][3]:
         assert torch.equal(runs[0][3][k], runs[1][3][k]), k
     assert runs[0][3]["gnn.convs.3.bn_e.num_batches_tracked"].item() == 2 and runs[0][3]["gnn.convs.3.bn_h.num_batches_tracked"].item() == 1
+    # the same step on the OTHER kernels behind the same entry points (round 2's streaming projection, the tile kernels for the
+    # block products and the weight gradients, the row-per-lane score-tail backward, the second-generation gate): two independent
+    # sets of kernels, each pinned against the oracle at small sizes, must tell the same story at full size
+    try:
+        ops.set_tuning(2, 5)
+        ops.set_tuning(4, 79)
+        ops.set_tuning(0, 8)
+        m = _train_model(random_state_dict(hidden, seed=5), hidden)
+        logits = m(views, x, ef)
+        loss = hip_bce(logits.squeeze(-1), y, pw)
+        loss.backward()
+        other = (logits.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
+        del m, logits, loss
+    finally:
+        ops.set_tuning(2, 0)
+        ops.set_tuning(4, 0)
+        ops.set_tuning(0, 0)
+    assert abs(other[1].item() - runs[0][1].item()) <= 1e-5 * abs(runs[0][1].item())
+    assert (torch.sigmoid(other[0]) - torch.sigmoid(runs[0][0])).abs().max().item() <= 1e-4
+    num = den = 0.0
+    for k, gk in runs[0][2].items():
+        d, s_ = (other[2][k] - gk).double(), gk.double()
+        num, den = num + float((d * d).sum()), den + float((s_ * s_).sum())
+        assert float(d.abs().max()) <= 2e-2 * max(float(s_.abs().max()), 1e-6), k   # (single tensors: relu-kink flips)
+    assert (num / den) ** 0.5 <= 1e-3
     # the step recorded into a hipGraph (what bench.py times) replays to the same bits as the eager step
     m = _train_model(random_state_dict(hidden, seed=5), hidden)
 
@@ -548,6 +573,43 @@ def test_training_step_full_size_properties():
     assert torch.equal(logits.detach(), runs[0][0]) and torch.equal(loss.detach(), runs[0][1])
     for k, p in m.named_parameters():
         assert torch.equal(p.grad, runs[0][2][k]), k
+
+
+def test_training_step_h256_at_the_configs3_shard_on_two_sets_of_kernels():
+    """One GPU's eighth of BASELINE configs[3] (N = 250k, E = 2.5M, H = 256: the width of configs[3] / [4]): the fwd + BCE + bwd step on
+    the round-3 kernels (plane form k_edge_gate_pl256 in modes 1 - 4, the 256 x 256 weight-gradient kernel, tiled score-tail backward)
+    against the same step on the kernels they replaced (streaming gate, tile GEMMs, 128 x 128 weight gradients, row-per-lane
+    score tail) - loss, probabilities and the whole gradient agree at full size."""
+    from gnnome_amd.loss import bce_loss as hip_bce
+    n, e, hidden = 250_000, 2_500_000, 256
+    gr = make_graph(n, e, seed=2)
+    views = gnnome_amd.graph.views_for((gr["src"], gr["dst"], n), dev())
+    x, ef, y, pw = ops.degree_features(views), gr["e"].to(dev()), gr["y"].to(dev()), gr["pos_weight"].to(dev())
+
+    def step():
+        m = _train_model(random_state_dict(hidden, seed=6), hidden)
+        logits = m(views, x, ef)
+        loss = hip_bce(logits.squeeze(-1), y, pw)
+        loss.backward()
+        return logits.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
+    new = step()
+    try:
+        ops.set_tuning(2, 5)
+        ops.set_tuning(4, 79)
+        ops.set_tuning(0, 9)
+        old = step()
+    finally:
+        ops.set_tuning(2, 0)
+        ops.set_tuning(4, 0)
+        ops.set_tuning(0, 0)
+    assert torch.isfinite(new[1]) and abs(old[1].item() - new[1].item()) <= 1e-5 * abs(new[1].item())
+    assert (torch.sigmoid(old[0]) - torch.sigmoid(new[0])).abs().max().item() <= 1e-4
+    num = den = 0.0
+    for k, gk in new[2].items():
+        d, s_ = (old[2][k] - gk).double(), gk.double()
+        num, den = num + float((d * d).sum()), den + float((s_ * s_).sum())
+        assert torch.isfinite(gk).all() and float(d.abs().max()) <= 2e-2 * max(float(s_.abs().max()), 1e-6), k
+    assert (num / den) ** 0.5 <= 1e-3
 
 
 @pytest.mark.parametrize("rows,H", [(777, 64), (40_003, 128), (300, 256), (5000, 16)])
