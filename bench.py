@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py - edges/sec of one full SymGatedGCNModel forward (encoders + 8 layers + scorer).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|10m|parity64|c4shard|c4|c5] [--kind banded|uniform]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|10m|parity64|c4shard|c4|c5|c5shard|c5quarter] [--kind banded|uniform]
                     [--mode infer|train]
 
 One "step" = one `model(graph, x, e)` on a synthetic assembly graph already resident in HBM (graph views prebuilt, as a
@@ -35,6 +35,8 @@ WORKLOADS = {
     "c4shard": (250_000, 2_500_000, 256),      # one GPU's eighth of configs[3]
     "c4": (2_000_000, 20_000_000, 256),        # BASELINE.json configs[3] (8 GPUs; 20.5 GB of edge state: fits one GPU as well)
     "c5": (5_000_000, 50_000_000, 256),        # BASELINE.json configs[4] (8-GPU training step)
+    "c5shard": (625_000, 6_250_000, 256),      # one GPU's eighth of configs[4]: what a rank of the 8-GPU training step holds
+    "c5quarter": (1_250_000, 12_500_000, 256), # a quarter of configs[4] (two ranks' shares: `--gpus 2 --one-gpu-gloo --mode train`)
     # SURVEY.md 8d's substitute for configs[0]: an E. coli-sized graph with the SHIPPED checkpoint (tests/golden/weights.pt,
     # H = 64) in the default "auto" arithmetic - what a user of inference.py runs: layer 0 (bn_e gain 135) goes through the
     # reference-order fp32 VALU kernels, layers 1-7 through the bf16x6 matrix-core kernels
@@ -302,6 +304,16 @@ def _single_gpu_forward(gnnome_amd, ops, make_graph, random_state_dict, workload
             "steps": steps, "hbm_roofline_frac_whole_fwd": algorithmic_bytes(n, e, hidden) / (ms * 1e-3) / HBM_PEAK}
 
 
+def _memory_record(dev, edges_local, hidden):
+    """Peak device memory of this process since the last reset: what the kernels' tensors took (allocated) and what torch's
+    caching allocator held from the driver for them (reserved >= allocated: rounding + fragmentation), and both per local edge."""
+    alloc, reserved = torch.cuda.max_memory_allocated(dev), torch.cuda.max_memory_reserved(dev)
+    free, total = torch.cuda.mem_get_info(dev)
+    return {"peak_memory_GB": alloc / 1e9, "peak_reserved_GB": reserved / 1e9, "device_total_GB": total / 1e9,
+            "bytes_per_local_edge_allocated": alloc / max(edges_local, 1), "bytes_per_local_edge_reserved": reserved / max(edges_local, 1),
+            "local_edges": edges_local, "hidden": hidden}
+
+
 def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry, dropout, storage="fp32"):
     """configs[2]'s shape: fwd + loss + bwd + Adam on the whole graph, fp32, the step replayed from a hipGraph (a training
     loop over one graph repeats the same launch sequence; ~450 library launches + a few hundred small torch ops cost
@@ -330,17 +342,25 @@ def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry
         opt.step()
         return loss.detach()
 
+    # every eager step on ONE side stream (torch's allocator keeps a pool per stream: a step on a second stream would hold a
+    # second set of activations - at the configs[4] shard that is 2 x 170 GB), then the cached blocks go back to the driver
+    # before the capture allocates the step's tensors once more in the graph's private pool
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
         for _ in range(3):
             eager_step()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        t0 = time.perf_counter()
+        eager_step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) * 1e3
+    memory_eager = _memory_record(dev, e, hidden)
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eager_step()
-    torch.cuda.synchronize()
-    eager_ms = (time.perf_counter() - t0) * 1e3
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         static_loss = eager_step()
@@ -359,6 +379,7 @@ def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry
                      else "train.py:138-145 + :328-330: train-mode forward (batch-statistic BatchNorm) + BCEWithLogits(pos_weight)")
                     + f" + backward + Adam, fp32 arithmetic, activation storage {storage}, dropout {dropout or 0}, whole step replayed from one hipGraph",
             "eager_ms_per_step": eager_ms, "dtype": "f32", "activation_storage": storage, "loss": float(loss),
+            "memory": {"eager_step": memory_eager, "hipgraph_step": _memory_record(dev, e, hidden)},
             "hbm_roofline_frac_3xBfwd": passes * 3 * b_fwd / (ms * 1e-3) / HBM_PEAK, "mfma_f32_frac_3xFfwd": passes * 3 * f_fwd / (ms * 1e-3) / MFMA_F32_PEAK}
 
 
@@ -412,7 +433,8 @@ def _partitioned_train_record(gnnome_amd, gdist, ops, g, n, e, hidden, dev, rank
         "hbm_roofline_frac_3xBfwd": 3 * b_fwd / (ms * 1e-3) / (world * HBM_PEAK), "mfma_f32_frac_3xFfwd": 3 * f_fwd / (ms * 1e-3) / (world * MFMA_F32_PEAK),
         "rank0": {"owned_nodes": plan.n_own, "halo_nodes": plan.n_local - plan.n_own, "local_edges": plan.views.num_edges,
                   "owned_in_edges": plan.n_score, "rows_sent_per_layer": int(sum(plan.send_counts)),
-                  "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9},
+                  "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 1e9,
+                  "memory": _memory_record(dev, plan.views.num_edges, hidden)},
         "so_sha16": so_sha16(),
     }
 

@@ -2,6 +2,7 @@
 // backward of the score predictor tail and of the gated aggregation, and two tiny helpers for the encoders.
 // The backward of the path is restated in gnnome_amd/train.py (autograd of models/full_graph.py:22-30 as
 // driven by train.py:138-145, 328-330); each kernel's contract is in include/gnnome_hip.h.
+#include <atomic>
 #include <algorithm>
 #include "gemm_tile.h"
 
@@ -644,11 +645,14 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
         float* cpart = colsum ? partial + (size_t)ch * Ka * Kb : nullptr;
 #define GN_W256(ABLV)                                                                                                                        \
     {                                                                                                                                       \
-        static bool attr_set = false;                                                                                                       \
-        if (!attr_set) {                                                                                                                    \
+        /* the attribute is per device and per function: one flag per device ordinal (set once, outside any stream capture's first use) */  \
+        static std::atomic<bool> attr_set[64];                                                                                              \
+        int dev_ = 0;                                                                                                                       \
+        GN_HIP(hipGetDevice(&dev_));                                                                                                        \
+        if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_].load(std::memory_order_acquire)) {                                                    \
             GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad256_partial<ABLV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        12 * kW2Plane));                                                                                     \
-            attr_set = true;                                                                                                                \
+            if (dev_ >= 0 && dev_ < 64) attr_set[dev_].store(true, std::memory_order_release);                                              \
         }                                                                                                                                   \
         hipLaunchKernelGGL(k_wgrad256_partial<ABLV>, dim3(Ka / kW2Tile, Kb / kW2Tile, (unsigned)ch), dim3(256), 12 * kW2Plane, s, a_op, lda, \
                            Ka, B, ldb, Kb, rows, rp, partial, cpart, gate_profile_buffer());                                                \

@@ -20,11 +20,26 @@ inference.py:388).  This is the north_star's scheme:
 All tensor math goes through an `ops` namespace exactly like engine.run_stack: the product passes
 gnnome_amd.ops (HIP); the CPU/gloo tests pass the checker backend to exercise this host logic.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import engine
 from . import ops as hip_ops
+
+
+def force_collectives():
+    """GNNOME_FORCE_COLLECTIVES=1: a single-rank process group still ISSUES every collective of the partitioned path (halo
+    all_to_all both ways, BatchNorm statistics all_gather, BatchNorm-backward and gradient all_reduce, logits all_gather) instead
+    of taking the world == 1 shortcuts - the way a one-GPU box runs this module's RCCL calls (tests/test_hip_partition.py).
+    A one-rank collective is the identity, so the results must equal the plain path bit for bit."""
+    return os.environ.get("GNNOME_FORCE_COLLECTIVES", "0") == "1"
+
+
+def _alone(world):
+    """True when the world == 1 shortcuts apply."""
+    return world == 1 and not force_collectives()
 
 
 def split_by_incident_edges(src, dst, num_nodes, world):
@@ -39,6 +54,36 @@ def split_by_incident_edges(src, dst, num_nodes, world):
         bounds.append(max(bounds[-1], min(b, num_nodes)))
     bounds.append(num_nodes)
     return bounds
+
+
+def partition_census(src, dst, num_nodes, world, bounds=None):
+    """What PartitionedGraph.from_global would give every rank of a `world`-way destination-range partition, computed in one
+    process without a process group (planning: which world size a graph wants; tools/partition_stats.py):
+    per rank the owned nodes, local edges (incident to an owned node), owned in-edges (the ones it scores), halo rows it
+    receives and rows it sends per layer.  Pure index arithmetic over the edge list, O(E) per rank."""
+    src, dst = torch.as_tensor(src).long(), torch.as_tensor(dst).long()
+    bounds = split_by_incident_edges(src, dst, num_nodes, world) if bounds is None else list(bounds)
+    bt = torch.tensor(bounds[1:-1], device=src.device, dtype=torch.long)
+    rs, rd = torch.bucketize(src, bt, right=True), torch.bucketize(dst, bt, right=True)   # owner rank of each endpoint
+    cut = rs != rd
+    ranks = []
+    owned_in = torch.bincount(rd, minlength=world)
+    local = owned_in + torch.bincount(rs[cut], minlength=world)
+    # halo rows of rank p = distinct far endpoints of its cut edges: (p, node) pairs, counted once
+    pair = torch.cat([rd[cut] * num_nodes + src[cut], rs[cut] * num_nodes + dst[cut]])
+    pair = torch.unique(pair)
+    holder, node = pair // num_nodes, pair % num_nodes
+    owner = torch.bucketize(node, bt, right=True)
+    recv = torch.bincount(holder, minlength=world)
+    send = torch.bincount(owner, minlength=world)
+    link = torch.bincount(owner * world + holder, minlength=world * world).view(world, world)   # rows owner -> holder
+    for p in range(world):
+        ranks.append({"rank": p, "owned_nodes": bounds[p + 1] - bounds[p], "local_edges": int(local[p]), "owned_in_edges": int(owned_in[p]),
+                      "halo_rows": int(recv[p]), "rows_sent_per_layer": int(send[p]), "largest_link_rows": int(link[p].max())})
+    e = int(src.numel())
+    return {"world": world, "num_nodes": num_nodes, "num_edges": e, "bounds": bounds, "cut_edges": int(cut.sum()),
+            "cut_fraction": float(cut.sum()) / max(e, 1), "edge_replication": float(local.sum()) / max(e, 1),
+            "imbalance_local_edges": float(local.max()) * world / max(float(local.sum()), 1.0), "ranks": ranks}
 
 
 class PartitionedGraph:
@@ -101,13 +146,13 @@ class PartitionedGraph:
         # (the plan travels on `device` tensors: RCCL moves device memory only, gloo takes either)
         req_counts = torch.tensor(self.recv_counts, dtype=torch.int64, device=device)
         got_counts = torch.empty(world, dtype=torch.int64, device=device)
-        if world > 1:
+        if not _alone(world):
             all_to_all_rows(got_counts, req_counts, None, None, group)
         else:
             got_counts.copy_(req_counts)
         self.send_counts = got_counts.tolist()
         wanted = torch.empty(sum(self.send_counts), dtype=torch.int64, device=device)
-        if world > 1:
+        if not _alone(world):
             all_to_all_rows(wanted, halo.contiguous(), self.send_counts, self.recv_counts, group)
         assert wanted.numel() == 0 or (int(wanted.min()) >= lo and int(wanted.max()) < hi)
         self.send_idx = (wanted - lo).int()
@@ -119,7 +164,7 @@ class PartitionedGraph:
         the pieces are all-gathered (padded to the largest) and un-permuted with one index_select.  The map from global
         edge id to its slot in the gathered buffer is exchanged here, once."""
         world = self.world
-        if world == 1:
+        if _alone(world):
             self.score_pad, self.score_index = self.n_score, None
             return
         counts = all_gather_rows(torch.tensor([self.n_score], dtype=torch.int64, device=device), world, group).view(-1).tolist()
@@ -136,7 +181,7 @@ class PartitionedGraph:
     def assemble_logits(self, piece, group=None):
         """piece[score_pad] (this rank's owned in-edges in sorted order, tail unused) -> logits[E_global] in edge-id order,
         complete on every rank."""
-        if self.world == 1:
+        if _alone(self.world):
             raise RuntimeError("single rank: the scorer writes edge-id order itself")
         gathered = all_gather_rows(piece, self.world, group).view(-1)
         return gathered.index_select(0, self.score_index)
@@ -189,7 +234,7 @@ class HaloExchange:
 
     def start(self, h):
         p = self.part
-        if p.world == 1:
+        if _alone(p.world):
             return
         packed = self.ops.gather_rows(h, p.send_idx)
         self._keep = packed
@@ -205,7 +250,7 @@ class HaloExchange:
         (one peer's block at a time: within a block the rows are distinct, so the sum order is fixed), then
         dh[n_own:] = 0."""
         p = self.part
-        if p.world == 1:
+        if _alone(p.world):
             return
         got = torch.empty((int(p.send_idx.numel()), dh.shape[1]), dtype=torch.float32, device=dh.device)
         all_to_all_rows(got, dh[p.n_own:].contiguous(), p.send_counts, p.recv_counts, self.group)
@@ -231,6 +276,7 @@ class PartitionShard:
         if part.n_own == 0 or part.n_score == 0:
             raise NotImplementedError("a rank without owned nodes or owned in-edges (graph too small for this world size)")
         self.part, self.ops, self.group, self.world = part, ops, group, part.world
+        self.alone = _alone(part.world)     # False under GNNOME_FORCE_COLLECTIVES=1: one rank, every collective issued
         self.views = part.views
         self.n_own, self.n_local = part.n_own, part.n_local
         self.e_own, self.e_local = part.n_score, part.views.num_edges
@@ -248,7 +294,7 @@ class PartitionShard:
         self._xchg.transpose(dh)
 
     def combine_stats(self, mean, var, rows):
-        if self.world == 1:
+        if self.alone:
             return mean, var
         H = mean.numel()
         mine = torch.cat([torch.full((1,), float(rows), dtype=torch.float64, device=mean.device), mean.double(), var.double() * rows])
@@ -260,7 +306,7 @@ class PartitionShard:
         return mean_all.float().contiguous(), (m2_all / total).float().contiguous()
 
     def sum_ranks(self, tensors):
-        if self.world == 1:
+        if self.alone:
             return tensors
         flat = torch.cat([t.reshape(-1) for t in tensors])
         all_reduce_sum(flat, self.group)
@@ -272,7 +318,7 @@ class PartitionShard:
 
     def finish_logits(self, piece):
         """world > 1: this rank's piece (owned in-edges, sorted order) -> the complete logits in edge-id order."""
-        return self.part.assemble_logits(piece, self.group) if self.world > 1 else piece
+        return piece if self.alone else self.part.assemble_logits(piece, self.group)
 
 
 def _project(ops, lw, h, n_own, xchg):
@@ -309,7 +355,7 @@ def run_partitioned(ops, prep, part, x_local, e_local, group=None, reduce_result
     xchg.finish()
     PQ = ops.linear(h, pw["W_nodes"], pw["b_nodes"])
     score_views = _ScoreViews(views, part.srt_geid)
-    if part.world == 1 or not reduce_result:
+    if _alone(part.world) or not reduce_result:
         # scatter straight to GLOBAL edge ids: a GraphViews-like shim whose srt_eid is the global map
         logits = (torch.zeros if part.world > 1 else torch.empty)(part.num_edges_global, dtype=torch.float32, device=h.device)
         if part.n_score > 0:
@@ -337,6 +383,7 @@ class CapturedPartitionedForward:
             raise RuntimeError("CapturedPartitionedForward is for eval-mode inference")
         ops, prep, part = runner.ops, runner.prep, runner.part
         self.part, self.group, self.ops = part, runner.group, ops
+        self.alone = alone = _alone(part.world)
         dev = runner.x.device
         with torch.no_grad():
             for _ in range(2):   # eager warm-up: weight preparation, allocator pools, the aggregation's hub scratch
@@ -358,20 +405,20 @@ class CapturedPartitionedForward:
             state["e"] = engine.gate(ops, lw, views, state["e"], B1, B2, (runner.e, prep.enc_edge), state["scratch"])
             state["h"] = ops.node_aggregate(state["e"], A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_own)
             self.h.append(state["h"])
-            self.packed.append(ops.gather_rows(state["h"], part.send_idx) if part.world > 1 else None)
+            self.packed.append(None if alone else ops.gather_rows(state["h"], part.send_idx))
 
         def score():
             pw = prep.predictor
             hs = pw["hs"]
             PQ = ops.linear(state["h"], pw["W_nodes"], pw["b_nodes"])
             sv = _ScoreViews(views, part.srt_geid)
-            if part.world == 1:
+            if alone:
                 self.piece = torch.empty(part.num_edges_global, dtype=torch.float32, device=dev)
             else:
                 self.piece = torch.empty(part.score_pad, dtype=torch.float32, device=dev)
             if part.n_score > 0:
                 ops.edge_score(state["e"], PQ[:, :hs], PQ[:, hs:], sv, pw["W1_e"], pw["W2"], pw["b2"], pw["W3"], pw["b3"], self.piece,
-                               num_edges=part.n_score, scatter_to_edge_id=part.world == 1)
+                               num_edges=part.n_score, scatter_to_edge_id=alone)
 
         with torch.no_grad():
             for fn in [lambda li=li: layer(li) for li in range(len(prep.layers))] + [score]:
@@ -385,9 +432,9 @@ class CapturedPartitionedForward:
         p = self.part
         for i, g in enumerate(self.graphs):
             g.replay()
-            if i < len(self.h) and p.world > 1:
+            if i < len(self.h) and not self.alone:
                 all_to_all_rows(self.h[i][p.n_own:], self.packed[i], p.recv_counts, p.send_counts, self.group)
-        return (self.piece if p.world == 1 else p.assemble_logits(self.piece, self.group)).unsqueeze(1)
+        return (self.piece if self.alone else p.assemble_logits(self.piece, self.group)).unsqueeze(1)
 
 
 class _ScoreViews:

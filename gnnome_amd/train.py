@@ -33,6 +33,7 @@ class WholeGraph:
     (owned nodes first, then halo; owned in-edges first, then the out-edges that end in the halo)."""
 
     world = 1
+    alone = True      # no collective is issued (a PartitionShard of one rank under GNNOME_FORCE_COLLECTIVES=1 says False)
 
     def __init__(self, views, ops=hip_ops):
         self.views, self.ops = views, ops
@@ -108,7 +109,7 @@ def _bn_train_fused(sh, bn, moments, updates):
 
 
 def _can_fuse_bn(sh, bn):
-    return sh.world == 1 and bn.momentum is not None and hasattr(sh.ops, "bn_train_finish")
+    return sh.alone and bn.momentum is not None and hasattr(sh.ops, "bn_train_finish")
 
 
 def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out, stats=None, apply=True):
@@ -119,7 +120,7 @@ def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out, stats=None, 
     first n_once rows only (the owned ones)."""
     ops = sh.ops
     s1, s2 = ops.bn_bwd_stats(dy, x, scale, shift, mean) if stats is None else stats   # (stats: gathered by the producer of dy)
-    if sh.world == 1 and hasattr(ops, "bn_bwd_terms"):
+    if sh.alone and hasattr(ops, "bn_bwd_terms"):
         s2h, c1, c2 = ops.bn_bwd_terms(s1, s2, rstd, rows)   # the three vectors below in one launch
     else:
         s2h = rstd * s2                                     # sum dy*m*xhat
@@ -147,6 +148,42 @@ def _storage_dtype(model):
     return torch.bfloat16 if kind == "bf16" else torch.float32
 
 
+def _recompute_gate(model, storage):
+    """`model.recompute_gate` (default False): the pre-normalisation gate output xe[E,H] of every layer is NOT kept for the
+    backward; the backward launches the layer's raw gate again on the same operands (deterministic kernels: the same bits).
+    One [E,H] tensor per layer less in HBM - 8 of the ~34 KB per edge a step holds at hidden 256 (BASELINE configs[4]: 6.25M
+    local edges per rank) - for one more gate launch per layer and step (~10 % of a step)."""
+    on = bool(getattr(model, "recompute_gate", False))
+    if on and storage != torch.float32:
+        raise ValueError('recompute_gate and activation_storage="bf16" are alternatives (nothing is stored when xe is recomputed)')
+    return on
+
+
+def _raw_gate(sh, conv, e, B1h, B2h, layer_norm, storage, path=None):
+    """xe = B1h[src] + B2h[dst] + e W3^T of one layer on the kernel the shard's shape allows -> (path, xe, statistics):
+    "plain" (LayerNorm: no statistics), "moments" (single rank: shifted column sums from the same pass, finished by
+    gnnome_bn_train_finish_f32) or "stats" ((mean, biased var) of the owned rows).  The backward of a model with
+    recompute_gate passes the forward's `path` back so that the same launch produces the same bits."""
+    ops, views = sh.ops, sh.views
+    W3 = conv.B_3.weight.detach().contiguous()
+    if layer_norm:
+        if storage != torch.float32:
+            raise _no_bf16_storage()
+        return "plain", ops.edge_gate_raw(e, B1h, B2h, views, W3), None
+    recomputing = path is not None
+    if path is None:
+        path = "moments" if _can_fuse_bn(sh, conv.bn_e) and ops.can_fuse_gate_moments(e, B1h, B2h, storage) else "stats"
+    if path == "moments":
+        xe, mom = ops.edge_gate_raw_moments(e, B1h, B2h, views, W3, storage=storage)
+        return path, xe, mom
+    if storage != torch.float32:
+        raise _no_bf16_storage()
+    if recomputing and sh.e_own != e.shape[0]:   # a partition's forward took edge_gate_raw + batch_stats(owned rows): the gate alone
+        return path, ops.edge_gate_raw(e, B1h, B2h, views, W3), None
+    xe, m_e, v_e = ops.edge_gate_raw_stats(e, B1h, B2h, views, W3, rows_stats=sh.e_own)
+    return path, xe, (m_e, v_e)
+
+
 def _no_bf16_storage():
     return ValueError('activation_storage="bf16" is built for the fused single-rank BatchNorm step at hidden_features 64 / 128 '
                       "(normalization='batch', momentum set, one process); use \"fp32\" here")
@@ -164,6 +201,7 @@ class _TrainStep(torch.autograd.Function):
         d = lambda t: t.detach().contiguous()  # noqa: E731
         new = lambda rows, cols: torch.empty((rows, cols), dtype=torch.float32, device=x.device)  # noqa: E731
         storage = _storage_dtype(model)
+        recompute = _recompute_gate(model, storage)
 
         h = ops.encode(x, d(model.linear1_node.weight), d(model.linear1_node.bias), d(model.linear2_node.weight), d(model.linear2_node.bias))
         e = ops.encode(e_raw, d(model.linear1_edge.weight), d(model.linear1_edge.bias), d(model.linear2_edge.weight),
@@ -181,19 +219,17 @@ class _TrainStep(torch.autograd.Function):
             mean_e = rstd_e = sc_e = sh_e = mean_h = rstd_h = sc_h = sh_h = None
             if layer_norm and storage != torch.float32:
                 raise _no_bf16_storage()
+            path, xe, stats = _raw_gate(sh, conv, e, blk(P, "B1"), blk(P, "B2"), layer_norm, storage)
             if layer_norm:   # per-row statistics: nothing crosses rows (or ranks), and there are no running buffers
-                xe = ops.edge_gate_raw(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight))
                 e_new = ops.ln_relu_res(xe, d(conv.bn_e.weight), d(conv.bn_e.bias), e)
             else:
-                if _can_fuse_bn(sh, conv.bn_e) and ops.can_fuse_gate_moments(e, blk(P, "B1"), blk(P, "B2"), storage):
-                    xe, mom = ops.edge_gate_raw_moments(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight), storage=storage)
-                    mean_e, rstd_e, sc_e, sh_e = _bn_train_fused(sh, conv.bn_e, mom, updates=2)
-                elif storage != torch.float32:
-                    raise _no_bf16_storage()
+                if path == "moments":
+                    mean_e, rstd_e, sc_e, sh_e = _bn_train_fused(sh, conv.bn_e, stats, updates=2)
                 else:
-                    xe, m_e, v_e = ops.edge_gate_raw_stats(e, blk(P, "B1"), blk(P, "B2"), views, d(conv.B_3.weight), rows_stats=e_own)
-                    mean_e, rstd_e, sc_e, sh_e = _bn_train(sh, conv.bn_e, m_e, v_e, e_own, sh.e_global, updates=2)
+                    mean_e, rstd_e, sc_e, sh_e = _bn_train(sh, conv.bn_e, stats[0], stats[1], e_own, sh.e_global, updates=2)
                 e_new = ops.bn_relu_res(xe, sc_e, sh_e, e)
+            if recompute:
+                xe = None   # the backward runs the same gate launch again (same kernel, same operands: the same bits)
             v, hf, rdf, hb, rdb = ops.node_aggregate_raw(e_new, blk(P, "A1"), blk(P, "A2"), blk(P, "A3"), views, 1, n_own,
                                                          rows_alloc=n_local)
             h_next = new(n_local, H)
@@ -210,7 +246,7 @@ class _TrainStep(torch.autograd.Function):
             if conv.dropout > 0.0:
                 mask = dropout_mask(n_own, H, conv.dropout, x.device)
                 h_next[:n_own].copy_(ops.mul23(h_next[:n_own], mask, mask)[0])
-            saved.append(dict(h=h, P=P, e=e, xe=xe, e_new=e_new, mean_e=mean_e, rstd_e=rstd_e, v=v, hf=hf, rdf=rdf, hb=hb, rdb=rdb,
+            saved.append(dict(h=h, P=P, e=e, xe=xe, gate_path=(path, layer_norm, storage), e_new=e_new, mean_e=mean_e, rstd_e=rstd_e, v=v, hf=hf, rdf=rdf, hb=hb, rdb=rdb,
                               mean_h=mean_h, rstd_h=rstd_h, mask=mask, Wcat=Wcat, WcatT=WcatT, W3T=W3T, sc_e=sc_e, sh_e=sh_e, sc_h=sc_h, sh_h=sh_h))
             h, e = h_next, e_new
 
@@ -226,7 +262,7 @@ class _TrainStep(torch.autograd.Function):
         # every edge of the graph is scored once, by the rank that owns its destination
         z1 = new(e_own, hs)
         w_tail = (W1[:, 2 * H:], d(pred.W2.weight), d(pred.W2.bias), d(pred.W3.weight.reshape(-1)), d(pred.W3.bias.reshape(-1)))
-        if sh.world > 1:    # one contiguous piece per rank in sorted order; finish_logits all-gathers and un-permutes them
+        if not sh.alone:    # one contiguous piece per rank in sorted order; finish_logits all-gathers and un-permutes them
             piece = torch.empty(sh.part.score_pad, dtype=torch.float32, device=h.device)
             ops.edge_score(e, ps, qd, sh.score_views, *w_tail, piece, num_edges=e_own, scatter_to_edge_id=False, z1_out=z1)
             logits = sh.finish_logits(piece)
@@ -263,7 +299,7 @@ class _TrainStep(torch.autograd.Function):
         g["predictor.W2.weight"] = ops.wgrad(dz2, tail["z1"])
         g["predictor.W2.bias"] = ops.colsum2(dz2)[0]
         g["predictor.W3.weight"] = ops.colsum2(u)[0].reshape(1, 32)
-        g["predictor.W3.bias"] = (dl if sh.world == 1 else dl[sh.score_views.srt_eid.long()]).sum().reshape(1)
+        g["predictor.W3.bias"] = (dl if sh.alone else dl[sh.score_views.srt_eid.long()]).sum().reshape(1)
         if e_local > e_own:
             dz1 = torch.cat([dz1, torch.zeros((e_local - e_own, hs), dtype=torch.float32, device=dev)], 0)
         W1 = tail["W1"]
@@ -296,6 +332,9 @@ class _TrainStep(torch.autograd.Function):
             Tf, Uf = ops.mul23(dv, s["rdf"], s["hf"])
             Tb, Ub = ops.mul23(dv, s["rdb"], s["hb"])
             sum_in, sum_out = ops.node_aggregate_raw(s["e_new"], None, Tb, Tf, views, 2, n_local)   # = dA3(role), dA2(role)
+            if s["xe"] is None:     # model.recompute_gate: xe was not kept - one more gate launch instead of an [E,H] tensor per layer
+                _, layer_norm_, storage_ = s["gate_path"]
+                _, s["xe"], _ = _raw_gate(sh, conv, s["e"], blk(s["P"], "B1"), blk(s["P"], "B2"), layer_norm_, storage_, path=s["gate_path"][0])
             stats_e = None
             if s["sc_e"] is not None and hasattr(ops, "agg_edge_bwd_stats"):
                 # de += ... and bn_e's backward statistics of the result in the same pass over the edges
@@ -352,6 +391,7 @@ class _TrainStep(torch.autograd.Function):
             g[pfx + "B_3.bias"] = g[pfx + ("B_1" if views.transposed else "B_2") + ".bias"].clone()
             for k, name in enumerate(names):
                 g[pfx + name + ".weight"] = gWcat[k * H:(k + 1) * H]
+            saved[li] = s = None    # this layer's activations are done with: their memory serves the next layer's temporaries
 
         # ---- encoders (models/full_graph.py:26-27)
         def encoder_bwd(dout, inp, gather, rows, l1, l2, pfx1, pfx2):

@@ -14,20 +14,41 @@ sys.path.insert(0, os.path.dirname(HERE))
 def worker(rank, world, port, case, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.load(case, weights_only=False)
+    if g.get("force_collectives"):   # one rank that still issues every collective (gnnome_amd.dist.force_collectives)
+        os.environ["GNNOME_FORCE_COLLECTIVES"] = "1"
+    if g.get("transport") == "nccl":   # RCCL on device memory: one rank per GPU (the test box has one GPU => world 1)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)
         import cpu_ops
         import gnnome_amd
         from gnnome_amd import dist as gdist
         from gnnome_amd import engine
-        g = torch.load(case, weights_only=False)
+        if g.get("wrappers"):   # the collective wrappers alone, on rows that really travel (a rank sends to itself at world 1)
+            where = torch.device("cuda", rank) if g.get("device") == "cuda" else torch.device("cpu")
+            gen = torch.Generator().manual_seed(5 + rank)
+            rows = torch.randn(world * 300, 128, generator=gen).to(where)
+            got = torch.empty_like(rows)
+            work = gdist.all_to_all_rows(got, rows, [300] * world, [300] * world, None, async_op=True)
+            if work is not None:
+                work.wait()
+            summed = gdist.all_reduce_sum(rows[:7].clone())
+            every = gdist.all_gather_rows(rows[:5], world)
+            ints = gdist.all_gather_rows(torch.arange(4, dtype=torch.int64, device=where) + rank, world)
+            torch.save({"sent": rows.cpu(), "got": got.cpu(), "summed": summed.cpu(), "every": every.cpu(), "ints": ints.cpu(),
+                        "backend": dist.get_backend()}, os.path.join(out_dir, f"rank{rank}.pt"))
+            return
         m = gnnome_amd.models.SymGatedGCNModel(2, 2, g["hidden"], 16, g["layers"], 64, g.get("normalization", "batch"), dropout=0.0).eval()
         m.load_state_dict(g["state_dict"])
         if g.get("device") == "cuda":
             # both ranks on the one GPU of the test box: HIP kernels as compute, gloo (host-staged) as transport
             from gnnome_amd import ops as backend
-            where = torch.device("cuda", 0)
+            where = torch.device("cuda", rank if g.get("transport") == "nccl" else 0)
             m.to(where)
             g = {k: (v.to(where) if k in ("x", "e", "y", "pos_weight") else v) for k, v in g.items()}
         else:
@@ -37,6 +58,7 @@ def worker(rank, world, port, case, out_dir):
             # train.py:138-145 + :328-330 on the partition: every rank computes the loss on the assembled logits
             import torch.nn.functional as F
             m.train()
+            m.recompute_gate = bool(g.get("recompute_gate"))
             runner = gdist.PartitionedRunner(m, part, g["x"], g["e"], where, ops=backend)
             logits = runner.train_forward()
             loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), g["y"], pos_weight=g["pos_weight"])
@@ -44,7 +66,8 @@ def worker(rank, world, port, case, out_dir):
             torch.save({"logits": logits.detach().squeeze(1).cpu(), "loss": loss.detach().cpu(),
                         "grads": {k: p.grad.cpu() for k, p in m.named_parameters()},
                         "buffers": {k: b.detach().cpu().clone() for k, b in m.named_buffers()}, "n_own": part.n_own, "n_local": part.n_local,
-                        "n_score": part.n_score, "e_local": int(part.edge_gid.numel())}, os.path.join(out_dir, f"rank{rank}.pt"))
+                        "n_score": part.n_score, "e_local": int(part.edge_gid.numel()), "backend": dist.get_backend()},
+                       os.path.join(out_dir, f"rank{rank}.pt"))
             return
         prep = engine.Prepared(m, where)
         with torch.no_grad():
@@ -57,6 +80,7 @@ def worker(rank, world, port, case, out_dir):
             replayed = runner.forward().squeeze(1).cpu()
         torch.save({"logits": logits.cpu(), "replayed": replayed, "n_own": part.n_own, "n_local": part.n_local, "n_score": part.n_score,
                     "e_local": int(part.edge_gid.numel()), "bounds": part.bounds, "send": part.send_counts,
-                    "recv": part.recv_counts}, os.path.join(out_dir, f"rank{rank}.pt"))
+                    "recv": part.recv_counts, "backend": dist.get_backend(), "score_index": part.score_index is not None},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()

@@ -16,6 +16,7 @@ from oracle.symgated_oracle import degree_features
 
 
 def main():
+    torch.set_num_threads(1)   # as make_golden.py: the reduction order of torch's CPU kernels depends on the thread count
     n, ec = 150, 1500
     gr = make_graph(n, ec, seed=8, kind="banded")
     src, dst, e, y, pw = gr["src"], gr["dst"], gr["e"], gr["y"], gr["pos_weight"]

@@ -159,3 +159,64 @@ def test_partitioned_layernorm_training_step_matches_reference_golden_g8(tmp_pat
         assert (torch.sigmoid(o["logits"]) - torch.sigmoid(g["logits"].squeeze(-1))).abs().max().item() < 1e-4
         assert abs(o["loss"].item() - g["loss"].item()) < 1e-5
         check_grads(o["grads"], g["grads"], rtol=1e-3)
+
+
+def test_one_rank_with_forced_collectives_equals_the_plain_path(tmp_path):
+    """GNNOME_FORCE_COLLECTIVES=1 (gnnome_amd.dist.force_collectives): a one-rank group issues every collective of the
+    partitioned path; a one-rank collective is the identity, so inference gives the same bits as without the switch and the
+    training step the reference golden.  The GPU twin of this test runs the same code over RCCL (tests/test_hip_partition.py)."""
+    from test_train_host import check_grads
+    g = load_golden("g2_uniform_1k.pt")
+    sd = random_state_dict(64, seed=3)
+    case = dict(src=g["src"], dst=g["dst"], num_nodes=g["num_nodes"], x=g["x"], e=g["e"], hidden=64, layers=8, state_dict=sd)
+    plain = _run(1, case, tmp_path)[0]
+    forced = _run(1, dict(case, force_collectives=True), tmp_path)[0]
+    assert forced["score_index"] and not plain["score_index"]          # the all-gather + index_select route was taken
+    assert torch.equal(plain["logits"], forced["logits"])
+    t = load_golden("g3_train_h64.pt")
+    tcase = dict(src=t["src"], dst=t["dst"], num_nodes=t["num_nodes"], x=t["x"], e=t["e"], y=t["y"], pos_weight=t["pos_weight"],
+                 hidden=64, layers=8, state_dict=random_state_dict(64, seed=t["seed"]), train=True, force_collectives=True)
+    o = _run(1, tcase, tmp_path)[0]
+    assert abs(o["loss"].item() - t["loss"].item()) < 1e-5
+    check_grads(o["grads"], t["grads"], rtol=1e-3)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_collective_wrappers_move_rows(world, tmp_path):
+    outs = _run(world, dict(wrappers=True), tmp_path)
+    for r, o in enumerate(outs):
+        for p in range(world):   # block p of what rank r received = block r of what rank p sent
+            assert torch.equal(o["got"][p * 300:(p + 1) * 300], outs[p]["sent"][r * 300:(r + 1) * 300])
+        assert torch.allclose(o["summed"], sum(q["sent"][:7] for q in outs))
+        assert all(torch.equal(o["every"][p], outs[p]["sent"][:5]) for p in range(world))
+        assert o["ints"].tolist() == [[p + k for k in range(4)] for p in range(world)]
+
+
+def test_partitioned_training_step_with_recompute_gate(tmp_path):
+    """model.recompute_gate on a partition (BASELINE configs[4]'s memory lever): two ranks, same bits as the stored form."""
+    t = load_golden("g3_train_h64.pt")
+    tcase = dict(src=t["src"], dst=t["dst"], num_nodes=t["num_nodes"], x=t["x"], e=t["e"], y=t["y"], pos_weight=t["pos_weight"],
+                 hidden=64, layers=8, state_dict=random_state_dict(64, seed=t["seed"]), train=True)
+    stored = _run(2, tcase, tmp_path)
+    again = _run(2, dict(tcase, recompute_gate=True), tmp_path)
+    for a, b in zip(stored, again):
+        assert torch.equal(a["logits"], b["logits"]) and all(torch.equal(a["grads"][k], b["grads"][k]) for k in a["grads"])
+
+
+@pytest.mark.parametrize("kind,world", [("banded", 2), ("uniform", 3)])
+def test_partition_census_predicts_what_every_rank_builds(kind, world, tmp_path):
+    """gnnome_amd.dist.partition_census (one process, no process group - tools/partition_stats.py and DESIGN.md's world-8
+    tables rest on it) against the plans the ranks really build."""
+    from gnnome_amd.dist import partition_census
+    n, e = 3000, 30000
+    gr = make_graph(n, e, seed=6, kind=kind)
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=degree_features(gr["src"], gr["dst"], n), e=gr["e"], hidden=64, layers=1,
+                state_dict=random_state_dict(64, num_layers=1, seed=1))
+    outs = _run(world, case, tmp_path)
+    c = partition_census(gr["src"], gr["dst"], n, world)
+    assert c["bounds"] == outs[0]["bounds"]
+    for o, r in zip(outs, c["ranks"]):
+        assert (o["n_own"], o["n_local"] - o["n_own"], o["e_local"], o["n_score"], sum(o["send"]), max(o["send"])) == \
+            (r["owned_nodes"], r["halo_rows"], r["local_edges"], r["owned_in_edges"], r["rows_sent_per_layer"], r["largest_link_rows"])
+    assert abs(c["edge_replication"] - sum(o["e_local"] for o in outs) / e) < 1e-12
+    assert (c["cut_fraction"] < 0.05) == (kind == "banded")

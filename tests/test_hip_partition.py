@@ -190,3 +190,45 @@ def test_three_ranks_training_step_h128_on_a_mostly_cut_graph(tmp_path):
     outs = _run(3, case, tmp_path)
     assert sum(o["e_local"] for o in outs) > 1.6 * e       # > 60 % of the edges are cut: replicated on a second rank
     _check_partitioned_step(outs, om, want, want_loss, rtol=3e-2)
+
+
+def test_rccl_collective_wrappers_on_device_memory(tmp_path):
+    """gnnome_amd.dist's three wrappers over RCCL ("nccl") with device tensors: rows that really travel through
+    all_to_all_single (async + wait, a rank sending to itself), all_reduce, all_gather_into_tensor (fp32 and int64)."""
+    o = _run(1, dict(wrappers=True, device="cuda", transport="nccl"), tmp_path)[0]
+    assert o["backend"] == "nccl"
+    assert torch.equal(o["got"], o["sent"]) and torch.equal(o["summed"], o["sent"][:7]) and torch.equal(o["every"][0], o["sent"][:5])
+    assert o["ints"].tolist() == [[0, 1, 2, 3]]
+
+
+def test_one_rank_over_rccl_with_forced_collectives_equals_the_plain_path(tmp_path):
+    """The first time RCCL runs gnnome_amd.dist: init_process_group("nccl") with one rank and
+    GNNOME_FORCE_COLLECTIVES=1, so that the plan's all_to_all, every layer's halo exchange (async, overlapped with the owned
+    rows' projection), the logits all_gather + index_select and, in training, the BatchNorm statistics all_gather, the
+    BatchNorm-backward / halo-gradient / flat gradient all_reduce all go through RCCL on device memory.  Inference: the same
+    bits as the plain single-rank partitioned path; training: the reference golden G3, and the H = 256 banded graph equal to
+    the un-forced step to rounding of the per-channel statistics."""
+    from gnnome_amd.synth import make_graph
+    from oracle.symgated_oracle import degree_features
+    n, e, hidden = 20_000, 200_000, 256
+    gr = make_graph(n, e, seed=3, kind="banded")
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=degree_features(gr["src"], gr["dst"], n), e=gr["e"], hidden=hidden, layers=8,
+                state_dict=random_state_dict(hidden, seed=2), device="cuda", captured=True)
+    plain = _run(1, case, tmp_path)[0]
+    rccl = _run(1, dict(case, transport="nccl", force_collectives=True), tmp_path)[0]
+    assert rccl["backend"] == "nccl" and rccl["score_index"] and not plain["score_index"]
+    assert torch.equal(plain["logits"], rccl["logits"]) and torch.equal(rccl["replayed"], rccl["logits"])
+
+    g = load_golden("g3_train_h64.pt")
+    tcase = dict(src=g["src"], dst=g["dst"], num_nodes=g["num_nodes"], x=g["x"], e=g["e"], y=g["y"], pos_weight=g["pos_weight"],
+                 hidden=64, layers=8, state_dict=random_state_dict(64, seed=g["seed"]), train=True, device="cuda", transport="nccl",
+                 force_collectives=True)
+    o = _run(1, tcase, tmp_path)[0]
+    assert o["backend"] == "nccl" and abs(o["loss"].item() - g["loss"].item()) < 1e-5
+    check_grads(o["grads"], g["grads"], rtol=1e-3)
+
+    big = dict(case, captured=False, train=True, y=gr["y"], pos_weight=gr["pos_weight"])
+    a = _run(1, big, tmp_path)[0]
+    b = _run(1, dict(big, transport="nccl", force_collectives=True), tmp_path)[0]
+    assert abs(a["loss"].item() - b["loss"].item()) < 1e-6 * abs(a["loss"].item()) + 1e-7
+    check_grads(b["grads"], a["grads"], rtol=2e-3)

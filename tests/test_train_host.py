@@ -130,3 +130,36 @@ def test_bf16_activation_storage_on_checker_backend_stays_close_to_the_reference
     m.activation_storage = "fp16"
     with pytest.raises(ValueError):
         train_forward_on(m, WholeGraph(views, cpu_ops), g["x"], g["e"])
+
+
+def _step_grads(golden, norm, recompute, seed_key="seed"):
+    g = load_golden(golden)
+    sd = random_state_dict(64, seed=g[seed_key])
+    if norm == "layer":
+        sd = {k: v for k, v in sd.items() if "running_" not in k and "num_batches" not in k}
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 8, 64, norm, dropout=0.0)
+    m.load_state_dict(sd)
+    m.train()
+    m.recompute_gate = recompute
+    views = cpu_ops.CpuViews(g["src"], g["dst"], g["num_nodes"])
+    logits = train_forward_on(m, WholeGraph(views, cpu_ops), g["x"], g["e"])
+    F.binary_cross_entropy_with_logits(logits.squeeze(-1), g["y"], pos_weight=g["pos_weight"]).backward()
+    return logits.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}, {k: b.clone() for k, b in m.named_buffers()}
+
+
+def test_recompute_gate_gives_the_same_bits_as_the_stored_activations():
+    """model.recompute_gate = True: xe is not kept for the backward, the layer's raw gate is launched again (what fits
+    BASELINE configs[4]'s 6.25M-edge shard into a rank's HBM with room to spare).  Same logits, gradients and BatchNorm
+    buffers, bit for bit, for both normalizations; and it is refused together with bf16 storage."""
+    import pytest
+    for golden, norm in (("g3_train_h64.pt", "batch"), ("g8_layernorm_train_h64.pt", "layer")):
+        l0, g0, b0 = _step_grads(golden, norm, False)
+        l1, g1, b1 = _step_grads(golden, norm, True)
+        assert torch.equal(l0, l1)
+        assert all(torch.equal(g0[k], g1[k]) for k in g0), norm
+        assert all(torch.equal(b0[k], b1[k]) for k in b0), norm
+    g = load_golden("g3_train_h64.pt")
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 8, 64, "batch", dropout=0.0).train()
+    m.recompute_gate, m.activation_storage = True, "bf16"
+    with pytest.raises(ValueError, match="alternatives"):
+        train_forward_on(m, WholeGraph(cpu_ops.CpuViews(g["src"], g["dst"], g["num_nodes"]), cpu_ops), g["x"], g["e"])

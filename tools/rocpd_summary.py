@@ -8,6 +8,23 @@ import sqlite3
 import sys
 
 
+def short_name(name):
+    """Demangled kernel name without its ARGUMENT list: the last balanced (...) group is dropped, template arguments stay (the modes
+    of one kernel template are different kernels), and "(anonymous namespace)::" is removed first - round 3 cut at the FIRST "(",
+    which collapsed every `gnnome::(anonymous namespace)::k<...>` into one row."""
+    name = name.replace("(anonymous namespace)::", "").strip()
+    if name.endswith(")"):
+        depth = 0
+        for i in range(len(name) - 1, -1, -1):
+            depth += name[i] == ")"
+            depth -= name[i] == "("
+            if depth == 0:
+                name = name[:i]
+                break
+    name = re.sub(r"^void ", "", name).strip()
+    return re.sub(r"\s*\[clone .*$", "", name)
+
+
 def main(path):
     c = sqlite3.connect(path)
     rows = c.execute("select name, start, end from kernels").fetchall() if _has(c, "kernels") else []
@@ -16,7 +33,7 @@ def main(path):
                          "on d.kernel_id = s.id").fetchall()
     agg = {}
     for name, start, end in rows:
-        name = re.sub(r"\(.*", "", name or "?")
+        name = short_name(name or "?")
         a = agg.setdefault(name, [0, 0, 1 << 62, 0])
         d = end - start
         a[0] += 1
@@ -28,7 +45,7 @@ def main(path):
     print("| kernel | calls | total_us | avg_us | min_us | max_us | % |")
     print("|---|---:|---:|---:|---:|---:|---:|")
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print(f"| `{name[:110]}` | {a[0]} | {a[1] / 1e3:.1f} | {a[1] / a[0] / 1e3:.2f} | {a[2] / 1e3:.2f} | {a[3] / 1e3:.2f} | {100 * a[1] / total:.1f} |")
+        print(f"| `{name[:140]}` | {a[0]} | {a[1] / 1e3:.1f} | {a[1] / a[0] / 1e3:.2f} | {a[2] / 1e3:.2f} | {a[3] / 1e3:.2f} | {100 * a[1] / total:.1f} |")
 
 
 def _has(c, view):
