@@ -314,7 +314,7 @@ def _memory_record(dev, edges_local, hidden):
             "local_edges": edges_local, "hidden": hidden}
 
 
-def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry, dropout, storage="fp32"):
+def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry, dropout, storage="fp32", recompute=False):
     """configs[2]'s shape: fwd + loss + bwd + Adam on the whole graph, fp32, the step replayed from a hipGraph (a training
     loop over one graph repeats the same launch sequence; ~450 library launches + a few hundred small torch ops cost
     30-40 ms of host time per step when issued eagerly)."""
@@ -324,6 +324,7 @@ def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry
     model.load_state_dict(random_state_dict(hidden, seed=1))
     model.to(dev)
     model.activation_storage = storage   # "bf16": xe / dxe stored as bfloat16 between the kernels (arithmetic stays fp32)
+    model.recompute_gate = recompute     # True: xe is not kept for the backward, the raw gate runs again (gnnome_amd/train.py)
     views = ops.GraphViews(g["src"].to(dev), g["dst"].to(dev), n)
     x, ef, y, pw = ops.degree_features(views), g["e"].to(dev), g["y"].to(dev), g["pos_weight"].to(dev)
     # torch.optim.Adam as train.py:259 builds it, in its fused single-kernel form (fused / capturable are implementation
@@ -378,7 +379,7 @@ def _train_record(gnnome_amd, ops, g, n, e, hidden, dev, steps, warmup, symmetry
             "step": ("train.py:159-170 symmetry loss: two train-mode forwards (graph and reversed graph) + BCE both ways + |org - rev|" if symmetry
                      else "train.py:138-145 + :328-330: train-mode forward (batch-statistic BatchNorm) + BCEWithLogits(pos_weight)")
                     + f" + backward + Adam, fp32 arithmetic, activation storage {storage}, dropout {dropout or 0}, whole step replayed from one hipGraph",
-            "eager_ms_per_step": eager_ms, "dtype": "f32", "activation_storage": storage, "loss": float(loss),
+            "eager_ms_per_step": eager_ms, "dtype": "f32", "activation_storage": storage, "recompute_gate": recompute, "loss": float(loss),
             "memory": {"eager_step": memory_eager, "hipgraph_step": _memory_record(dev, e, hidden)},
             "hbm_roofline_frac_3xBfwd": passes * 3 * b_fwd / (ms * 1e-3) / HBM_PEAK, "mfma_f32_frac_3xFfwd": passes * 3 * f_fwd / (ms * 1e-3) / MFMA_F32_PEAK}
 
@@ -429,7 +430,7 @@ def _partitioned_train_record(gnnome_amd, gdist, ops, g, n, e, hidden, dev, rank
                                f"BCEWithLogits(pos_weight) + backward + Adam, fp32, random-init weights seed 1",
                    "parallelism": f"dst-range x{world}, halo all_to_all per layer both ways, BatchNorm statistics merged over ranks, "
                                   f"one flat gradient all-reduce ({n_params * 4} B) per step; {transport}"},
-        "loss": float(loss), "ranks_in_step": in_step, "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+        "loss": float(loss), "ranks_in_step": in_step, "recompute_gate": bool(getattr(model, "recompute_gate", False)), "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
         "hbm_roofline_frac_3xBfwd": 3 * b_fwd / (ms * 1e-3) / (world * HBM_PEAK), "mfma_f32_frac_3xFfwd": 3 * f_fwd / (ms * 1e-3) / (world * MFMA_F32_PEAK),
         "rank0": {"owned_nodes": plan.n_own, "halo_nodes": plan.n_local - plan.n_own, "local_edges": plan.views.num_edges,
                   "owned_in_edges": plan.n_score, "rows_sent_per_layer": int(sum(plan.send_counts)),
@@ -448,17 +449,25 @@ def _local_degree_features(ops, g, n, plan, dev):
     return x_local
 
 
+# Peak device memory of one training step per LOCAL edge at hidden 256, torch's reserved bytes (what the caching allocator holds from
+# the driver), measured on the MI355X at 2.5M and 6.25M local edges - the two sizes agree to 0.2 % (profiles/r04_bench_train_c5shard*.json,
+# r04_bench_train_c4shard*.json): xe stored / recomputed in the backward (model.recompute_gate).  Nearly everything scales with the width.
+TRAIN_BYTES_PER_EDGE_H256 = {"stored": 35_300, "recompute": 29_200}
+DEVICE_BUDGET = 0.85 * 309.2e9    # of the 288 GiB torch reports for an MI355X; the rest is left to RCCL's buffers and the views
+
+
 def train_workload_for(world, kind, one_gpu):
-    """Default graph of `--mode train` at N > 1: BASELINE configs[4] (c5) when one rank's share of the step fits its HBM, else
-    the largest workload that does.  A rank keeps ~2 [E_local,H] tensors per layer for the backward plus the gradients'
-    temporaries: ~20 x E_local x H x 4 B, against 200 GB of the 288."""
-    cut = 1.0 + ((world - 1) / world if kind == "uniform" else 0.05)
+    """Default graph of `--mode train` at N > 1 -> (workload, recompute_gate): BASELINE configs[4] (c5) when one rank's share of
+    the step fits its HBM, else the largest workload that does; xe is recomputed in the backward only where storing it does not fit
+    (it costs 10 % of the step).  c5 on 8 ranks: 6.31M local edges x 35.3 KB = 223 GB of the 309."""
+    cut = 1.0 + ((world - 1) / world if kind == "uniform" else 0.01)
     for name in ("c5", "c4", "10m", "c2"):
         _, e, h = WORKLOADS[name]
-        per_rank = 20 * (e / world) * cut * h * 4
-        if per_rank * (world if one_gpu else 1) < 200e9:
-            return name
-    return "c2"
+        for mode in ("stored", "recompute"):
+            per_rank = TRAIN_BYTES_PER_EDGE_H256[mode] * (h / 256) * (e / world) * cut
+            if per_rank * (world if one_gpu else 1) < DEVICE_BUDGET:
+                return name, mode == "recompute"
+    return "c2", False
 
 
 def main():
@@ -471,6 +480,8 @@ def main():
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: one forward (BASELINE configs[1]); train: the training step as the headline value (configs[2], fp32)")
     ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"], help="train: model.activation_storage (bf16 = xe / dxe stored as bfloat16)")
+    ap.add_argument("--recompute-gate", action="store_true", help="train: model.recompute_gate (xe recomputed in the backward instead of stored: "
+                                                                  "-8 of ~34 KB per edge at hidden 256)")
     ap.add_argument("--symmetry", action="store_true", help="train: the reference's default step (symmetry loss: two forwards, dropout 0.2)")
     ap.add_argument("--hipgraph", action="store_true", help="replay the forward from a captured hipGraph (infer; at --gpus > 1: one graph per stretch between two collectives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -479,12 +490,18 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the target_10m / train sub-records (N = 1) and the scaling reference (N > 1)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--tuning", default="", help="A/B measurement only: gnnome_set_tuning pairs 'key=value,key=value' (include/gnnome_hip.h); recorded in the line")
+    ap.add_argument("--plan", default="slices", choices=["slices", "global"],
+                    help="N > 1: build the partition from per-rank slices of the edge list (default) or from the whole list on every rank")
     ap.add_argument("--one-gpu-gloo", action="store_true",
                     help="plumbing check of the N>1 path on a 1-GPU box: all ranks share cuda:0, collectives go over gloo "
                          "(host-staged); the numbers it prints are NOT a multi-GPU measurement")
     args = ap.parse_args()
     if args.workload is None:
-        args.workload = "c2" if args.gpus == 1 else train_workload_for(args.gpus, args.kind, args.one_gpu_gloo) if args.mode == "train" else "10m"
+        if args.gpus > 1 and args.mode == "train":
+            args.workload, need_recompute = train_workload_for(args.gpus, args.kind, args.one_gpu_gloo)
+            args.recompute_gate = args.recompute_gate or need_recompute
+        else:
+            args.workload = "c2" if args.gpus == 1 else "10m"
     if args.cpu_baseline_only:  # child process of the cpu_baseline leg: no GPU work, bounded by the parent's timeout
         cpu_baseline(args.workload, args.kind, mode=args.mode, full=args.cpu_baseline_full)
         return
@@ -579,7 +596,7 @@ def main():
 
         if args.mode == "train":
             rec = _train_record(gnnome_amd, ops, g, n, e, hidden, dev, args.steps, args.warmup, args.symmetry, 0.2 if args.symmetry else None,
-                                storage=args.storage)
+                                storage=args.storage, recompute=args.recompute_gate)
             rec.update({"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                         "data": "synthetic", "config": {"workload": f"{args.workload}: {args.kind} synthetic assembly graph N={n} E={e}, SymGatedGCNModel "
                                                                     f"hidden={hidden} L=8 hs=64, {rec.pop('step')}, random-init weights seed 1",
@@ -613,14 +630,23 @@ def main():
                                                               max(5, args.steps // 2), 3)
         dist.barrier()
         t0 = time.perf_counter()
-        plan = gdist.PartitionedGraph.from_global(g["src"], g["dst"], n, rank, world, dev)
-        # every rank holds the edge list (as inference.py holds the whole graph): degree features of the WHOLE graph
-        # on its own GPU, then each rank keeps the rows of its partition
         if args.mode == "train":
             model.train()
-        runner = gdist.PartitionedRunner(model, plan, None, g["e"], dev, x_local=_local_degree_features(ops, g, n, plan, dev))
+            model.recompute_gate = args.recompute_gate
+        if args.plan == "slices":
+            # every rank starts from ITS 1/world of the edge list (as a reader splitting the input would): degrees all-reduced, edges
+            # and their features shuffled to the owners of their endpoints (PartitionedGraph.from_slices) - no rank plans over E rows
+            a, b = e * rank // world, e * (rank + 1) // world
+            plan = gdist.PartitionedGraph.from_slices(g["src"][a:b], g["dst"][a:b], n, rank, world, dev)
+            runner = gdist.PartitionedRunner(model, plan, None, None, dev, x_local=plan.local_degree_features(),
+                                             e_local=plan.shuffle_edge_rows(g["e"][a:b].to(dev)))
+        else:
+            # every rank holds the edge list (as inference.py holds the whole graph): degree features of the WHOLE graph
+            # on its own GPU, then each rank keeps the rows of its partition
+            plan = gdist.PartitionedGraph.from_global(g["src"], g["dst"], n, rank, world, dev)
+            runner = gdist.PartitionedRunner(model, plan, None, g["e"], dev, x_local=_local_degree_features(ops, g, n, plan, dev))
         torch.cuda.synchronize()
-        cold = {"partition_plan_views_features_ms": (time.perf_counter() - t0) * 1e3}
+        cold = {"partition_plan_views_features_ms": (time.perf_counter() - t0) * 1e3, "plan": args.plan}
         if args.mode == "train":
             rec = _partitioned_train_record(gnnome_amd, gdist, ops, g, n, e, hidden, dev, rank, world, plan, runner, model, args, gloo_transport)
             if rank == 0:

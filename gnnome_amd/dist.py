@@ -45,6 +45,11 @@ def _alone(world):
 def split_by_incident_edges(src, dst, num_nodes, world):
     """Node-range boundaries [b_0=0, ..., b_world=N] balancing in-degree + out-degree per range."""
     deg = torch.bincount(dst.long(), minlength=num_nodes) + torch.bincount(src.long(), minlength=num_nodes)
+    return split_by_degree(deg, num_nodes, world)
+
+
+def split_by_degree(deg, num_nodes, world):
+    """The same boundaries from the per-node incident-edge counts (from_slices all-reduces them over the ranks' slices)."""
     csum = torch.cumsum(deg + 1, 0)  # +1: isolated nodes still cost a node update
     total = int(csum[-1]) if num_nodes > 0 else 0
     bounds = [0]
@@ -114,13 +119,91 @@ class PartitionedGraph:
         self.rank, self.world, self.num_edges_global = rank, world, int(src.numel())
         self.bounds = split_by_incident_edges(src, dst, num_nodes, world)
         lo, hi = self.bounds[rank], self.bounds[rank + 1]
-        self.lo, self.hi, self.n_own = lo, hi, hi - lo
-
-        own_d = (dst >= lo) & (dst < hi)
-        own_s = (src >= lo) & (src < hi)
-        keep = own_d | own_s
+        keep = ((dst >= lo) & (dst < hi)) | ((src >= lo) & (src < hi))
         self.edge_gid = torch.nonzero(keep).squeeze(1)
-        ls, ld = src[keep], dst[keep]
+        return self._build(src[keep], dst[keep], device, ops, group)
+
+    @classmethod
+    def from_slices(cls, src_slice, dst_slice, num_nodes, rank, world, device, ops=hip_ops, group=None):
+        """Build from a rank's SLICE of the edge list: rank r holds the edges with global ids [off_r, off_r + m_r), the slices in
+        rank order making up the whole list (a reader that splits its input file G ways; no rank ever holds all E endpoints).
+        Degrees are all-reduced ([N] int64) for the range boundaries, then every edge travels once to the owner of its
+        destination and, when that is another rank, once to the owner of its source (one all_to_all of (src, dst, id) triples).
+        The ids a rank receives arrive ascending - peer blocks in rank order, each ascending - so the local edge order, and with
+        it every later array, equals from_global's.  The same route moves edge features: shuffle_edge_rows(e_slice)."""
+        self = cls()
+        src = torch.as_tensor(src_slice).to(device).long()
+        dst = torch.as_tensor(dst_slice).to(device).long()
+        self.rank, self.world = rank, world
+        alone = _alone(world)
+        m = torch.tensor([src.numel()], dtype=torch.int64, device=device)
+        counts = m.view(1, 1) if alone else all_gather_rows(m, world, group)
+        counts = counts.view(-1).tolist()
+        self.num_edges_global = int(sum(counts))
+        offset = int(sum(counts[:rank]))
+        deg = torch.stack([torch.bincount(dst, minlength=num_nodes), torch.bincount(src, minlength=num_nodes)])   # in | out, this slice
+        if not alone:
+            all_reduce_sum(deg, group)
+        self.global_degrees = deg        # [2, N] int64 of the WHOLE graph: what inference.py:416-420 z-scores into x
+        self.bounds = split_by_degree(deg[0] + deg[1], num_nodes, world)
+        bt = torch.tensor(self.bounds[1:-1], device=device, dtype=torch.long)
+        owner_d, owner_s = torch.bucketize(dst, bt, right=True), torch.bucketize(src, bt, right=True)
+        gid = torch.arange(offset, offset + src.numel(), device=device)
+        second = owner_s != owner_d
+        to_rank = torch.cat([owner_d, owner_s[second]])
+        which = torch.cat([torch.arange(src.numel(), device=device), torch.nonzero(second).squeeze(1)])
+        order = torch.argsort(to_rank * (self.num_edges_global + 1) + gid[which])     # by receiving rank, then by global id
+        self._slice_rows = which[order]                                                # slice row of every record sent
+        self._slice_send = torch.bincount(to_rank, minlength=world).tolist()
+        sc = torch.tensor(self._slice_send, dtype=torch.int64, device=device)
+        rc = torch.empty(world, dtype=torch.int64, device=device)
+        if alone:
+            rc.copy_(sc)
+        else:
+            all_to_all_rows(rc, sc, None, None, group)
+        self._slice_recv = rc.tolist()
+        triples = torch.stack([src, dst, gid], 1)[self._slice_rows].contiguous()
+        got = torch.empty((sum(self._slice_recv), 3), dtype=torch.int64, device=device)
+        if alone:
+            got.copy_(triples)
+        else:
+            all_to_all_rows(got, triples, self._slice_recv, self._slice_send, group)
+        self.edge_gid = got[:, 2].contiguous()
+        assert self.edge_gid.numel() < 2 or bool((self.edge_gid[1:] > self.edge_gid[:-1]).all()), "edge ids must arrive ascending"
+        return self._build(got[:, 0].contiguous(), got[:, 1].contiguous(), device, ops, group)
+
+    def shuffle_edge_rows(self, rows_slice):
+        """[m_r, F] rows of this rank's edge slice (features, labels) -> the rows of its LOCAL edges, in local edge-id order (the
+        route from_slices sent the endpoints along)."""
+        if not hasattr(self, "_slice_rows"):
+            raise RuntimeError("shuffle_edge_rows needs a plan built by from_slices")
+        rows_slice = torch.as_tensor(rows_slice)
+        flat = rows_slice.reshape(rows_slice.shape[0], -1).to(self._slice_rows.device)
+        out = torch.empty((sum(self._slice_recv), flat.shape[1]), dtype=flat.dtype, device=flat.device)
+        packed = flat[self._slice_rows].contiguous()
+        if _alone(self.world):
+            out.copy_(packed)
+        else:
+            all_to_all_rows(out, packed, self._slice_recv, self._slice_send, self._group)
+        return out.reshape((out.shape[0],) + tuple(rows_slice.shape[1:]))
+
+    def local_degree_features(self):
+        """x rows of this rank's owned + halo nodes, [zscore(in_degree) | zscore(out_degree)] of the WHOLE graph (inference.py:416-420;
+        mean and unbiased std in fp64, applied in fp32 like gnnome_degree_features_f32), from the degrees from_slices all-reduced."""
+        if not hasattr(self, "global_degrees"):
+            raise RuntimeError("local_degree_features needs a plan built by from_slices")
+        d = self.global_degrees.double()
+        mean, std = d.mean(1, keepdim=True), d.std(1, keepdim=True)
+        local = self.global_degrees[:, self.node_gid].float()
+        return ((local - mean.float()) / std.float()).t().contiguous()
+
+    def _build(self, ls, ld, device, ops, group):
+        """Everything after the rank knows its local edges (ls, ld: global endpoints, ascending global edge id)."""
+        rank, world = self.rank, self.world
+        self._group = group
+        lo, hi = self.bounds[rank], self.bounds[rank + 1]
+        self.lo, self.hi, self.n_own = lo, hi, hi - lo
+        own_d = (ld >= lo) & (ld < hi)
         ends = torch.cat([ls, ld])
         halo = torch.unique(ends[(ends < lo) | (ends >= hi)])  # ascending => grouped by owner rank
         self.node_gid = torch.cat([torch.arange(lo, hi, device=halo.device), halo])
@@ -447,14 +530,16 @@ class _ScoreViews:
 class PartitionedRunner:
     """Holds one rank's partition, weights and inputs on its GPU; forward() = one whole-graph scoring pass."""
 
-    def __init__(self, model, part, x_global, e_global, device, ops=hip_ops, group=None, x_local=None):
+    def __init__(self, model, part, x_global, e_global, device, ops=hip_ops, group=None, x_local=None, e_local=None):
         """x_global[N,F]: the node features of the whole graph (this rank keeps its owned + halo rows), or x_local: those rows
-        already selected (part.local_node_rows), for callers that never hold the [N,F] table on this device."""
+        already selected (part.local_node_rows), for callers that never hold the [N,F] table on this device; e_global[E,F] or
+        e_local (part.local_edge_rows / part.shuffle_edge_rows) likewise."""
         self.ops, self.part, self.group, self.model = ops, part, group, model
         self.prep = None if model.training else engine.prepared_for(model, device, engine.Prepared)
         rows = part.local_node_rows(x_global) if x_local is None else x_local
         self.x = rows.to(device=device, dtype=torch.float32).contiguous()
-        self.e = part.local_edge_rows(e_global).to(device=device, dtype=torch.float32).contiguous()
+        erows = part.local_edge_rows(e_global) if e_local is None else e_local
+        self.e = erows.to(device=device, dtype=torch.float32).contiguous()
 
     def capture(self):
         """Record the forward as hipGraph segments between the collectives (CapturedPartitionedForward); forward() replays them."""

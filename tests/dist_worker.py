@@ -54,6 +54,22 @@ def worker(rank, world, port, case, out_dir):
         else:
             backend, where = cpu_ops, torch.device("cpu")
         part = gdist.PartitionedGraph.from_global(g["src"], g["dst"], g["num_nodes"], rank, world, where, ops=backend)
+        if g.get("sliced"):
+            # the same plan from this rank's SLICE of the edge list (uneven slices, rank order): must equal from_global's, array by array
+            E = int(g["src"].numel())
+            cuts = [0] + [min(E, (E * (r + 1)) // world + (37 if r + 1 < world else 0)) for r in range(world)]
+            a, b = cuts[rank], cuts[rank + 1]
+            sl = gdist.PartitionedGraph.from_slices(g["src"][a:b], g["dst"][a:b], g["num_nodes"], rank, world, where, ops=backend)
+            same = all(torch.equal(getattr(sl, k).cpu(), getattr(part, k).cpu()) for k in ("node_gid", "edge_gid", "srt_geid", "send_idx")) and \
+                all(getattr(sl, k) == getattr(part, k) for k in ("bounds", "n_own", "n_local", "n_score", "send_counts", "recv_counts", "score_pad",
+                                                               "num_edges_global")) and \
+                all(torch.equal(getattr(sl.views, k).cpu(), getattr(part.views, k).cpu()) for k in ("in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos"))
+            e_rows = sl.shuffle_edge_rows(g["e"][a:b])
+            same = same and torch.equal(e_rows.cpu(), part.local_edge_rows(g["e"]).cpu())
+            x_rows = sl.local_degree_features()
+            same = same and torch.allclose(x_rows.cpu(), part.local_node_rows(g["x"]).cpu(), atol=2e-6, rtol=1e-6)
+            part_sliced_equal = bool(same)
+            part = sl      # and the run below uses the sliced plan
         if g.get("train"):
             # train.py:138-145 + :328-330 on the partition: every rank computes the loss on the assembled logits
             import torch.nn.functional as F
@@ -80,7 +96,8 @@ def worker(rank, world, port, case, out_dir):
             replayed = runner.forward().squeeze(1).cpu()
         torch.save({"logits": logits.cpu(), "replayed": replayed, "n_own": part.n_own, "n_local": part.n_local, "n_score": part.n_score,
                     "e_local": int(part.edge_gid.numel()), "bounds": part.bounds, "send": part.send_counts,
-                    "recv": part.recv_counts, "backend": dist.get_backend(), "score_index": part.score_index is not None},
+                    "recv": part.recv_counts, "backend": dist.get_backend(), "score_index": part.score_index is not None,
+                    "sliced_equal": part_sliced_equal if g.get("sliced") else None},
                    os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()

@@ -220,3 +220,19 @@ def test_partition_census_predicts_what_every_rank_builds(kind, world, tmp_path)
             (r["owned_nodes"], r["halo_rows"], r["local_edges"], r["owned_in_edges"], r["rows_sent_per_layer"], r["largest_link_rows"])
     assert abs(c["edge_replication"] - sum(o["e_local"] for o in outs) / e) < 1e-12
     assert (c["cut_fraction"] < 0.05) == (kind == "banded")
+
+
+@pytest.mark.parametrize("kind,world", [("banded", 2), ("uniform", 3), ("banded", 1)])
+def test_plan_from_edge_list_slices_equals_plan_from_the_whole_list(kind, world, tmp_path):
+    """PartitionedGraph.from_slices: every rank starts from ITS slice of the edge list (uneven slices), degrees are all-reduced,
+    edges travel to the owners of their endpoints - and the plan, the views, the shuffled edge features and the z-scored degree
+    features equal from_global's, so the forward gives the same logits (no rank needs the whole edge list)."""
+    n, e = 3000, 30000
+    gr = make_graph(n, e, seed=9, kind=kind)
+    sd = random_state_dict(64, num_layers=2, seed=1)
+    x = degree_features(gr["src"], gr["dst"], n)
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], hidden=64, layers=2, state_dict=sd)
+    whole = _run(world, case, tmp_path)
+    sliced = _run(world, dict(case, sliced=True), tmp_path)
+    assert all(o["sliced_equal"] for o in sliced)
+    assert all(torch.equal(a["logits"], b["logits"]) for a, b in zip(whole, sliced))

@@ -215,8 +215,8 @@ def test_one_rank_over_rccl_with_forced_collectives_equals_the_plain_path(tmp_pa
     case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=degree_features(gr["src"], gr["dst"], n), e=gr["e"], hidden=hidden, layers=8,
                 state_dict=random_state_dict(hidden, seed=2), device="cuda", captured=True)
     plain = _run(1, case, tmp_path)[0]
-    rccl = _run(1, dict(case, transport="nccl", force_collectives=True), tmp_path)[0]
-    assert rccl["backend"] == "nccl" and rccl["score_index"] and not plain["score_index"]
+    rccl = _run(1, dict(case, transport="nccl", force_collectives=True, sliced=True), tmp_path)[0]   # (+ the plan from edge-list slices)
+    assert rccl["backend"] == "nccl" and rccl["score_index"] and not plain["score_index"] and rccl["sliced_equal"]
     assert torch.equal(plain["logits"], rccl["logits"]) and torch.equal(rccl["replayed"], rccl["logits"])
 
     g = load_golden("g3_train_h64.pt")

@@ -612,6 +612,57 @@ def test_training_step_h256_at_the_configs3_shard_on_two_sets_of_kernels():
     assert (num / den) ** 0.5 <= 1e-3
 
 
+def test_training_step_at_the_configs4_shard_stored_recomputed_and_on_the_other_kernels():
+    """One GPU's eighth of BASELINE configs[4] (N = 625k, E = 6.25M, H = 256: what a rank of the 8-GPU training step holds;
+    train.py:138-145, 328-330).  (1) the step runs and is finite at this size, inside the memory bench.py budgets for it
+    (35.3 KB per local edge reserved, measured: profiles/r04_bench_train_c5shard.json); (2) model.recompute_gate - xe not kept,
+    the raw gate launched again in the backward - gives the SAME BITS (logits, loss, all 142 gradients, BatchNorm buffers) with
+    less memory, which also shows every kernel of the step to be deterministic at this size; (3) the kernels each of these
+    replaced (streaming gate, tile GEMMs, 128 x 128 weight gradients, row-per-lane score tail) tell the same story."""
+    from gnnome_amd.loss import bce_loss as hip_bce
+    n, e, hidden = 625_000, 6_250_000, 256
+    gr = make_graph(n, e, seed=3)
+    views = gnnome_amd.graph.views_for((gr["src"], gr["dst"], n), dev())
+    x, ef, y, pw = ops.degree_features(views), gr["e"].to(dev()), gr["y"].to(dev()), gr["pos_weight"].to(dev())
+
+    def step(recompute=False):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev())
+        m = _train_model(random_state_dict(hidden, seed=7), hidden)
+        m.recompute_gate = recompute
+        logits = m(views, x, ef)
+        loss = hip_bce(logits.squeeze(-1), y, pw)
+        loss.backward()
+        torch.cuda.synchronize()
+        return (logits.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                {k: b.clone() for k, b in m.named_buffers()}, torch.cuda.max_memory_reserved(dev()))
+    stored = step()
+    assert torch.isfinite(stored[1]) and all(torch.isfinite(v).all() for v in stored[2].values()) and len(stored[2]) == 142
+    assert stored[4] <= 37_000 * e, f"{stored[4] / e:.0f} B per edge reserved"       # bench.py's budget: 35.3 KB measured
+    again = step(recompute=True)
+    assert torch.equal(stored[0], again[0]) and torch.equal(stored[1], again[1])
+    assert all(torch.equal(stored[2][k], again[2][k]) for k in stored[2]) and all(torch.equal(stored[3][k], again[3][k]) for k in stored[3])
+    assert again[4] <= 31_000 * e and again[4] < stored[4] - 4_000 * e, f"{again[4] / e:.0f} B per edge reserved with recompute_gate"
+    try:
+        ops.set_tuning(2, 5)
+        ops.set_tuning(4, 79)
+        ops.set_tuning(0, 9)
+        old = step()
+    finally:
+        ops.set_tuning(2, 0)
+        ops.set_tuning(4, 0)
+        ops.set_tuning(0, 0)
+    assert abs(old[1].item() - stored[1].item()) <= 1e-5 * abs(stored[1].item())
+    assert (torch.sigmoid(old[0]) - torch.sigmoid(stored[0])).abs().max().item() <= 1e-4
+    num = den = 0.0
+    for k, gk in stored[2].items():
+        d, s_ = (old[2][k] - gk).double(), gk.double()
+        num, den = num + float((d * d).sum()), den + float((s_ * s_).sum())
+        assert float(d.abs().max()) <= 2e-2 * max(float(s_.abs().max()), 1e-6), k
+    assert (num / den) ** 0.5 <= 1e-3
+
+
 @pytest.mark.parametrize("rows,H", [(777, 64), (40_003, 128), (300, 256), (5000, 16)])
 def test_layernorm_kernels(rows, H):
     """gnnome_ln_relu_res_f32 / gnnome_ln_bwd_f32 against an fp64 evaluation of their contract (torch autograd)."""
