@@ -11,7 +11,7 @@ namespace gnnome {
 void set_error(const char* fmt, ...);
 
 // Tuning knobs (gnnome_set_tuning): variant selection for A/B measurements; 0 = the shipped default.
-enum { kTuneGateVariant = 0, kTuneGateAblation = 1, kTuneLinearVariant = 2, kTuneGateTileOrder = 3, kTuneGateExperiment = 4, kTuneAggLdsKiB = 5, kTuneAggHubs = 6, kTuneAggVariant = 7, kTuneRefVariant = 8, kTuneCount = 16 };
+enum { kTuneGateVariant = 0, kTuneGateAblation = 1, kTuneLinearVariant = 2, kTuneGateTileOrder = 3, kTuneGateExperiment = 4, kTuneAggLdsKiB = 5, kTuneAggHubs = 6, kTuneAggVariant = 7, kTuneRefVariant = 8, kTuneOverlapBand = 9, kTuneCount = 16 };
 int tuning(int key);
 
 // Layer 0 only: the e tile is not loaded but COMPUTED by the load waves from the raw edge features,

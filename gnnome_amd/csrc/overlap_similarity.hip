@@ -23,6 +23,19 @@
 // traffic to speak of (the two strings are read once) - this path is bound by the integer VALU rate.
 // Reads are addressed in place: node 2r reads read r forwards, node 2r+1 reads it backwards through the complement half of
 // the symbol table - no reverse-complemented copy of the reads exists.
+//
+// Round 4: an Ukkonen BAND in front of it (k_overlap_banded).  The full matrix costs m * n cells; overlaps between accurate
+// reads differ in a few dozen positions, and an alignment of cost d never leaves the diagonals [min(0, n-m) - d, max(0, n-m) + d].
+// The banded pass runs the same block recurrence over a window of 8 blocks (256 query rows) that slides down one block every
+// 32 target columns - ONE THREAD per overlap, window state in registers, no LDS besides the symbol table:
+//   * cells outside the window count as upper bounds (a block enters with Pv = all +1, the first block of a column takes
+//     hin = +1), so the banded value is >= the true distance, and it IS the true distance whenever it is <= the band's k
+//     (then the optimal path lies inside the band and every cell on it was computed from true predecessors);
+//   * match masks are not tabulated: a block keeps its 32 query symbols as NP bit planes (NP = 2 / 3 / 4 for alphabets of
+//     <= 4 / 8 / 16 symbols) and Eq = AND_k (plane_k XOR ~column_bit_k) costs 2 NP - 1 integer operations per block step;
+//   * an overlap whose banded value exceeds k (k = 96 for m = n; smaller when the lengths differ, none when they differ by
+//     more than ~190), or whose alphabet has more than 16 symbols, is left marked for the full-matrix wave kernels below.
+// ~8 block steps per column instead of m / 32: a 7.7 kb HiFi-grade overlap costs 1/30 of the cells.
 #include "common.h"
 
 #include <algorithm>
@@ -53,6 +66,172 @@ __device__ __forceinline__ int class_of(int m) {
     return need <= 4 ? need : need <= 6 ? 6 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 0;
 }
 
+constexpr int kNeedFull = -3;   // dist_out value of an overlap that still wants the full-matrix kernel (never leaves this file)
+constexpr int kBandW = 8;       // blocks in the sliding window
+
+// m, n of an edge exactly as the full kernel defines them (read_src[-ol:] is the whole read when ol exceeds its length)
+__device__ __forceinline__ void overlap_shape(const int64_t* __restrict__ read_off, int u, int v, int L, int& m, int& n, int& ulen, int& vlen) {
+    ulen = (int)(read_off[(u >> 1) + 1] - read_off[u >> 1]);
+    vlen = (int)(read_off[(v >> 1) + 1] - read_off[v >> 1]);
+    m = max(min(L, ulen), 0);
+    n = max(min(L, vlen), 0);
+}
+
+// every edge: the trivial cases are answered here, the rest is marked for the banded / full kernels
+__global__ void k_overlap_prepare(const int64_t* __restrict__ read_off, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                  const int32_t* __restrict__ ol, int64_t E, int32_t* __restrict__ dist_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    int m, n, ulen, vlen;
+    overlap_shape(read_off, src[i], dst[i], ol[i], m, n, ulen, vlen);
+    dist_out[i] = (m == 0 || n == 0) ? max(m, n) : kNeedFull;   // an empty side: the distance is the other side's length
+}
+
+__global__ void k_overlap_finish(int64_t E, int32_t* __restrict__ dist_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < E && dist_out[i] == kNeedFull) dist_out[i] = -1;   // no kernel could take it (too long / alphabet too large for LDS): reported, not guessed
+}
+
+template <int NP>
+__global__ __launch_bounds__(64) void k_overlap_banded(const uint8_t* __restrict__ reads, const int64_t* __restrict__ read_off,
+                                                       const uint8_t* __restrict__ symtab, const int32_t* __restrict__ src,
+                                                       const int32_t* __restrict__ dst, const int32_t* __restrict__ ol, int64_t E,
+                                                       int* __restrict__ ticket, int32_t* __restrict__ dist_out) {
+    __shared__ uint8_t st[512];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 128; i += 64) reinterpret_cast<uint32_t*>(st)[i] = reinterpret_cast<const uint32_t*>(symtab)[i];
+    __syncthreads();
+    for (;;) {
+        int first = 0;
+        if (lane == 0) first = atomicAdd(ticket, 64);
+        first = __builtin_amdgcn_readfirstlane(first);
+        if (first >= E) break;
+        const int64_t ed = (int64_t)first + lane;
+        if (ed >= E || dist_out[ed] != kNeedFull) continue;
+        const int u = src[ed], v = dst[ed];
+        int m, n, ulen, vlen;
+        overlap_shape(read_off, u, v, ol[ed], m, n, ulen, vlen);
+        // the band: diagonals c - r in [lo, hi] = [min(0, n-m) - k, max(0, n-m) + k]; in chunk q (columns 32 q .. 32 q + 31) the
+        // window holds the blocks q - U .. q - U + 7, which covers the band when U >= ceil(hi / 32) and 7 - U >= floor((31 - lo) / 32)
+        const int delta = n - m, a = max(delta, 0), bneg = -min(delta, 0);
+        int k = -1, U = 0;
+        for (int kk = 96; kk >= 16; kk -= 16) {
+            const int uu = (a + kk + 31) / 32, dn = (31 + kk + bneg) / 32;
+            if (uu + dn <= kBandW - 1) { k = kk, U = uu; break; }
+        }
+        if (k < 0) continue;   // the lengths differ by too much for this window: the full kernel
+        const int64_t uo = read_off[u >> 1], vo = read_off[v >> 1];
+        const bool urc = u & 1, vrc = v & 1;
+        const uint8_t* stu = st + (urc ? 256 : 0);
+        const uint8_t* stv = st + (vrc ? 256 : 0);
+        const int bmax = (m - 1) / 32;
+        uint32_t Pv[kBandW], Mv[kBandW], pl[NP][kBandW];
+        // the NP bit planes of query block b (rows past the end of the query keep plane bits 0: whatever they match, rows above
+        // them do not depend on it, and their vertical deltas are taken off the score at the end)
+        auto load_block = [&](int b, uint32_t (&out)[NP]) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) out[j] = 0u;
+            const int base = 32 * b;
+            uint8_t raw[32];
+#pragma unroll
+            for (int bit = 0; bit < 32; ++bit) {
+                const int p = ulen - m + min(base + bit, m - 1);
+                raw[bit] = urc ? reads[uo + (ulen - 1 - p)] : reads[uo + p];
+            }
+#pragma unroll
+            for (int bit = 0; bit < 32; ++bit) {
+                const uint32_t sy = base + bit < m ? stu[raw[bit]] : 0u;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) out[j] |= ((sy >> j) & 1u) << bit;
+            }
+        };
+        int score = 0;
+#pragma unroll
+        for (int i = 0; i < kBandW; ++i) {
+            Pv[i] = 0xFFFFFFFFu, Mv[i] = 0u;
+            const int b = i - U;
+            uint32_t t[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) t[j] = 0u;
+            if (b >= 0 && b <= bmax) {
+                load_block(b, t);
+                score += 32;   // column 0 of the NW matrix: D[i][0] = i
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) pl[j][i] = t[j];
+        }
+        const int chunks = (n + 31) / 32;
+        for (int q = 0; q < chunks; ++q) {
+            const int fb = q - U;   // block at window index 0
+            if (q > 0) {
+#pragma unroll
+                for (int i = 0; i + 1 < kBandW; ++i) {
+                    Pv[i] = Pv[i + 1], Mv[i] = Mv[i + 1];
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) pl[j][i] = pl[j][i + 1];
+                }
+                const int b = fb + kBandW - 1;
+                uint32_t t[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) t[j] = 0u;
+                Pv[kBandW - 1] = 0xFFFFFFFFu, Mv[kBandW - 1] = 0u;
+                if (b >= 0 && b <= bmax) {
+                    load_block(b, t);
+                    score += 32;   // the block enters one column late as an upper bound: every row + 1 on the row above
+                }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) pl[j][kBandW - 1] = t[j];
+            }
+            const int il = min(kBandW - 1, bmax - fb);   // window index of the lowest block that exists: its bottom row carries `score`
+            // this chunk's 32 target symbols, 4 bits each
+            uint32_t tsym[4] = {0u, 0u, 0u, 0u};
+            {
+                uint8_t raw[32];
+#pragma unroll
+                for (int cc = 0; cc < 32; ++cc) {
+                    const int j = min(32 * q + cc, n - 1);
+                    raw[cc] = vrc ? reads[vo + (vlen - 1 - j)] : reads[vo + j];
+                }
+#pragma unroll
+                for (int cc = 0; cc < 32; ++cc) tsym[cc >> 3] |= (uint32_t)stv[raw[cc]] << (4 * (cc & 7));
+            }
+            const int cols = min(32, n - 32 * q);
+            for (int cc = 0; cc < cols; ++cc) {
+                const uint32_t sy = (tsym[cc >> 3] >> (4 * (cc & 7))) & 15u;
+                uint32_t inv[NP];   // ~(bit j of the column's symbol, spread over the word): plane ^ inv has a 1 where the plane bit EQUALS it
+#pragma unroll
+                for (int j = 0; j < NP; ++j) inv[j] = ((sy >> j) & 1u) - 1u;
+                int h = 1;   // the first block of the column: row 0 of the NW matrix (+1 per column), or an upper bound below it
+#pragma unroll
+                for (int i = 0; i < kBandW; ++i) {
+                    if (fb + i >= 0 && i <= il) {
+                        uint32_t eq = pl[0][i] ^ inv[0];
+#pragma unroll
+                        for (int j = 1; j < NP; ++j) eq &= pl[j][i] ^ inv[j];
+                        h = myers_block(Pv[i], Mv[i], eq, h);
+                        if (i == il) score += h;
+                    }
+                }
+            }
+        }
+        // D[m][n]: take the vertical deltas of the rows below the query's last one off the bottom of block bmax
+        const int ib = bmax - (chunks - 1 - U);
+        int result = kNeedFull;
+        if (ib >= 0 && ib < kBandW) {
+            uint32_t pv = 0u, mv = 0u;
+#pragma unroll
+            for (int i = 0; i < kBandW; ++i)
+                if (i == ib) pv = Pv[i], mv = Mv[i];
+            const int used = m - 32 * bmax;   // rows of the last block that belong to the query (1..32)
+            const uint32_t mask = used >= 32 ? 0u : (0xFFFFFFFFu << used);
+            const int d = score - (__popc(pv & mask) - __popc(mv & mask));
+            if (d <= k) result = d;   // inside the band: exact.  Otherwise only an upper bound: the full kernel decides
+        }
+        dist_out[ed] = result;
+        if (result != kNeedFull) atomicAdd(ticket + 1, 1);   // workspace int 11: overlaps the band settled (statistics only)
+    }
+}
+
 // One workgroup = one wave.  Every class's launch walks the whole edge list through its own ticket counter and takes the
 // edges of its class (a skipped edge costs three integer loads); no host-side sort, no host sync.
 template <int B>
@@ -81,13 +260,9 @@ __global__ __launch_bounds__(64) void k_overlap_edit_distance(const uint8_t* __r
             const int vlen = (int)(read_off[(v >> 1) + 1] - read_off[v >> 1]);
             mine_m = max(min(L, ulen), 0);   // read_src[-ol:] is the whole read when ol exceeds its length
             mine_n = max(min(L, vlen), 0);
-            if (mine_m == 0 || mine_n == 0) {
-                if (B == 1) dist_out[cand] = max(mine_m, mine_n);   // an empty side: the distance is the other side's length
-            } else {
-                const int cls = class_of(mine_m);
-                if (cls == 0 && B == 32) dist_out[cand] = -1;       // longer than 65 536 rows: reported, not guessed
-                take = cls == B;
-            }
+            // (empty sides were answered by k_overlap_prepare, overlaps inside the band by k_overlap_banded; a query longer than
+            //  65 536 rows has no class and keeps its mark, which k_overlap_finish turns into -1: reported, not guessed)
+            take = mine_m > 0 && mine_n > 0 && class_of(mine_m) == B && dist_out[cand] == kNeedFull;
         }
         unsigned long long todo = __ballot(take);
         while (todo) {
@@ -208,6 +383,19 @@ extern "C" int gnnome_overlap_edit_distance(const uint8_t* reads, const int64_t*
     hipStream_t s = (hipStream_t)stream;
     int* tickets = reinterpret_cast<int*>(workspace);
     GN_HIP(hipMemsetAsync(tickets, 0, 16 * sizeof(int), s));
+    const unsigned eb = (unsigned)((num_edges + 255) / 256);
+    hipLaunchKernelGGL(k_overlap_prepare, dim3(eb), dim3(256), 0, s, read_off, src, dst, overlap_length, num_edges, dist_out);
+    GN_LAUNCH_CHECK();
+    if (tuning(kTuneOverlapBand) != 1 && num_symbols <= 16) {   // (key 9 = 1: full-matrix kernels only, for A/B runs and cross-checks)
+        const int bgrid = (int)std::min<int64_t>((num_edges + 63) / 64, (int64_t)persistent_grid() * 32);
+        if (num_symbols <= 4)
+            hipLaunchKernelGGL((k_overlap_banded<2>), dim3((unsigned)bgrid), dim3(64), 0, s, reads, read_off, symtab, src, dst, overlap_length, num_edges, tickets + 10, dist_out);
+        else if (num_symbols <= 8)
+            hipLaunchKernelGGL((k_overlap_banded<3>), dim3((unsigned)bgrid), dim3(64), 0, s, reads, read_off, symtab, src, dst, overlap_length, num_edges, tickets + 10, dist_out);
+        else
+            hipLaunchKernelGGL((k_overlap_banded<4>), dim3((unsigned)bgrid), dim3(64), 0, s, reads, read_off, symtab, src, dst, overlap_length, num_edges, tickets + 10, dist_out);
+        GN_LAUNCH_CHECK();
+    }
     // persistent waves: enough to fill every SIMD several times over (the kernel is VALU-bound, 8 waves per SIMD hide the
     // cross-lane and LDS latencies of one another), never more than there are 64-edge tickets
     const int grid = (int)std::min<int64_t>((num_edges + 63) / 64, (int64_t)persistent_grid() * 16);
@@ -228,6 +416,8 @@ extern "C" int gnnome_overlap_edit_distance(const uint8_t* reads, const int64_t*
     GN_CLASS(0, 1);
 #undef GN_CLASS
     if (rc != GNNOME_OK) return rc;
+    hipLaunchKernelGGL(k_overlap_finish, dim3(eb), dim3(256), 0, s, num_edges, dist_out);
+    GN_LAUNCH_CHECK();
     if (similarity_out) {
         hipLaunchKernelGGL(k_similarity, dim3((unsigned)((num_edges + 255) / 256)), dim3(256), 0, s, dist_out, overlap_length, num_edges, similarity_out);
         GN_LAUNCH_CHECK();

@@ -5,7 +5,8 @@
 `reads[r]` is read r as its S line gives it; node 2r is that read, node 2r+1 its reverse complement (graph_parser.py:174-181,
 :365).  For every edge the reference computes `1 - edlib.align(src_seq[-ol:], dst_seq[:ol])['editDistance'] / ol` (0.5 where
 ol == 0) on the CPU with the third-party aligner edlib; here the exact edit distances come from
-gnnome_overlap_edit_distance (csrc/overlap_similarity.hip: Myers' bit-vector programme, one wavefront per overlap) - no
+gnnome_overlap_edit_distance (csrc/overlap_similarity.hip: Myers' bit-vector programme - an Ukkonen band of 256 rows, one
+thread per overlap, settles every overlap whose distance is at most ~96; the full matrix, one wavefront per overlap, the rest) - no
 aligner dependency, no reverse-complemented copies of the reads, no CPU fallback.
 """
 import ctypes
@@ -49,9 +50,10 @@ def symbol_table(data):
     return torch.from_numpy(np.concatenate([index, index[COMPLEMENT]])), max(len(alphabet), 1)
 
 
-def edit_distances(reads, src, dst, overlap_length, device=None, with_similarity=True):
+def edit_distances(reads, src, dst, overlap_length, device=None, with_similarity=True, stats=None):
     """-> (dist int32[E], similarity float32[E] | None) on the device.  reads: list of sequences, or (uint8 data, int64
-    offsets) as pack_reads returns them."""
+    offsets) as pack_reads returns them.  stats: a dict that receives {"banded": overlaps settled by the Ukkonen-band pass,
+    "edges": E} (the rest went through the full-matrix kernels; both are exact)."""
     lib = _lib.load()
     device = device or torch.device("cuda", torch.cuda.current_device())
     data, off = reads if isinstance(reads, tuple) else pack_reads(reads)
@@ -75,6 +77,8 @@ def edit_distances(reads, src, dst, overlap_length, device=None, with_similarity
         _lib.check(lib.gnnome_overlap_edit_distance(_ptr(data), _ptr(off), off.numel() - 1, _ptr(symtab), nsym, _ptr(src), _ptr(dst), _ptr(ol),
                                                     E, _ptr(dist), _ptr(sim), _ptr(ws), ws.numel(), _stream(device)), "overlap_edit_distance")
     ws.record_stream(torch.cuda.current_stream(device))
+    if stats is not None:
+        stats.update(banded=int(ws.view(torch.int32)[11]) if E else 0, edges=E)
     if E and int(dist.min()) < 0:
         bad = int((dist < 0).sum())
         raise ValueError(f"{bad} overlaps could not be aligned on the device: longer than {MAX_OVERLAP} bases, or an alphabet of {nsym} "

@@ -63,7 +63,8 @@ const char* gnnome_last_error(void);
  *   key 6 aggregation hubs  : 1 = hub split path off
  *   key 7 aggregation variant: 1-5 items in flight / occupancy A/B, 6 unsplit item loop
  *   key 8 reference-order kernels: 0 the fp32 matrix cores (v_mfma_f32_32x32x2_f32 as a k-ascending fma chain), 1 the
- *                             scalar-fed VALU chains of round 2 (same bits) */
+ *                             scalar-fed VALU chains of round 2 (same bits)
+ *   key 9 overlap edit distance: 0 banded (Ukkonen) pass first, the full matrix for what exceeds the band; 1 full matrix only */
 int gnnome_set_tuning(int key, int value);
 
 /* Measurement only: when set to a device buffer of 256 x 8 int64, every launch of the edge-tile kernel leaves, per

@@ -157,3 +157,75 @@ def test_many_overlaps_of_assembly_shape_against_the_oracle():
     want_d, _ = overlap_oracle.calculate_similarities(reads, src, dst, ol)
     d, _ = overlap.edit_distances(reads, src, dst, ol, device=dev())
     assert d.cpu().tolist() == want_d
+
+
+def _with_edits(rng, s, subs, dels, ins):
+    """s with exactly `subs` substitutions, `dels` deletions and `ins` insertions at distinct, spread-out positions."""
+    pos = sorted(rng.sample(range(5, len(s) - 5), subs + dels + ins))
+    rng.shuffle(kinds := ["s"] * subs + ["d"] * dels + ["i"] * ins)
+    out, at = [], 0
+    for p, kd in zip(pos, kinds):
+        out.append(s[at:p])
+        if kd == "s":
+            out.append(rng.choice([c for c in "ACGT" if c != s[p]]))
+        elif kd == "i":
+            out.append(rng.choice("ACGT") + s[p])
+        at = p + 1
+    out.append(s[at:])
+    return "".join(out)
+
+
+@pytest.mark.gpu
+def test_banded_pass_is_exact_inside_its_band_and_hands_over_outside():
+    """Round 4: the Ukkonen-band kernel (one thread per overlap, a window of 256 query rows) in front of the full-matrix wave
+    kernel.  Around the band's k = 96: distances 80 .. 110 at equal lengths, length differences up to +-250 (k shrinks, then the
+    band is not used at all), all four orientations, queries shorter than a block, alphabets of 4 / 5 / 16 / 22 symbols -
+    default path, full-matrix-only path (tuning key 9) and the Wagner-Fischer oracle give the same integers; the statistics
+    say which kernel settled how many."""
+    from gnnome_amd import ops, overlap
+    rng = random.Random(11)
+    base = "".join(rng.choice("ACGT") for _ in range(4000))
+    reads, src, dst, ol = [], [], [], []
+
+    def pair(a, b, L=None):   # read 2i ends with a, read 2i+1 starts with b
+        reads.extend([base[:100] + a, b + base[200:300]])
+        r = len(reads) // 2 - 1
+        su, sv = rng.randrange(2), rng.randrange(2)
+        # a strand flip is expressed on the node id: node 2r+1 reads read r reverse-complemented, so store the reverse complement
+        if su:
+            reads[2 * r] = overlap_oracle.read_seqs([reads[2 * r]])[1]
+        if sv:
+            reads[2 * r + 1] = overlap_oracle.read_seqs([reads[2 * r + 1]])[1]
+        src.append(2 * (2 * r) + su), dst.append(2 * (2 * r + 1) + sv), ol.append(len(a) if L is None else L)
+    for d in list(range(80, 111, 3)) + [0, 1, 95, 96, 97]:
+        pair(base[:3000], _with_edits(rng, base[:3000], d, 0, 0))                          # equal lengths, d substitutions
+    for dl, ins in [(10, 0), (0, 10), (40, 5), (5, 40), (90, 0), (0, 90), (150, 0), (0, 150), (250, 3), (3, 250)]:
+        b = _with_edits(rng, base[:3000], 6, dl, ins)                                      # lengths differ by ins - dl
+        reads.extend([base[:3000], b])                                                     # ol beyond both reads: the whole reads, m != n
+        r = len(reads) // 2 - 1
+        src.append(2 * (2 * r)), dst.append(2 * (2 * r + 1)), ol.append(5000)
+    for ln in (1, 5, 31, 32, 33, 63, 64, 65, 200, 255, 256, 257):
+        pair(base[:ln], _with_edits(rng, base[:ln], min(2, max(ln - 12, 0)), 0, 0) if ln > 12 else base[:ln])
+    want_d, _ = overlap_oracle.calculate_similarities(reads, src, dst, ol)
+    st = {}
+    d, _ = overlap.edit_distances(reads, src, dst, ol, device=dev(), stats=st)
+    assert d.cpu().tolist() == want_d
+    inside = sum(1 for w, s_, t_, L in zip(want_d, src, dst, ol) if w <= 16 and L > 0)
+    assert st["edges"] == len(src) and inside <= st["banded"] < len(src)     # the far-off pairs were NOT settled by the band
+    try:
+        ops.set_tuning(9, 1)
+        st1 = {}
+        d1, _ = overlap.edit_distances(reads, src, dst, ol, device=dev(), stats=st1)
+    finally:
+        ops.set_tuning(9, 0)
+    assert st1["banded"] == 0 and d1.cpu().tolist() == want_d
+    # alphabets: 5 symbols (3 planes), 16 (4 planes), 22 (no band: full matrix only)
+    for alphabet, banded in (("ACGTN", True), ("ACGTNacgtnRYKMSW", True), ("ACGTNacgtnRYKMSWBDHVbd", False)):
+        g = "".join(rng.choice(alphabet) for _ in range(2500))
+        rd = [g, _mutate(rng, g, 0.01, alphabet), g[:700], _mutate(rng, g[:700], 0.3, alphabet)]
+        s2, d2, o2 = [0, 1, 3, 4, 2], [2, 3, 0, 6, 1], [2400, 2500, 2000, 700, 1500]
+        w2, _ = overlap_oracle.calculate_similarities(rd, s2, d2, o2)
+        st2 = {}
+        got, _ = overlap.edit_distances(rd, s2, d2, o2, device=dev(), stats=st2)
+        assert got.cpu().tolist() == w2, alphabet
+        assert (st2["banded"] > 0) == banded, (alphabet, st2)
