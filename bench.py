@@ -476,7 +476,10 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="default: 250 forwards at c2 (>= 1.2 s timed), fewer for the larger workloads")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: c2 at --gpus 1, 10m at --gpus > 1")
-    ap.add_argument("--kind", default="banded", choices=["banded", "uniform"])
+    ap.add_argument("--kind", default="banded", choices=["banded", "uniform", "permuted"],
+                    help="permuted: the banded graph with shuffled read ids (locality exists, the numbering hides it)")
+    ap.add_argument("--node-order", default="input", choices=["input", "locality"],
+                    help="locality: renumber the reads by gnnome_amd.node_order.locality_order once, outside the timed region")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: one forward (BASELINE configs[1]); train: the training step as the headline value (configs[2], fp32)")
     ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"], help="train: model.activation_storage (bf16 = xe / dxe stored as bfloat16)")
@@ -567,7 +570,18 @@ def main():
         ef = g["e"].to(dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        views = ops.GraphViews(src, dst, n)
+        node_perm, order_ms = None, None
+        if args.node_order == "locality":
+            from gnnome_amd import node_order as _order
+            _order.locality_order(src, dst, n)   # (first call: kernel code load)
+            torch.cuda.synchronize()
+            t_o = time.perf_counter()
+            node_perm, order_stats = _order.locality_order(src, dst, n, return_stats=True)
+            torch.cuda.synchronize()
+            order_ms = (time.perf_counter() - t_o) * 1e3
+            extras["node_order"] = dict(order_stats, ms=order_ms, kind="locality (gnnome_amd/node_order.py), computed once per graph, not timed")
+            t0 = time.perf_counter()
+        views = ops.GraphViews(src, dst, n, node_perm=node_perm)
         x = ops.degree_features(views)   # inference.py:416-420 on the device, off the views' CSR pointers
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -633,17 +647,21 @@ def main():
         if args.mode == "train":
             model.train()
             model.recompute_gate = args.recompute_gate
+        node_perm = None
+        if args.node_order == "locality":   # the order needs the whole graph once; every rank computes the same permutation on its GPU
+            from gnnome_amd import node_order as _order
+            node_perm = _order.locality_order(g["src"].to(dev), g["dst"].to(dev), n)
         if args.plan == "slices":
             # every rank starts from ITS 1/world of the edge list (as a reader splitting the input would): degrees all-reduced, edges
             # and their features shuffled to the owners of their endpoints (PartitionedGraph.from_slices) - no rank plans over E rows
             a, b = e * rank // world, e * (rank + 1) // world
-            plan = gdist.PartitionedGraph.from_slices(g["src"][a:b], g["dst"][a:b], n, rank, world, dev)
+            plan = gdist.PartitionedGraph.from_slices(g["src"][a:b], g["dst"][a:b], n, rank, world, dev, node_perm=node_perm)
             runner = gdist.PartitionedRunner(model, plan, None, None, dev, x_local=plan.local_degree_features(),
                                              e_local=plan.shuffle_edge_rows(g["e"][a:b].to(dev)))
         else:
             # every rank holds the edge list (as inference.py holds the whole graph): degree features of the WHOLE graph
             # on its own GPU, then each rank keeps the rows of its partition
-            plan = gdist.PartitionedGraph.from_global(g["src"], g["dst"], n, rank, world, dev)
+            plan = gdist.PartitionedGraph.from_global(g["src"], g["dst"], n, rank, world, dev, node_perm=node_perm)
             runner = gdist.PartitionedRunner(model, plan, None, g["e"], dev, x_local=_local_degree_features(ops, g, n, plan, dev))
         torch.cuda.synchronize()
         cold = {"partition_plan_views_features_ms": (time.perf_counter() - t0) * 1e3, "plan": args.plan}
@@ -748,6 +766,8 @@ def main():
                         f"{chunks_timed} node ranges (engine.aggregate_then_project)") if chunks_timed > 1 else "1",
         }
         res.update(extras)
+        if args.node_order != "input":
+            res["config"]["node_order"] = args.node_order
         if args.tuning:
             res["tuning"] = args.tuning   # not the shipped defaults
         if "scaling_reference" in extras:

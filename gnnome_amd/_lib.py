@@ -78,10 +78,12 @@ SIGNATURES = {
     "gnnome_mark_walk_visited": [_p, _p, _p, _l, _p, _p],
     "gnnome_overlap_workspace_bytes": [ctypes.POINTER(_sz)],
     "gnnome_overlap_edit_distance": [_p, _p, _l, _p, _i, _p, _p, _p, _l, _p, _p, _p, _sz, _p],
+    "gnnome_adjacency_support": [_p, _p, _p, _l, _l, _p, _p],
+    "gnnome_bfs_levels": [_p, _p, _l, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

@@ -106,16 +106,22 @@ class PartitionedGraph:
         self.send_idx = None        # int32 [sum(send_counts)] owned local rows to pack, grouped by peer
         self.send_counts = None     # python list, rows to send to each peer
         self.recv_counts = None     # python list, halo rows received from each peer (in halo order)
+        self.node_perm = self.node_gather = None   # optional renumbering the ranges were cut in (caller's id -> internal id, and back)
         self.score_pad = 0          # rows of the padded logits piece every rank contributes to the all_gather
         self.score_index = None     # int64 [E_global]: where global edge id k sits in the flattened [world, score_pad] gather
 
     @classmethod
-    def from_global(cls, src, dst, num_nodes, rank, world, device, ops=hip_ops, group=None):
+    def from_global(cls, src, dst, num_nodes, rank, world, device, ops=hip_ops, group=None, node_perm=None):
         """Build from the full edge list (every rank holds it in this harness, as inference.py holds the
         whole DGLGraph).  The plan is computed on `device` (masks, unique, searchsorted over the E-sized edge list: 0.9 s per
-        rank on the host at 10M edges) + one all_to_all of halo requests."""
+        rank on the host at 10M edges) + one all_to_all of halo requests.
+        node_perm (int64[N], the same on every rank; gnnome_amd.node_order.locality_order): the RANGES are cut in the renumbered
+        node order - for graphs whose ids do not follow the layout; local_node_rows still takes rows in the caller's numbering."""
         self = cls()
         src, dst = torch.as_tensor(src).to(device).long(), torch.as_tensor(dst).to(device).long()
+        if node_perm is not None:
+            self._set_node_perm(node_perm, num_nodes, device)
+            src, dst = self.node_perm[src], self.node_perm[dst]
         self.rank, self.world, self.num_edges_global = rank, world, int(src.numel())
         self.bounds = split_by_incident_edges(src, dst, num_nodes, world)
         lo, hi = self.bounds[rank], self.bounds[rank + 1]
@@ -124,7 +130,7 @@ class PartitionedGraph:
         return self._build(src[keep], dst[keep], device, ops, group)
 
     @classmethod
-    def from_slices(cls, src_slice, dst_slice, num_nodes, rank, world, device, ops=hip_ops, group=None):
+    def from_slices(cls, src_slice, dst_slice, num_nodes, rank, world, device, ops=hip_ops, group=None, node_perm=None):
         """Build from a rank's SLICE of the edge list: rank r holds the edges with global ids [off_r, off_r + m_r), the slices in
         rank order making up the whole list (a reader that splits its input file G ways; no rank ever holds all E endpoints).
         Degrees are all-reduced ([N] int64) for the range boundaries, then every edge travels once to the owner of its
@@ -134,6 +140,9 @@ class PartitionedGraph:
         self = cls()
         src = torch.as_tensor(src_slice).to(device).long()
         dst = torch.as_tensor(dst_slice).to(device).long()
+        if node_perm is not None:   # (as from_global: ranges over renumbered nodes; the permutation itself needs the whole graph once)
+            self._set_node_perm(node_perm, num_nodes, device)
+            src, dst = self.node_perm[src], self.node_perm[dst]
         self.rank, self.world = rank, world
         alone = _alone(world)
         m = torch.tensor([src.numel()], dtype=torch.int64, device=device)
@@ -269,8 +278,17 @@ class PartitionedGraph:
         gathered = all_gather_rows(piece, self.world, group).view(-1)
         return gathered.index_select(0, self.score_index)
 
+    def _set_node_perm(self, node_perm, num_nodes, device):
+        self.node_perm = torch.as_tensor(node_perm).to(device=device, dtype=torch.int64)
+        if self.node_perm.numel() != num_nodes:
+            raise ValueError(f"node_perm has {self.node_perm.numel()} entries for {num_nodes} nodes")
+        self.node_gather = torch.empty(num_nodes, dtype=torch.int64, device=device)
+        self.node_gather[self.node_perm] = torch.arange(num_nodes, device=device)
+
     def local_node_rows(self, x_global):
-        return x_global[self.node_gid.to(x_global.device)]
+        """Rows of this rank's owned + halo nodes out of a table in the CALLER's node numbering."""
+        gid = self.node_gid if self.node_gather is None else self.node_gather[self.node_gid]
+        return x_global[gid.to(x_global.device)]
 
     def local_edge_rows(self, e_global):
         return e_global[self.edge_gid.to(e_global.device)]

@@ -263,6 +263,15 @@ def layer_step(ops, lw, views, h, e, n_out=None, raw_edges=None, scratch=None, P
     return ops.node_aggregate(e, A1, A2, A3, views, h, lw.norm, lw.scale_h, lw.shift_h, num_nodes_out=n_out), e, None
 
 
+def encode_nodes(ops, views, x, enc):
+    """h0 in the views' node numbering: x arrives in the caller's, and views over renumbered nodes (GraphViews.node_perm,
+    gnnome_amd/node_order.py) read it through the encoder's gather argument - no permuted copy of x is made."""
+    gather = getattr(views, "node_gather", None)
+    if gather is None:
+        return ops.encode(x, *enc)
+    return ops.encode(x, *enc, gather=gather, rows=views.num_nodes)
+
+
 def encode_edges(ops, prep, views, e_raw):
     """e0 in sorted order - or None when layer 0's gate kernel will produce it on the fly."""
     fuse = getattr(ops, "can_fuse_edge_encoder", None)
@@ -292,7 +301,7 @@ def run_stack(ops, prep, views, x, e_raw, exchange=None, n_own=None, n_score=Non
     sorted positions (both used by the destination-range partition, dist.py).  With PIPELINE_CHUNKS > 1 (off by
     default: measured slower) every node projection after the first runs under the preceding aggregation on a second
     stream (aggregate_then_project)."""
-    h = ops.encode(x, *prep.enc_node)
+    h = encode_nodes(ops, views, x, prep.enc_node)
     e = encode_edges(ops, prep, views, e_raw)
     scratch = {}
     pipelined = (exchange is None and n_own is None and getattr(ops, "side_stream", None) is not None and PIPELINE_CHUNKS > 1
@@ -325,7 +334,7 @@ def model_forward(model, graph, x, e):
     out_device = x.device
     device = compute_device(x, e)
     prep = prepared_for(model, device, Prepared)
-    views = views_for(graph, device)
+    views = views_for(graph, device, node_order=getattr(model, "node_order", "input"))
     if x.shape[0] != views.num_nodes or e.shape[0] != views.num_edges:
         raise ValueError(f"x has {x.shape[0]} rows for {views.num_nodes} nodes, e has {e.shape[0]} rows for {views.num_edges} edges")
     with torch.no_grad():
@@ -347,7 +356,11 @@ def layer_forward_edge_id_order(conv, g, h, e):
         hd = h.detach().to(device=device, dtype=torch.float32).contiguous()
         ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
         es = hip_ops.gather_rows(ed, views.srt_eid)
+        if views.node_gather is not None:   # views over renumbered nodes: rows in, rows out in the caller's numbering
+            hd = hip_ops.gather_rows(hd, views.node_gather)
         h_new, _, _ = layer_step(hip_ops, lw, views, hd, es)
+        if views.node_perm is not None:
+            h_new = h_new.index_select(0, views.node_perm)
         e_new = torch.empty_like(es)
         e_new[views.srt_eid.long()] = es
         h_new = F.dropout(h_new, conv.dropout, training=conv.training)
@@ -365,6 +378,8 @@ def score_forward_edge_id_order(pred, graph, x, e):
         xd = x.detach().to(device=device, dtype=torch.float32).contiguous()
         ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
         es = hip_ops.gather_rows(ed, views.srt_eid)
+        if views.node_gather is not None:
+            xd = hip_ops.gather_rows(xd, views.node_gather)
         logits = torch.empty(views.num_edges, dtype=torch.float32, device=device)
         score_step(hip_ops, pw, views, xd, es, logits)
     views.check_range()

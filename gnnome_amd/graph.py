@@ -24,9 +24,21 @@ def edge_list(graph):
     return torch.as_tensor(src), torch.as_tensor(dst), int(n)
 
 
-def views_for(graph, device):
+NODE_ORDERS = ("input", "locality", "auto")
+AUTO_MIN_NODES = 20_000      # "auto": smaller graphs live in cache whatever their numbering
+AUTO_SPAN_FRACTION = 1 / 16  # "auto": renumber when the mean |src - dst| exceeds this fraction of the node count
+
+
+def views_for(graph, device, node_order="input"):
     """Build (or fetch the cached) views of `graph` on `device`.  Cached per graph OBJECT: callers such as
-    train.py:96 / :336 create fresh sub-graphs every step, which simply miss the cache."""
+    train.py:96 / :336 create fresh sub-graphs every step, which simply miss the cache.
+    node_order ("input" | "locality" | "auto"; `model.node_order`): "locality" builds the views over nodes renumbered by
+    gnnome_amd.node_order.locality_order - for graphs whose ids do not follow the layout (graph_parser.py:174-181 numbers reads
+    in S-line order) and that are scored or trained on more than once: the order costs tens of forwards to compute; "auto" does
+    so only for cacheable graph objects of at least AUTO_MIN_NODES nodes whose mean edge span says the ids are shuffled.
+    Callers never see the renumbering (GraphViews.node_perm)."""
+    if node_order not in NODE_ORDERS:
+        raise ValueError(f"node_order={node_order!r} not in {NODE_ORDERS}")
     if isinstance(graph, GraphViews):
         if graph.device != device:
             raise ValueError(f"GraphViews live on {graph.device}, inputs on {device}")
@@ -38,6 +50,8 @@ def views_for(graph, device):
             key = graph
         except TypeError:  # not weak-referenceable
             hit = None
+        if hit is not None and ((node_order == "locality" and hit.node_perm is None) or (node_order == "input" and hit.node_perm is not None)):
+            hit = None   # cached under the other numbering: build again
         if hit is not None and hit.device == device and hit.num_nodes == int(graph.num_nodes()):
             # (a graph mutated in place is a new graph to DGL as well - node_subgraph / reverse return fresh objects;
             # the edge count is re-checked where the object can tell it without building the edge list)
@@ -49,7 +63,13 @@ def views_for(graph, device):
     src, dst, n = edge_list(graph)
     src = src.to(device=device, dtype=torch.int32).contiguous()
     dst = dst.to(device=device, dtype=torch.int32).contiguous()
-    views = GraphViews(src, dst, n, validate="lazy")   # range check deferred: engine.model_forward / train_forward
+    perm = None
+    if node_order == "locality" or (node_order == "auto" and key is not None and n >= AUTO_MIN_NODES):
+        from . import node_order as order
+        cs, cd = src.clamp(0, max(n - 1, 0)), dst.clamp(0, max(n - 1, 0))
+        if node_order == "locality" or order.mean_edge_span(cs, cd) > AUTO_SPAN_FRACTION * n:   # ("auto": one host sync, cached graphs only)
+            perm = order.locality_order(cs, cd, n)
+    views = GraphViews(src, dst, n, validate="lazy", node_perm=perm)   # range check deferred: engine.model_forward / train_forward
     if key is not None:
         try:
             _cache[key] = views

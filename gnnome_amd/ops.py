@@ -81,10 +81,14 @@ class GraphViews:
     """In-edge / out-edge orderings of one edge list (see include/gnnome_hip.h, "graph views")."""
 
     __slots__ = ("num_nodes", "num_edges", "in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst", "device",
-                 "transposed", "_range", "_bad", "__weakref__")
+                 "transposed", "_range", "_bad", "node_perm", "node_gather", "__weakref__")
 
-    def __init__(self, src, dst, num_nodes, validate="now"):
-        """validate = "now": endpoints are range-checked before anything is built (one host sync).  "lazy": no host sync -
+    def __init__(self, src, dst, num_nodes, validate="now", node_perm=None):
+        """node_perm (int64[N], optional): the views are built over RENUMBERED nodes, node_perm[caller's id] = internal id
+        (gnnome_amd/node_order.py); node rows cross the boundary in the caller's numbering - x is gathered through
+        node_gather (internal id -> caller's id) by the node encoder, degree_features returns rows in the caller's order,
+        logits are per edge id and never notice.
+        validate = "now": endpoints are range-checked before anything is built (one host sync).  "lazy": no host sync -
         the extremes are reduced on the device, the endpoints are clamped into range so that no kernel can fault, and
         check_range() raises later (the model call does it once everything is enqueued); for callers that hand over a
         fresh graph every step (train.py:96, :336).  False: trusted input."""
@@ -103,6 +107,17 @@ class GraphViews:
             else:
                 self.check_range()
         self.num_nodes, self.num_edges, self.device, self.transposed = n, e, dev, False
+        self.node_perm = self.node_gather = None
+        if node_perm is not None:
+            node_perm = node_perm.to(device=dev, dtype=torch.int64)
+            if node_perm.numel() != n:
+                raise ValueError(f"node_perm has {node_perm.numel()} entries for {n} nodes")
+            gather = torch.empty(n, dtype=torch.int64, device=dev)
+            gather[node_perm] = torch.arange(n, device=dev)
+            self.node_perm, self.node_gather = node_perm, gather.int()
+            if validate != "lazy":   # ("lazy" already clamped the endpoints into range)
+                src, dst = src.clamp(0, max(n - 1, 0)), dst.clamp(0, max(n - 1, 0))
+            src, dst = node_perm[src.long()].int(), node_perm[dst.long()].int()
         mk = lambda k: torch.empty(k, dtype=torch.int32, device=dev)  # noqa: E731
         self.in_ptr, self.out_ptr = mk(n + 1), mk(n + 1)
         self.srt_src, self.srt_dst, self.srt_eid, self.out_pos, self.out_dst = mk(e), mk(e), mk(e), mk(e), mk(e)
@@ -783,6 +798,8 @@ def degree_features(views, reverse=False):
     ws = _closure_workspace(views.device)
     _call("gnnome_degree_features_f32", views.device, _ptr(views.in_ptr), _ptr(views.out_ptr), views.num_nodes, int(bool(reverse)), _ptr(x),
           _ptr(ws), ws.numel())
+    if views.node_perm is not None:   # rows in the caller's node numbering (the z-score is over all nodes: order-independent)
+        x = x.index_select(0, views.node_perm)
     return x
 
 

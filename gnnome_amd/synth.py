@@ -5,6 +5,8 @@ Structural conventions kept from the reference's graph builder:
   * every edge (u, v) has a mate (v^1, u^1) carrying the same features (graph_parser.py:300-340)
   * e = [zscore(overlap_length), overlap_similarity] (utils/data_utils.py:31-41)
 Edge ids are randomly permuted so the CSR build and the un-permute of the logits are exercised.
+kind: "banded" (reads in layout order, 1 % long-range edges), "uniform" (no locality at all), "permuted" (the banded graph with
+shuffled read ids: locality exists but the numbering hides it - gnnome_amd/node_order.py finds it again).
 """
 import numpy as np
 import torch
@@ -38,8 +40,14 @@ def make_graph(num_nodes, num_edges, seed=1, kind="banded"):
     assert num_nodes % 2 == 0 and num_edges % 2 == 0
     rng = np.random.default_rng(seed)
     half = num_edges // 2
-    if kind == "banded":
+    if kind in ("banded", "permuted"):
         u, v = _pairs_banded(num_nodes // 2, half, num_edges / num_nodes, rng)
+        if kind == "permuted":
+            # the banded graph with its READ ids shuffled (strands stay paired): what a GFA whose S lines are not in layout
+            # order gives (graph_parser.py:174-181 numbers reads in S-line order).  A generator of its own, so that the
+            # "banded" stream - and with it every other tensor of the graph - is the same as for kind="banded".
+            rp = np.random.default_rng(seed + 7919).permutation(num_nodes // 2).astype(np.int64)
+            u, v = 2 * rp[u >> 1] + (u & 1), 2 * rp[v >> 1] + (v & 1)
     elif kind == "uniform":
         u = rng.integers(0, num_nodes, size=half)
         v = rng.integers(0, num_nodes, size=half)

@@ -203,7 +203,9 @@ class _TrainStep(torch.autograd.Function):
         storage = _storage_dtype(model)
         recompute = _recompute_gate(model, storage)
 
-        h = ops.encode(x, d(model.linear1_node.weight), d(model.linear1_node.bias), d(model.linear2_node.weight), d(model.linear2_node.bias))
+        node_gather = getattr(views, "node_gather", None)   # views over renumbered nodes read x (caller's numbering) through it
+        h = ops.encode(x, d(model.linear1_node.weight), d(model.linear1_node.bias), d(model.linear2_node.weight), d(model.linear2_node.bias),
+                       **({} if node_gather is None else dict(gather=node_gather, rows=n_local)))
         e = ops.encode(e_raw, d(model.linear1_edge.weight), d(model.linear1_edge.bias), d(model.linear2_edge.weight),
                        d(model.linear2_edge.bias), gather=views.srt_eid, rows=e_local)
         saved = []
@@ -407,7 +409,7 @@ class _TrainStep(torch.autograd.Function):
             g[pfx1 + ".weight"] = ops.wgrad(dt, x4)[:, :F_].contiguous()
             g[pfx1 + ".bias"] = ops.colsum2(dt)[0] if dt.shape[1] in (16, 32, 64) else dt.sum(0)
 
-        encoder_bwd(dh, tail["x"], None, n_local, model.linear1_node, model.linear2_node, "linear1_node", "linear2_node")
+        encoder_bwd(dh, tail["x"], getattr(views, "node_gather", None), n_local, model.linear1_node, model.linear2_node, "linear1_node", "linear2_node")
         encoder_bwd(de, tail["e_raw"], views.srt_eid, e_local, model.linear1_edge, model.linear2_edge, "linear1_edge", "linear2_edge")
 
         ctx.saved = ctx.tail = None
@@ -419,7 +421,7 @@ def train_forward(model, graph, x, e):
     """`model(graph, x, e)` in train mode with autograd support: logits [E,1] on the compute device."""
     from .engine import compute_device
     device = compute_device(x, e)
-    views = views_for(graph, device)
+    views = views_for(graph, device, node_order=getattr(model, "node_order", "input"))
     xd = x.detach().to(device=device, dtype=torch.float32).contiguous()
     ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
     out = train_forward_on(model, WholeGraph(views), xd, ed)

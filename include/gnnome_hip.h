@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 8
+#define GNNOME_ABI_VERSION 9
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -465,6 +465,25 @@ int gnnome_overlap_edit_distance(const uint8_t* reads, const int64_t* read_off, 
                                  int num_symbols, const int32_t* src, const int32_t* dst, const int32_t* overlap_length,
                                  int64_t num_edges, int32_t* dist_out, float* similarity_out, void* workspace,
                                  size_t workspace_bytes, void* stream);
+
+/* ---- Node order (round 4): locality for inputs whose node ids do not follow the layout ---------------------------------------
+ * The reference numbers nodes in S-line order of the GFA (graph_parser.py:174-181: read r -> nodes 2r, 2r+1), which need not be
+ * the order of the reads along the genome; gnnome_amd/node_order.py renumbers the READS once per graph so that the
+ * destination-range partition (gnnome_amd/dist.py) cuts few edges and gathers hit L2.  Logits stay in edge-id order: nothing
+ * the reference's callers see changes.  Two kernels; sorting, compaction and the final numbering are torch operators.
+ *
+ * gnnome_adjacency_support: for every entry p of a CSR adjacency with SORTED rows (row_of[p] = its row), supported[p] = 1 iff
+ *   the two endpoints have a common neighbour (an overlap graph is locally transitive; repeat-induced edges are not).
+ * gnnome_bfs_levels: breadth-first levels of every component, one workgroup for the whole graph (the frontier of an overlap graph
+ *   is dozens of reads wide and tens of thousands of levels deep).  level_key[v] int32[num_nodes] = a counter that grows by one
+ *   per level and does not restart between components (-1: never reached - no neighbours); seeds / num_seeds (device, NULL: the
+ *   smallest unvisited id that has a neighbour starts the next component); far_node[c] = the smallest id in the last level of
+ *   component c; *num_components (device).  frontier_workspace: int32[2 * num_nodes].  Levels and far nodes are functions of the
+ *   graph alone. */
+int gnnome_adjacency_support(const int32_t* ptr, const int32_t* adj, const int32_t* row_of, int64_t num_rows, int64_t nnz,
+                             uint8_t* supported, void* stream);
+int gnnome_bfs_levels(const int32_t* ptr, const int32_t* adj, int64_t num_nodes, const int32_t* seeds, const int32_t* num_seeds,
+                      int32_t* level_key, int32_t* frontier_workspace, int32_t* far_node, int32_t* num_components, void* stream);
 
 /* ---- bf16 STORAGE of two training activations (activation_storage = "bf16", BASELINE configs[2]) ------------------------------
  * The reference trains in fp32 throughout; as an OPTION the pre-normalisation gate output xe[E,H] (written once, read three

@@ -53,13 +53,15 @@ def worker(rank, world, port, case, out_dir):
             g = {k: (v.to(where) if k in ("x", "e", "y", "pos_weight") else v) for k, v in g.items()}
         else:
             backend, where = cpu_ops, torch.device("cpu")
-        part = gdist.PartitionedGraph.from_global(g["src"], g["dst"], g["num_nodes"], rank, world, where, ops=backend)
+        part = gdist.PartitionedGraph.from_global(g["src"], g["dst"], g["num_nodes"], rank, world, where, ops=backend,
+                                                  node_perm=g.get("node_perm"))
         if g.get("sliced"):
             # the same plan from this rank's SLICE of the edge list (uneven slices, rank order): must equal from_global's, array by array
             E = int(g["src"].numel())
             cuts = [0] + [min(E, (E * (r + 1)) // world + (37 if r + 1 < world else 0)) for r in range(world)]
             a, b = cuts[rank], cuts[rank + 1]
-            sl = gdist.PartitionedGraph.from_slices(g["src"][a:b], g["dst"][a:b], g["num_nodes"], rank, world, where, ops=backend)
+            sl = gdist.PartitionedGraph.from_slices(g["src"][a:b], g["dst"][a:b], g["num_nodes"], rank, world, where, ops=backend,
+                                                    node_perm=g.get("node_perm"))
             same = all(torch.equal(getattr(sl, k).cpu(), getattr(part, k).cpu()) for k in ("node_gid", "edge_gid", "srt_geid", "send_idx")) and \
                 all(getattr(sl, k) == getattr(part, k) for k in ("bounds", "n_own", "n_local", "n_score", "send_counts", "recv_counts", "score_pad",
                                                                "num_edges_global")) and \

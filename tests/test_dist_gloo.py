@@ -236,3 +236,29 @@ def test_plan_from_edge_list_slices_equals_plan_from_the_whole_list(kind, world,
     sliced = _run(world, dict(case, sliced=True), tmp_path)
     assert all(o["sliced_equal"] for o in sliced)
     assert all(torch.equal(a["logits"], b["logits"]) for a, b in zip(whole, sliced))
+
+
+def test_partition_over_renumbered_nodes_gives_the_same_logits_and_a_banded_cut(tmp_path):
+    """node_perm (gnnome_amd/node_order.py on the GPU; here: the inverse of the shuffle that made the ids useless): the ranges
+    are cut in the renumbered order, x / logits stay in the caller's numbering.  A banded graph with shuffled read ids is cut
+    like a uniform one; with the permutation that undoes the shuffle it is cut like the banded one, and both routes (whole edge
+    list, slices) give the logits of the unpartitioned oracle."""
+    import numpy as np
+    from gnnome_amd.dist import partition_census
+    n, e = 3000, 30000
+    gr = make_graph(n, e, seed=6, kind="permuted")
+    rp = np.random.default_rng(6 + 7919).permutation(n // 2)             # synth.make_graph's shuffle: read r -> rp[r]
+    inv = np.empty(n // 2, dtype=np.int64)
+    inv[rp] = np.arange(n // 2)
+    perm = torch.from_numpy(np.stack([2 * inv, 2 * inv + 1], 1).reshape(-1))    # node 2 r' + s -> 2 inv[r'] + s
+    assert partition_census(gr["src"], gr["dst"], n, 2)["cut_fraction"] > 0.4
+    assert partition_census(perm[gr["src"].long()], perm[gr["dst"].long()], n, 2)["cut_fraction"] < 0.05
+    sd = random_state_dict(64, num_layers=2, seed=1)
+    x = degree_features(gr["src"], gr["dst"], n)
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], hidden=64, layers=2, state_dict=sd, node_perm=perm, sliced=True)
+    outs = _run(2, case, tmp_path)
+    with torch.no_grad():
+        want = model_from_state_dict(sd).eval()((gr["src"], gr["dst"], n), x, gr["e"]).squeeze(1)
+    for o in outs:
+        assert o["sliced_equal"] and (torch.sigmoid(o["logits"]) - torch.sigmoid(want)).abs().max().item() < 1e-4
+        assert o["n_local"] - o["n_own"] < 0.1 * n and o["e_local"] < 0.55 * e       # banded halo, banded replication

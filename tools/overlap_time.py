@@ -47,8 +47,7 @@ def main():
     for r in range(R - 6):
         for t in range(1, 6):
             o = len(reads[r]) - 2500 * t
-            if o > 500:
-                o = min(o, len(reads[r + t]))
+            if 500 < o <= len(reads[r + t]):   # (a read contained in another one is no overlap edge: assemblers drop contained reads)
                 src.append(2 * r), dst.append(2 * (r + t)), ol.append(o)              # suffix of r against prefix of r + t
                 src.append(2 * (r + t) + 1), dst.append(2 * r + 1), ol.append(o)      # its mate on the other strand
     packed = overlap.pack_reads(reads)
