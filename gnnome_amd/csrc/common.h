@@ -11,7 +11,7 @@ namespace gnnome {
 void set_error(const char* fmt, ...);
 
 // Tuning knobs (gnnome_set_tuning): variant selection for A/B measurements; 0 = the shipped default.
-enum { kTuneGateVariant = 0, kTuneGateAblation = 1, kTuneLinearVariant = 2, kTuneGateTileOrder = 3, kTuneGateExperiment = 4, kTuneAggLdsKiB = 5, kTuneAggHubs = 6, kTuneAggVariant = 7, kTuneRefVariant = 8, kTuneOverlapBand = 9, kTuneCount = 16 };
+enum { kTuneGateVariant = 0, kTuneGateAblation = 1, kTuneLinearVariant = 2, kTuneGateTileOrder = 3, kTuneGateExperiment = 4, kTuneAggLdsKiB = 5, kTuneAggHubs = 6, kTuneAggVariant = 7, kTuneRefVariant = 8, kTuneOverlapBand = 9, kTuneArith = 10, kTuneCount = 16 };
 int tuning(int key);
 
 // Layer 0 only: the e tile is not loaded but COMPUTED by the load waves from the raw edge features,
@@ -68,6 +68,8 @@ int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, flo
 int stream_linear_acc_256(const float* A, int64_t M, const float* W, int ldw, float* C, hipStream_t s);   // edge_gate_stream.hip
 // H = 256 in the wave-specialised plane form (edge_gate_pl256.hip): modes 0 (gate), 1 (raw gate, optional statistics), 2 (C += A W^T)
 int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s);
+// the same tiles in fp16x3 arithmetic with LDS-DMA tile loads (edge_tile_f16.hip; modes 0, 1, 4): the default, gnnome_set_tuning(10, 1) = bf16x6
+int gate_f16_launch(int mode, const GateBfArgs& a, int grid, hipStream_t s);
 int gate_pl256_stats_rows();
 void hub_cache_invalidate();        // node_aggregate.hip: forget the hub list of the previous graph (called when views are built)
 long long* gate_profile_buffer();   // gnnome_debug_gate_profile's buffer (edge_gate_bf.hip), NULL in normal use

@@ -458,6 +458,8 @@ int launch_pl256(const GateBfArgs& args, hipStream_t s) {
     a.num_tiles = (int)tiles;
     a.prof = gate_profile_buffer();
     if (MODE == 1 && a.stats != nullptr) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * (size_t)grid_pl256() * 4 * 2 * 256, s));   // idle waves / the other half
+    if (PROBE == 0 && (MODE == 0 || MODE == 1 || MODE == 4) && tuning(kTuneArith) == 0)   // the shipped default: fp16x3 + LDS-DMA (edge_tile_f16.hip)
+        return gate_f16_launch(MODE, a, grid_pl256(), s);
     hipLaunchKernelGGL((k_edge_gate_pl256<MODE, PROBE>), dim3(grid_pl256()), dim3(512), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;

@@ -134,7 +134,10 @@ def test_linear(m, k, nout):
     A2 = torch.zeros(m, k)
     A2[torch.arange(m), torch.arange(m) % k] = 1.0
     got2 = ops.linear(A2.to(dev()), W.to(dev()), None)
-    assert torch.equal(got2.cpu(), W.t()[torch.arange(m) % k])
+    if k == 256 and m >= 8192 and nout % 128 == 0:   # fp16x3 (edge_tile_f16.hip): 1.0 * (w1 + w2 / 2048) is w to 2^-22, not bit for bit
+        assert torch.allclose(got2.cpu(), W.t()[torch.arange(m) % k], rtol=2.0 ** -21, atol=1e-9)
+    else:
+        assert torch.equal(got2.cpu(), W.t()[torch.arange(m) % k])
     base = torch.randn(m, nout, generator=g)
     acc = ops.linear(A.to(dev()), W.to(dev()), b.to(dev()), out=base.to(dev()).clone(), accumulate=True)
     _assert_close(acc, want + base.double(), scale=float(k) ** 0.5 * 4)
@@ -265,7 +268,11 @@ def test_h256_streaming_gate_in_pieces_equals_one_launch():
     assert torch.equal(pieces, whole) and torch.equal(stream_default, whole)
     # the wave-specialised plane form (W3 in registers, two workgroups per row) feeds the matrix cores the same k in the same order:
     # the same bits as the streaming kernel, at a ragged 300k edges
-    default = ops.edge_gate(*args, out=torch.full_like(d["e"], float("nan")))
+    try:
+        ops.set_tuning(10, 1)    # (the default at H = 256 is round 4's fp16x3 kernel, edge_tile_f16.hip: tests/test_edge_tile_f16.py)
+        default = ops.edge_gate(*args, out=torch.full_like(d["e"], float("nan")))
+    finally:
+        ops.set_tuning(10, 0)
     assert torch.equal(default, whole)
     # ... and as a residual GEMM C += A W^T (the backward's d e_in = d e' + dxe W3 at H = 256)
     A, C0 = d["e"], torch.randn_like(d["e"])
@@ -791,10 +798,15 @@ def test_h256_configs3_properties(n, e):
     assert a.shape == (e, 1) and torch.isfinite(a).all() and torch.equal(a, m(views, x, ef))
     if e == 2_500_000:   # the whole forward on round 2's streaming gate (variant 9): the plane form gives the same bits at full size
         try:
-            ops.set_tuning(0, 9)
-            assert torch.equal(a, m(views, x, ef))
+            ops.set_tuning(10, 1)   # the bf16x6 plane form (round 3) ...
+            a6 = m(views, x, ef)
+            ops.set_tuning(0, 9)    # ... and round 2's streaming gate: the same bits
+            assert torch.equal(a6, m(views, x, ef))
         finally:
             ops.set_tuning(0, 0)
+            ops.set_tuning(10, 0)
+        assert _prob_diff(a, a6) < PROB_TOL / 10    # the fp16x3 default against them: one tenth of the parity bar
+        del a6
     b = _model(_swap_roles(sd, hidden), hidden)(views.reversed(), x, ef)
     assert _prob_diff(a, b) < PROB_TOL
     perm = torch.randperm(e, generator=torch.Generator().manual_seed(3)).to(dev())
