@@ -426,6 +426,34 @@ long long* gate_profile_buffer() { return g_gate_prof; }
 //   * G = B1h[src] + B2h[dst] and the e rows (for the residual) never enter LDS: the lanes that fetched them keep them in
 //     registers until their own epilogue (32 + 32 VGPRs), and the accumulators start from zero.
 // ---------------------------------------------------------------------------------------------------
+// fp16x3 arithmetic (round 4; the derivation and the error model are in edge_tile_f16.hip's header and tests/test_f16x3_model.py): an fp32
+// operand as TWO fp16 planes, x1 = RN16(x) and x2 = RN16((x - x1) * 2048), three products instead of bf16x6's six, the two small ones in
+// a second accumulator that is folded in with 2^-11 once per tile.
+typedef _Float16 h2_pl __attribute__((ext_vector_type(2)));
+typedef _Float16 h8_pl __attribute__((ext_vector_type(8)));
+typedef float f32x2_pl __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4_h(const f32x4 x, uint2& p1, uint2& p2) {
+    h2_pl a[2], b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f32x2_pl v = {x[2 * j], x[2 * j + 1]};
+        a[j] = __builtin_convertvector(v, h2_pl);
+        const f32x2_pl big = v * 2048.f;
+        const f32x2_pl r = {__builtin_fmaf((float)a[j][0], -2048.f, big[0]), __builtin_fmaf((float)a[j][1], -2048.f, big[1])};   // exact
+        b[j] = __builtin_convertvector(r, h2_pl);
+    }
+    p1 = make_uint2(__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]));
+    p2 = make_uint2(__builtin_bit_cast(unsigned, b[0]), __builtin_bit_cast(unsigned, b[1]));
+}
+__device__ __forceinline__ void split8_h(const f32x4 lo, const f32x4 hi, uint4& p1, uint4& p2) {
+    uint2 a1, a2, b1, b2;
+    split4_h(lo, a1, a2);
+    split4_h(hi, b1, b2);
+    p1 = make_uint4(a1.x, a1.y, b1.x, b1.y);
+    p2 = make_uint4(a2.x, a2.y, b2.x, b2.y);
+}
+__device__ __forceinline__ h8_pl as_h8(const uint4 v) { return __builtin_bit_cast(h8_pl, v); }
+
 __device__ __forceinline__ void split4_planes(const f32x4 x, uint2& p1, uint2& p2, uint2& p3) {
     unsigned h[4], m[4], l[4];
 #pragma unroll
@@ -447,10 +475,13 @@ __device__ __forceinline__ void split4_planes(const f32x4 x, uint2& p1, uint2& p
 // ONE 128-column block of W in its compute waves' registers for the whole launch, the a.num_cblocks workgroups of an XCD that share a
 // tile stream read an A row from HBM once (the others find it in that XCD's L2); no gathers, bias instead of the epilogue.  A has row
 // stride a.ldn, C row stride a.ld_out, a.scale = bias (NULL: none).
-template <bool ENC, int MODE = 0, bool X16 = false>
+// F16 (round 4, the default for the forward modes 0, 1 and 4; gnnome_set_tuning(10, 1) = bf16x6): two fp16 planes and three MFMAs per
+// k step instead of three bf16 planes and six - the slot stays 26 KB (the x tile needs 17 KB of it either way).
+template <bool ENC, int MODE = 0, bool X16 = false, bool F16 = false>
 __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
     static_assert(MODE >= 0 && MODE <= 4, "modes of the plane form");   // 2: C += A W^T (the residual GEMM; mode 3 without the BatchNorm step)
     static_assert(!ENC || MODE == 0, "the folded encoder belongs to the inference gate");
+    static_assert(!F16 || MODE == 0 || MODE == 1 || MODE == 4, "fp16x3 is built for the forward modes (gradients need a scale)");
     constexpr int H = 128, TM = 32, RING = 4, KS = H / 16, LDK = H + 4, PLD = 2 * H + 16, PLANE = TM * PLD, SLOTB = 3 * PLANE;
     constexpr int NP = 8, RSTEP = 4, NT = 768;
     static_assert(TM * LDK * 4 <= SLOTB, "the x tile reuses the planes' slot");
@@ -506,11 +537,14 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
     if (wave < 4) {
         // ------------------------------------------------------------------ compute wave: 32 rows x 32 columns
         const int cl = lane & 31, half = lane >> 5, col = 32 * wave + cl;
-        uint4 w1[KS], w2[KS], w3[KS];
+        uint4 w1[KS], w2[KS], w3[F16 ? 1 : KS];
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
             const float* wp = a.W3 + (int64_t)(H * cbk + col) * a.ldw + 16 * q + 8 * half;
-            split3(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4), w1[q], w2[q], w3[q]);
+            if (F16)
+                split8_h(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4), w1[q], w2[q]);
+            else
+                split3(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4), w1[q], w2[q], w3[q]);
         }
         auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
         const int lane_x = 4 * half * LDK + col;   // accumulator element r sits in tile row 4 half + crow(r)
@@ -524,26 +558,37 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
             flag_wait_bf(full0 + 4 * slot, 2u * use, 0);
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_wait += t1 - t0; t0 = t1; }
             const unsigned char* ap = ring + slot * SLOTB + cl * PLD + 16 * half;   // + 32 q, + PLANE * plane
-            f32x16 acc;
+            f32x16 acc, accC;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            uint4 c1 = *reinterpret_cast<const uint4*>(ap), c2 = *reinterpret_cast<const uint4*>(ap + PLANE),
-                  c3 = *reinterpret_cast<const uint4*>(ap + 2 * PLANE);
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f, accC[r] = 0.f;
+            uint4 c1 = *reinterpret_cast<const uint4*>(ap), c2 = *reinterpret_cast<const uint4*>(ap + PLANE), c3 = c1;
+            if (!F16) c3 = *reinterpret_cast<const uint4*>(ap + 2 * PLANE);
 #pragma unroll
             for (int q = 0; q < KS; ++q) {
                 const int qn = q + 1 < KS ? q + 1 : q;
-                const uint4 n1 = *reinterpret_cast<const uint4*>(ap + 32 * qn), n2 = *reinterpret_cast<const uint4*>(ap + 32 * qn + PLANE),
-                            n3 = *reinterpret_cast<const uint4*>(ap + 32 * qn + 2 * PLANE);
-                // smallest terms first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c3), as_bf(w1[q]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w3[q]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c2), as_bf(w2[q]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c2), as_bf(w1[q]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w2[q]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w1[q]), acc, 0, 0, 0);
+                const uint4 n1 = *reinterpret_cast<const uint4*>(ap + 32 * qn), n2 = *reinterpret_cast<const uint4*>(ap + 32 * qn + PLANE);
+                uint4 n3 = n1;
+                if (!F16) n3 = *reinterpret_cast<const uint4*>(ap + 32 * qn + 2 * PLANE);
+                if (F16) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c1), as_h8(w1[q]), acc, 0, 0, 0);
+                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c1), as_h8(w2[q]), accC, 0, 0, 0);
+                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c2), as_h8(w1[q]), accC, 0, 0, 0);
+                } else {
+                    // smallest terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c3), as_bf(w1[q]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w3[F16 ? 0 : q]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c2), as_bf(w2[q]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c2), as_bf(w1[q]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w2[q]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w1[q]), acc, 0, 0, 0);
+                }
                 c1 = n1;
                 c2 = n2;
                 c3 = n3;
+            }
+            if (F16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += accC[r] * (1.0f / 2048.f);
             }
             if (a.prof) { asm volatile("" ::"v"(acc[0])); t1 = __builtin_readcyclecounter(); t_loop += t1 - t0; t0 = t1; }
             // every compute wave has read the planes -> the slot becomes the x tile
@@ -667,11 +712,15 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 uint2 p1, p2, p3;
-                split4_planes(av[p], p1, p2, p3);
                 unsigned char* d = S + (r0 + p * RSTEP) * PLD + 8 * c4;
+                if (F16) {
+                    split4_h(av[p], p1, p2);
+                } else {
+                    split4_planes(av[p], p1, p2, p3);
+                    *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
+                }
                 *reinterpret_cast<uint2*>(d) = p1;
                 *reinterpret_cast<uint2*>(d + PLANE) = p2;
-                *reinterpret_cast<uint2*>(d + 2 * PLANE) = p3;
                 if (MODE == 0) ek[p] = av[p];
                 if (MODE != 4) gk[p] = MODE >= 2 ? g1[p] : g1[p] + g2[p];
                 // G is summed HERE, not where it is used: sunk into the epilogue, the sum would drag the wait for the gathers
@@ -703,7 +752,11 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                     f32x4 y;
                     if (MODE == 0) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + gk[p][j]) * sc4[j] + sh4[j], 0.f) + ek[p][j];
+                        for (int j = 0; j < 4; ++j) {
+                            const float t = (x[u][j] + gk[p][j]) * sc4[j] + sh4[j];
+                            // F16: an operand beyond fp16's range reaches here as inf / NaN and must not leave the relu as 0 (t - t is 0 iff t is finite)
+                            y[j] = (!F16 || t - t == 0.f) ? fmaxf(t, 0.f) + ek[p][j] : __builtin_nanf("");
+                        }
                         if (row < valid) *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
                     } else if (MODE == 4) {
                         y = x[u] + sc4;   // + bias
@@ -754,8 +807,18 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
     }
 }
 
+template <bool ENC, int MODE = 0, bool X16 = false, bool F16 = false>
+static int launch_pl_arith(const GateBfArgs& args, hipStream_t s);
 template <bool ENC, int MODE = 0, bool X16 = false>
 static int launch_pl(const GateBfArgs& args, hipStream_t s) {
+    // forward modes: fp16x3 unless gnnome_set_tuning(10, 1) asks for bf16x6 (the folded-encoder form keeps bf16x6; mode 1 with bf16 storage follows
+    // the fp32-storage kernel, so that what it stores is that kernel's result rounded)
+    constexpr bool kForward = !ENC && (MODE == 1 || (!X16 && (MODE == 0 || MODE == 4)));
+    if (kForward && tuning(kTuneArith) == 0) return launch_pl_arith<ENC, kForward ? MODE : 0, kForward ? X16 : false, kForward>(args, s);
+    return launch_pl_arith<ENC, MODE, X16, false>(args, s);
+}
+template <bool ENC, int MODE, bool X16, bool F16>
+static int launch_pl_arith(const GateBfArgs& args, hipStream_t s) {
     GateBfArgs a = args;
     const int64_t tiles = (a.E + 31) / 32;
     GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
@@ -765,7 +828,7 @@ static int launch_pl(const GateBfArgs& args, hipStream_t s) {
     if (MODE == 1) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * kNumCUs * 8 * 2 * 128, s));   // idle waves leave zeros
     GN_REQUIRE(MODE != 4 || (a.num_cblocks >= 1 && a.num_cblocks <= persistent_grid() / kXcds && a.ldn >= 128 && a.ldn % 4 == 0 && a.ld_out % 4 == 0),
                "linear (K = 128): %d column blocks / strides %d, %d", a.num_cblocks, a.ldn, a.ld_out);
-    hipLaunchKernelGGL((k_edge_gate_pl<ENC, MODE, X16>), dim3(persistent_grid()), dim3(768), 0, s, a);
+    hipLaunchKernelGGL((k_edge_gate_pl<ENC, MODE, X16, F16>), dim3(persistent_grid()), dim3(768), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
