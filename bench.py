@@ -766,6 +766,9 @@ def main():
                         f"{chunks_timed} node ranges (engine.aggregate_then_project)") if chunks_timed > 1 else "1",
         }
         res.update(extras)
+        res["arithmetic"] = ("fp32 in / fp32 out; dense products as an exact-split fp32 emulation on the 16-bit matrix cores with fp32 accumulation: fp16x3 "
+                             "(two fp16 planes per operand, three MFMAs; measured no further from an fp64 product than an fp32 GEMM - tests/test_f16x3_model.py) "
+                             "for the forward at H >= 128, bf16x6 elsewhere; --tuning 10=1 = bf16x6 everywhere (round 3)")
         if args.node_order != "input":
             res["config"]["node_order"] = args.node_order
         if args.tuning:
@@ -776,17 +779,33 @@ def main():
             gate_ms, gate_n = kt.mean_ms(timed[0])
             gate_flops = 2.0 * e_gate * hidden * hidden
             gate_bytes = 2.0 * e_gate * hidden * 4 + 2 * e_gate * 4   # read e, write e', read src/dst (B_layer's edge part)
+            # round 4: the forward's dense products run as fp16x3 (two fp16 planes per fp32 operand, three f16 MFMAs per K = 16 step - csrc/edge_tile_f16.hip)
+            # unless --tuning 10=1 asks for round 3's bf16x6 (six); H = 64 still runs bf16x6
+            terms = 6.0 if (hidden == 64 or "10=1" in (args.tuning or "").replace(" ", "")) else 3.0
+            arith = "bf16x6" if terms == 6.0 else "fp16x3"
             if hidden in (64, 128):
-                # bf16x6 edge-tile kernel: the exact-fp32 product costs 6 bf16 MFMAs per K=16 (197 GF per launch at
-                # configs[1] = 0.08 ms at the 2.5 PF bf16 peak) against 1.03 GB = 0.13 ms at 8 TB/s: HBM is the bound
+                # the product costs `terms` 16-bit MFMAs per K=16 (98 GF per launch at configs[1] as fp16x3 = 0.04 ms at the 2.5 PF peak)
+                # against 1.03 GB = 0.13 ms at 8 TB/s: HBM is the bound
                 res["roofline"] = {
-                    "kernel": ("k_edge_gate_pl" if hidden == 128 else "k_edge_gate_bf") + " (fused B_3 GEMM as bf16x6 + u_add_v + bn_e + relu + residual)",
+                    "kernel": ("k_edge_gate_pl" if hidden == 128 else "k_edge_gate_bf") + f" (fused B_3 GEMM as {arith} + u_add_v + bn_e + relu + residual)",
                     "bound": "hbm", "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK,
                     "traffic": _pmc_traffic(args, hidden, e) if world == 1 else None,
                     "avg_launch_ms": gate_ms, "launches": gate_n, "algorithmic_bytes_per_launch": gate_bytes,
                     "fp32_equivalent_flops_per_launch": gate_flops, "fp32_equivalent_tflops": gate_flops / (gate_ms * 1e-3) / 1e12,
-                    "bf16_mfma_frac": 6.0 * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK,
+                    "mfma_16bit_frac": terms * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK, "arithmetic": arith,
+                }
+            elif terms == 3.0:
+                # H = 256, fp16x3 + LDS-DMA (k_edge_tile_f16): 3 f16 MFMAs per K=16 = 0.39 ms per launch at the 2.5 PF peak against 0.64 ms of HBM
+                # time for this shard (8 TB/s): HBM is the bound now
+                res["roofline"] = {
+                    "kernel": "k_edge_tile_f16 (H=256: fp16x3, e tiles by LDS-DMA, planes in place, W3 in registers, two workgroups per row)",
+                    "bound": "hbm", "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                    "avg_launch_ms": gate_ms, "launches": gate_n, "algorithmic_bytes_per_launch": gate_bytes,
+                    "fp32_equivalent_tflops": gate_flops / (gate_ms * 1e-3) / 1e12,
+                    "mfma_16bit_frac": terms * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK, "arithmetic": arith,
+                    "bf16x6_equivalent_mfma_frac": 6.0 * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK,
                 }
             else:
                 # H = 256: the wave-specialised plane form (bf16x6, W3 in registers, two workgroups per row); 6 bf16 MFMAs per K=16
@@ -797,7 +816,7 @@ def main():
                     "frac": 6.0 * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK, "traffic": None,
                     "avg_launch_ms": gate_ms, "launches": gate_n, "bf16_flops_per_launch": 6.0 * gate_flops,
                     "fp32_equivalent_tflops": gate_flops / (gate_ms * 1e-3) / 1e12,
-                    "algorithmic_bytes_per_launch": gate_bytes, "hbm_frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK,
+                    "algorithmic_bytes_per_launch": gate_bytes, "hbm_frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK, "arithmetic": arith,
                 }
             if world > 1:
                 res["roofline"]["note"] = f"rank 0's launches: {e_gate} local edges (its node range's in- and out-edges)"
