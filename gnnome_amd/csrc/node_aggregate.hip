@@ -26,7 +26,9 @@
 // single-wave sum.  Up to kHubCap hubs per call take this path; any further ones fall back to the single wave.
 #include "common.h"
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 namespace gnnome {
 
@@ -51,41 +53,47 @@ struct HubScratch {
     int known = -1;             // -1: not known yet
 };
 
-// Per-device scratch of the hub path, allocated on first use (never inside a stream capture: the first call of any
-// process is an eager one - CapturedForward and the benchmarks warm up before they record).  One buffer per device:
-// launches of this library on one device are stream-ordered.
-// CONTRACT: the scratch is shared by every stream of a device, so two aggregations of graphs WITH hubs must not
-// be in flight on two streams of one device at once (this package launches all its work on torch's current stream; the
-// optional second stream of engine.aggregate_then_project runs projections only).  The host-side table is guarded by a
-// mutex, and the first use never allocates inside a stream capture: it reports an error instead (warm up eagerly first).
-static HubScratch g_hub_table[64];
+// Scratch of the hub path, one per (device, stream), allocated on first use (never inside a stream capture: the first call of any
+// process is an eager one - CapturedForward and the benchmarks warm up before they record).  Round 4 (VERDICT r3 12.i / ADVICE r3): the
+// scratch used to be one buffer per DEVICE behind a "do not run two aggregations of graphs with hubs on two streams at once" contract;
+// it is now keyed by the stream as well, so launches on different streams never share it, and every read or write of the host-side
+// state (key, known, pending) happens under the mutex, which launch_agg holds for its whole hub section.
+static std::map<std::pair<int, hipStream_t>, HubScratch> g_hub_table;
 static std::mutex g_hub_guard;
 
 // gnnome_build_graph_views calls this: new CSR arrays may land at the addresses of freed ones (torch's caching allocator does
 // that routinely), and the list - and the "this graph has no hubs" fact - of the previous graph must not outlive it.
 void hub_cache_invalidate() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    if (hipGetDevice(&dev) != hipSuccess) return;
     std::lock_guard<std::mutex> lock(g_hub_guard);
-    g_hub_table[dev].key_in = g_hub_table[dev].key_out = nullptr;
-    g_hub_table[dev].key_n = -1;
-    g_hub_table[dev].known = -1;
-    g_hub_table[dev].pending = false;
+    for (auto& kv : g_hub_table) {
+        if (kv.first.first != dev) continue;
+        kv.second.key_in = kv.second.key_out = nullptr;
+        kv.second.key_n = -1;
+        kv.second.known = -1;
+        kv.second.pending = false;
+    }
 }
 
+// (called with g_hub_guard held)
 static HubScratch* hub_scratch(hipStream_t s, bool* capturing_unallocated) {
-    HubScratch* table = g_hub_table;
-    std::mutex& guard = g_hub_guard;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(guard);
-    HubScratch& h = table[dev];
-    if (h.partials == nullptr) {
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    auto it = g_hub_table.find(std::make_pair(dev, s));
+    if (it == g_hub_table.end() || it->second.partials == nullptr) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            // a capture runs on a stream of its own and must not allocate: it records against the scratch the eager warm-up on this device
+            // left (the recording then shares it with that stream - replays of graphs WITH hubs must not overlap eager aggregations there)
+            for (auto& kv : g_hub_table)
+                if (kv.first.first == dev && kv.second.partials != nullptr) return &kv.second;
             *capturing_unallocated = true;
             return nullptr;
         }
+    }
+    HubScratch& h = g_hub_table[std::make_pair(dev, s)];
+    if (h.partials == nullptr) {
         if (h.count == nullptr && hipMalloc(&h.count, sizeof(int)) != hipSuccess) return nullptr;
         if (h.nodes == nullptr && hipMalloc(&h.nodes, sizeof(int) * kHubCap) != hipSuccess) return nullptr;
         if (hipMalloc(&h.partials, sizeof(float) * (size_t)kHubCap * kHubChunks * 4 * kHubMaxH) != hipSuccess) return nullptr;
@@ -442,10 +450,15 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
                (long long)node_begin, (long long)node_end, (long long)n_out);
     // the hub path (see the header comment): find the long lists, reduce them chunk-wise, let the node's wave add the chunks
     bool capturing_unallocated = false;
+    std::lock_guard<std::mutex> hub_lock(g_hub_guard);   // the scratch's host-side state is read and written below, up to the launches
     HubScratch* hub = tuning(kTuneAggHubs) == 1 ? nullptr : hub_scratch(s, &capturing_unallocated);
     GN_REQUIRE(!capturing_unallocated, "node_aggregate: first call on this device inside a stream capture - run one eager call first "
                                        "(the hub scratch is allocated on first use)");
-    if (hub != nullptr && hub->key_in == in_ptr && hub->key_out == out_ptr && hub->key_n == n_out) {
+    // the hub list is a function of in-degree + out-degree: the same for a graph and its reversed views (in_ptr / out_ptr swapped)
+    auto same_graph = [&](const HubScratch* h) {
+        return h->key_n == n_out && ((h->key_in == in_ptr && h->key_out == out_ptr) || (h->key_in == out_ptr && h->key_out == in_ptr));
+    };
+    if (hub != nullptr && same_graph(hub)) {
         hipStreamCaptureStatus capq = hipStreamCaptureStatusNone;
         const bool capturing = hub->pending && (hipStreamIsCapturing(s, &capq) != hipSuccess || capq != hipStreamCaptureStatusNone);
         if (hub->pending && !capturing && hipEventQuery(hub->ready) == hipSuccess) {   // (an event query is not allowed inside a stream capture)
@@ -459,13 +472,12 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
     const int* hub_nodes = hub ? hub->nodes : nullptr;
     const float* hub_partials = hub ? hub->partials : nullptr;
     if (hub && !hub_pass)   // a later range of the same call sequence: the hub list must be the one its first range built
-        GN_REQUIRE(hub->key_in == in_ptr && hub->key_out == out_ptr && hub->key_n == n_out,
-                   "node_aggregate_range: the ranges of one aggregation must start with the range that begins at node 0");
+        GN_REQUIRE(same_graph(hub), "node_aggregate_range: the ranges of one aggregation must start with the range that begins at node 0");
     if (hub_pass) {
         // The list is rebuilt when the CSR arrays change (8 layers share one graph).  A stale list - another graph at the
         // same addresses - costs speed only: the kernels re-read every count, a listed node that is no hub takes the normal
         // path, an unlisted hub the single-wave path, and the partials are recomputed at every call.
-        if (hub->key_in != in_ptr || hub->key_out != out_ptr || hub->key_n != n_out) {
+        if (!same_graph(hub)) {
             GN_HIP(hipMemsetAsync(hub->count, 0, sizeof(int), s));
             hipLaunchKernelGGL(k_find_hubs, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, in_ptr, out_ptr, n_out, hub->count, hub->nodes);
             hub->key_in = in_ptr, hub->key_out = out_ptr, hub->key_n = n_out;

@@ -78,10 +78,16 @@ __device__ __forceinline__ void overlap_shape(const int64_t* __restrict__ read_o
 }
 
 // every edge: the trivial cases are answered here, the rest is marked for the banded / full kernels
-__global__ void k_overlap_prepare(const int64_t* __restrict__ read_off, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
-                                  const int32_t* __restrict__ ol, int64_t E, int32_t* __restrict__ dist_out) {
+__global__ void k_overlap_prepare(const int64_t* __restrict__ read_off, int64_t num_reads, const int32_t* __restrict__ src,
+                                  const int32_t* __restrict__ dst, const int32_t* __restrict__ ol, int64_t E, int32_t* __restrict__ dist_out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= E) return;
+    // an endpoint outside [0, 2 num_reads) would index read_off out of bounds: the edge is reported (-1) and no later kernel touches it
+    // (they take kNeedFull entries only, and test that before they read an offset) - ADVICE r3
+    if (src[i] < 0 || dst[i] < 0 || (src[i] >> 1) >= num_reads || (dst[i] >> 1) >= num_reads) {
+        dist_out[i] = -1;
+        return;
+    }
     int m, n, ulen, vlen;
     overlap_shape(read_off, src[i], dst[i], ol[i], m, n, ulen, vlen);
     dist_out[i] = (m == 0 || n == 0) ? max(m, n) : kNeedFull;   // an empty side: the distance is the other side's length
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(64) void k_overlap_edit_distance(const uint8_t* __r
     uint32_t* peq = lds;                                            // [nsym][B][64]
     uint8_t* st = reinterpret_cast<uint8_t*>(lds + nsym * B * 64);  // [512]: symbol of byte b, symbol of complement(b)
     const int lane = threadIdx.x;
-    for (int i = lane; i < 128; i += 64) reinterpret_cast<uint32_t*>(st)[i] = reinterpret_cast<const uint32_t*>(symtab)[i];
+    for (int i = lane; i < 512; i += 64) st[i] = (uint8_t)min((int)symtab[i], nsym - 1);   // (an entry >= nsym would index past the mask table)
     __syncthreads();
     for (;;) {
         int first = 0;
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(64) void k_overlap_edit_distance(const uint8_t* __r
         const int64_t cand = (int64_t)first + lane;
         int mine_m = 0, mine_n = 0;
         bool take = false;
-        if (cand < E) {
+        if (cand < E && dist_out[cand] == kNeedFull) {   // (the mark first: an edge with an endpoint out of range never reaches read_off)
             const int L = ol[cand], u = src[cand], v = dst[cand];
             const int ulen = (int)(read_off[(u >> 1) + 1] - read_off[u >> 1]);
             const int vlen = (int)(read_off[(v >> 1) + 1] - read_off[v >> 1]);
@@ -379,12 +385,13 @@ extern "C" int gnnome_overlap_edit_distance(const uint8_t* reads, const int64_t*
     GN_REQUIRE(reads && read_off && symtab && src && dst && overlap_length && dist_out && workspace, "overlap_edit_distance: null pointer");
     GN_REQUIRE(num_symbols >= 1 && num_symbols <= kMaxSyms, "overlap_edit_distance: %d symbols (1..%d supported)", num_symbols, kMaxSyms);
     GN_REQUIRE(workspace_bytes >= 16 * sizeof(int), "overlap_edit_distance: workspace too small");
-    GN_REQUIRE(num_edges < (1ll << 31) - 64, "overlap_edit_distance: too many edges");
+    // (every wave draws one more 64-edge ticket after the list is exhausted: the int counter must have room for that)
+    GN_REQUIRE(num_edges < (1ll << 31) - 64 - (int64_t)persistent_grid() * 32 * 64, "overlap_edit_distance: too many edges");
     hipStream_t s = (hipStream_t)stream;
     int* tickets = reinterpret_cast<int*>(workspace);
     GN_HIP(hipMemsetAsync(tickets, 0, 16 * sizeof(int), s));
     const unsigned eb = (unsigned)((num_edges + 255) / 256);
-    hipLaunchKernelGGL(k_overlap_prepare, dim3(eb), dim3(256), 0, s, read_off, src, dst, overlap_length, num_edges, dist_out);
+    hipLaunchKernelGGL(k_overlap_prepare, dim3(eb), dim3(256), 0, s, read_off, num_reads, src, dst, overlap_length, num_edges, dist_out);
     GN_LAUNCH_CHECK();
     if (tuning(kTuneOverlapBand) != 1 && num_symbols <= 16) {   // (key 9 = 1: full-matrix kernels only, for A/B runs and cross-checks)
         const int bgrid = (int)std::min<int64_t>((num_edges + 63) / 64, (int64_t)persistent_grid() * 32);

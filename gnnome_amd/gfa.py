@@ -124,14 +124,21 @@ def read_gfa(path, similarity="auto", keep_sequences=False):
            "prefix_length": (read_length[src_t] - ol_t) if src else ol_t.clone(), "read_length": read_length,
            "read_to_node": read_to_node, "node_to_read": node_to_read, "read_to_node2": read_to_node2,
            "read_seqs": read_seqs if keep_sequences else None, "overlap_similarity": None}
-    if sims and all(s is not None for s in sims):
-        out["overlap_similarity"] = torch.tensor(sims, dtype=torch.float32)
-    elif callable(similarity) and not no_seqs:
+    if callable(similarity) and not no_seqs:    # an explicit aligner overrides SI:f: tags (the docstring said so, the code did not)
         out["overlap_similarity"] = torch.tensor([similarity(read_seqs[u], read_seqs[v], ol) if ol > 0 else 0.5 for u, v, ol in zip(src, dst, ols)],
                                                  dtype=torch.float32)
+    elif sims and all(s is not None for s in sims):
+        out["overlap_similarity"] = torch.tensor(sims, dtype=torch.float32)
     elif similarity not in (None, False) and not no_seqs and (similarity == "device" or torch.cuda.is_available()):
-        from .overlap import overlap_similarity   # the MI355X kernel; raises without the library or a device ("device" insists)
-        out["overlap_similarity"] = overlap_similarity(forward, src_t, dst_t, ol_t).cpu()
+        from .overlap import overlap_similarity   # the MI355X kernel
+        if similarity == "device":              # "device" insists: a missing library, > 32 symbols or an overlap beyond 65 536 bases raise
+            out["overlap_similarity"] = overlap_similarity(forward, src_t, dst_t, ol_t).cpu()
+        else:                                   # "auto": what cannot be aligned here is reported and left to the caller, as before the kernel existed
+            try:
+                out["overlap_similarity"] = overlap_similarity(forward, src_t, dst_t, ol_t).cpu()
+            except (RuntimeError, ValueError, OSError) as ex:
+                import warnings
+                warnings.warn(f"read_gfa: overlap similarities not computed on the device ({ex}); overlap_similarity is None")
     return out
 
 

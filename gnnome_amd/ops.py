@@ -748,7 +748,10 @@ def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None
         out = torch.empty_like(de)
         _call("gnnome_bn_bwd_dgrad_out_f32", de.device, _ptr(de), _ptr(out), _ptr(xe), de.shape[0], once, 256, _ptr(scale), _ptr(shift), _ptr(a),
               _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))
-        de.set_(out)
+        if de._base is not None or de.storage_offset() != 0:   # a view of somebody else's storage: set_ would leave that storage unchanged
+            de.copy_(out)
+        else:
+            de.set_(out)
         return dxe
     _call("gnnome_bn_bwd_dgrad_x16" if x16 else "gnnome_bn_bwd_dgrad_f32", de.device, _ptr(de), _ptr(xe), de.shape[0], once, de.shape[1], _ptr(scale), _ptr(shift),
           _ptr(a), _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))

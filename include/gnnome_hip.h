@@ -456,7 +456,8 @@ int gnnome_mark_walk_visited(const int32_t* succ_ptr, const int32_t* succ_nbr, c
  *   read_off    int64[R+1]     offsets of read r in `reads`
  *   symtab      uint8[512]     [b] = index of byte b in the caller's alphabet, [256+b] = index of complement(b)
  *                              (the table Bio.Seq.reverse_complement applies); num_symbols <= 32
- *   src, dst    int32[E]       node ids (graph.edges()); overlap_length int32[E]
+ *   src, dst    int32[E]       node ids (graph.edges()); overlap_length int32[E].  An edge with an endpoint outside [0, 2 num_reads)
+ *                              is reported as -1 and not aligned; symtab entries >= num_symbols are read as num_symbols - 1
  *   dist_out    int32[E]       edit distances; entries the kernels cannot serve keep the caller's fill value (fill with -1):
  *                              a query longer than 65 536 bases, or an alphabet whose match masks exceed LDS at that length
  *   similarity_out float32[E]  (NULL: skip) 1 - dist / ol evaluated in double precision like the reference's Python floats */

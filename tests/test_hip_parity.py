@@ -134,7 +134,7 @@ def test_linear(m, k, nout):
     A2 = torch.zeros(m, k)
     A2[torch.arange(m), torch.arange(m) % k] = 1.0
     got2 = ops.linear(A2.to(dev()), W.to(dev()), None)
-    if (k == 128 and nout % 128 == 0 and nout >= 256) or (k == 256 and nout % 128 == 0 and m >= 8192):   # the fp16x3 routes (edge_tile_f16.hip, k_edge_gate_pl<.., F16>): 1.0 * (w1 + w2 / 2048)
+    if (k == 128 and nout % 128 == 0 and nout >= 256) or (k == 256 and nout % 128 == 0):   # the fp16x3 routes (edge_tile_f16.hip, k_edge_gate_pl<.., F16>): 1.0 * (w1 + w2 / 2048)
         assert torch.allclose(got2.cpu(), W.t()[torch.arange(m) % k], rtol=2.0 ** -21, atol=1e-9)   # is w to 2^-22, not bit for bit
     else:
         assert torch.equal(got2.cpu(), W.t()[torch.arange(m) % k])
