@@ -117,11 +117,14 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char ring[NS * SLOTB];
     __shared__ __attribute__((aligned(16))) float xt[XT];
     __shared__ __attribute__((aligned(16))) float norm_lds[2 * HC];
-    __shared__ unsigned flags[NS + 2];   // full[NS], done, drained
+    __shared__ unsigned flags[2 * NS + 2];   // full[NS], done, drained, landed[NS] (EPI_CONV)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned full0 = lds_addr(&flags[0]), done0 = lds_addr(&flags[NS]), drained0 = lds_addr(&flags[NS + 1]);
+    const unsigned full0 = lds_addr(&flags[0]), done0 = lds_addr(&flags[NS]), drained0 = lds_addr(&flags[NS + 1]), landed0 = lds_addr(&flags[NS + 2]);
+    // MODE 4 (no gathers, no residual: the epilogue waves only add a bias and store): THEY turn the landed rows into planes, the compute waves
+    // keep DMA + MFMA.  (In the gate the same split made the epilogue waves the long pole: 1.68 against 1.34 ms per launch.)
+    constexpr bool EPI_CONV = MODE == 4;
     // the work distribution of k_edge_gate_pl256: pairs of workgroups on one XCD (blocks b and b + 8 share b % 8) take the two column
     // halves of the same tiles; mode 4: the a.num_cblocks workgroups of an XCD that share idx / num_cblocks walk the same tiles
     const int per_xcd = gridDim.x / kXcds, xcd = blockIdx.x % kXcds, idx = blockIdx.x / kXcds;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
     };
     auto tile_valid = [&](int r) { return (int)min((int64_t)TM, a.E - (int64_t)tile_of(r) * TM); };
     const int colh = HC * hh;
-    if (tid < NS + 2) flags[tid] = 0;
+    if (tid < 2 * NS + 2) flags[tid] = 0;
     if (MODE == 4) {
         for (int i = tid; i < HC; i += 512) norm_lds[i] = a.scale ? a.scale[colh + i] : 0.f;
     } else {
@@ -194,14 +197,16 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
             for (int p = 0; p < 8; ++p) dma_piece();
         }
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        {
+        if (EPI_CONV) {
+            flag_bump(landed0, lane);   // my rows of tile 0 are in the slot
+        } else {
             f32x4 t[8];
 #pragma unroll
             for (int p = 0; p < 8; ++p) t[p] = row_read(0, p);
 #pragma unroll
             for (int p = 0; p < 8; ++p) row_write(0, p, t[p]);
+            flag_bump(full0, lane);
         }
-        flag_bump(full0, lane);
         auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
         float* X = xt + 4 * half * LDK + 32 * wave + cl;   // accumulator element r sits in tile row 4 half + crow(r)
         long long t_wait = 0, t_loop = 0, t_x = 0, t0 = 0, t1 = 0;
@@ -212,7 +217,9 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
             const int slot = j % NS;
             if (a.prof) t0 = __builtin_readcyclecounter();
             if (!(PROBE & 1)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's rows of tile j + 1 have landed (tile j + 2's may be in flight)
-            flag_wait(full0 + 4 * slot, 4u * ((unsigned)(j / NS) + 1u));   // tile j's planes are complete; every compute wave is through with tile j - 1
+            if (EPI_CONV) flag_bump(landed0 + 4 * ((j + 1) % NS), lane);
+            flag_wait(full0 + 4 * slot, 4u * ((unsigned)(j / NS) + 1u));   // tile j's planes are complete; (!EPI_CONV:) every compute wave is through with tile j - 1
+            if (EPI_CONV) flag_wait(done0, 4u * (unsigned)j);              // every compute wave is through with tile j - 1: its slot may be refilled
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_wait += t1 - t0; t0 = t1; }
             const unsigned char* ap = ring + slot * SLOTB + cl * RSB + 16 * half;   // + 32 q: the lane's eight halves of step q; + 2 H: the second plane
             dma_begin(j + 3);   // tile j + 3 goes into the slot tile j - 1 has left
@@ -227,9 +234,9 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
                 const uint4 n1 = *reinterpret_cast<const uint4*>(ap + 32 * qn), n2 = *reinterpret_cast<const uint4*>(ap + 32 * qn + 2 * H);
                 if ((q & 1) == 0) {
                     if (!(PROBE & 1)) dma_piece();
-                    if (!(PROBE & 2)) raw = row_read(j + 1, q >> 1);        // tile j + 1, this wave's row q / 2 ...
+                    if (!(PROBE & 2) && !EPI_CONV) raw = row_read(j + 1, q >> 1);        // tile j + 1, this wave's row q / 2 ...
                 } else {
-                    if (!(PROBE & 2)) row_write(j + 1, q >> 1, raw);        // ... becomes planes a step later
+                    if (!(PROBE & 2) && !EPI_CONV) row_write(j + 1, q >> 1, raw);        // ... becomes planes a step later
                 }
                 if (PROBE & 4) {
                     accM[q] += __uint_as_float(c1.x ^ c2.y ^ __builtin_bit_cast(uint4, w1[q]).x ^ __builtin_bit_cast(uint4, w2[q]).y);
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
                 c1 = n1;
                 c2 = n2;
             }
-            flag_bump(full0 + 4 * ((j + 1) % NS), lane);   // my rows of tile j + 1 are planes, my reads of tile j are issued
+            if (!EPI_CONV) flag_bump(full0 + 4 * ((j + 1) % NS), lane);   // my rows of tile j + 1 are planes, my reads of tile j are issued
             if (a.prof) { asm volatile("" ::"v"(accM[0])); t1 = __builtin_readcyclecounter(); t_loop += t1 - t0; t0 = t1; }
             flag_wait(drained0, 4u * (unsigned)j);   // x(j - 1) has been read by all four epilogue waves
 #pragma unroll
@@ -287,6 +294,22 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
                 if (MODE == 0) ek[S][p] = *reinterpret_cast<const f32x4*>(a.e_in + (row0 + min(rl + p, valid - 1)) * H + colh + 4 * c4);
             }
         };
+        // EPI_CONV: rows 8 ew .. 8 ew + 7 of tile ordinal r become planes in place (all 64 lanes read a row before any of them writes it)
+        auto to_planes = [&](int r) {
+            flag_wait(landed0 + 4 * (r % NS), 4u * ((unsigned)(r / NS) + 1u));
+            unsigned char* rows = ring + (r % NS) * SLOTB + 8 * ew * RSB;
+            f32x4 t[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) t[p] = *reinterpret_cast<const f32x4*>(rows + p * RSB + 16 * lane);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                uint2 p1, p2;
+                split4h(t[p], p1, p2);
+                *reinterpret_cast<uint2*>(rows + p * RSB + 8 * lane) = p1;
+                *reinterpret_cast<uint2*>(rows + p * RSB + 8 * lane + 2 * H) = p2;
+            }
+            flag_bump(full0 + 4 * (r % NS), lane);
+        };
         f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1;   // MODE 1: this lane's running shifted sums of its four columns
         long long t_done = 0, t_epi = 0, t_issue = 0, t0 = 0, t1 = 0;
         const f32x4 sc4 = *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4);   // MODE 0: scale; 1: centres; 4: bias
@@ -295,6 +318,7 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
         auto tile = [&](auto set, int i) {
             constexpr int S = decltype(set)::value, S2 = (S + 2) % 3;
             if (a.prof) t0 = __builtin_readcyclecounter();
+            if (EPI_CONV && i + 1 < n) to_planes(i + 1);   // (while the compute waves are busy with tile i)
             flag_wait(done0, 4u * ((unsigned)i + 1u));
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_done += t1 - t0; t0 = t1; }
             f32x4 x[NP];
@@ -347,6 +371,7 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
             fetch_side(std::integral_constant<int, S2>{}, i + 2);
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_issue += t1 - t0; }
         };
+        if (EPI_CONV) to_planes(0);
         fetch_index(std::integral_constant<int, 0>{}, 0);
         fetch_index(std::integral_constant<int, 1>{}, 1);
         fetch_side(std::integral_constant<int, 0>{}, 0);

@@ -26,6 +26,7 @@
 // single-wave sum.  Up to kHubCap hubs per call take this path; any further ones fall back to the single wave.
 #include "common.h"
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -434,6 +435,136 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
     }
 }
 
+// Round 4 experiment (tuning key 7 = 9, H = 128, the fused inference update): TWO NODES PER WAVE.  The kernel above gives a wave one node and
+// lets its two 32-lane groups take alternate items of that node's list: a list of 10 + 10 items costs four rounds of 8 row slots (62 % of
+// them live) and a cross-group reduction.  Here each 32-lane group owns a node of its own (consecutive nodes: mates 2r / 2r + 1 on an
+// assembly graph, with lists of equal length): three rounds of 4 slots per direction and node (83 % live), half as many waves, no
+// cross-lane sums - every node's items are added in list order by one lane group, so the result is a function of the graph alone here
+// too (another association than the kernel above: equal to fp32 rounding, not bit for bit).
+// MEASURED (tools/agg_time.py 128 variants, tools/forward_ab.py 0,9,11,12,13 7; configs[1]): 0.2011 against 0.2051 ms per launch, forward 4.405 against
+// 4.419 ms - level: the kernel's time does not depend on how its waves are cut (as with U and occupancy in rounds 2-3).  Not the default.
+// PERSIST (variants 11 / 12): a workgroup walks a CONTIGUOUS chunk of node pairs in order instead of taking one group of four pairs, so that the
+// table rows A2h[src] / A3h[dst] of one step - neighbours of neighbouring reads, largely the same rows - are still in that CU's L1 at the next;
+// NT: the e rows (no reuse inside a CU) are loaded nontemporally so that they do not evict them.
+// MEASURED NEGATIVE: 0.294 (4 workgroups per CU) / 0.303 (+ nontemporal) / 0.311 ms (8 per CU) against 0.205: a CU walking its own chunk gives
+// up what the plain launch has - many CUs of an XCD streaming ADJACENT e rows at the same time (DRAM pages, shared L2 lines).
+template <int NORM, int U = 4, bool PERSIST = false, bool NT = false>
+__global__ __launch_bounds__(kAggThreads) void k_node_aggregate_pair(
+    const float* __restrict__ e, int64_t n_out, const float* __restrict__ A1h, const float* __restrict__ A2h, const float* __restrict__ A3h,
+    int ldn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_ptr,
+    const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_dst, const float* __restrict__ h_in, int ldh,
+    float* __restrict__ h_out, const float* __restrict__ scale, const float* __restrict__ shift, int total_blocks,
+    const int* __restrict__ hub_count, const int* __restrict__ hub_nodes, int64_t node0) {
+    constexpr int H = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 5, gl = lane & 31, c = 4 * gl;
+    auto load_e = [&](int64_t row) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(e + row * H + c);
+        return NT ? __builtin_nontemporal_load(p) : *p;
+    };
+    // total_blocks: PERSIST - the number of 4-pair steps of the whole range, dealt out in contiguous chunks to the gridDim.x workgroups
+    const int steps_per = PERSIST ? (total_blocks + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+    const int chunk = PERSIST ? xcd_remap(blockIdx.x, gridDim.x) : 0;
+  for (int it = 0; it < steps_per; ++it) {
+    const int64_t step = PERSIST ? (int64_t)chunk * steps_per + it : (int64_t)xcd_remap(blockIdx.x, total_blocks);
+    if (PERSIST && step >= total_blocks) break;
+    const int64_t node = node0 + 2 * (step * (kAggThreads / 64) + wave) + grp;
+    bool valid = node < n_out;
+    int ib = 0, din = 0, ob = 0, cnt = 0;
+    if (valid) {
+        ib = in_ptr[node], din = in_ptr[node + 1] - ib;
+        ob = out_ptr[node], cnt = din + out_ptr[node + 1] - ob;
+        if (cnt > kHubThreshold && hub_nodes != nullptr) {   // a listed hub is left to the HUBFIN launch of the kernel above
+            const int nh = min(*hub_count, kHubCap);
+            for (int k = 0; k < nh; ++k) valid = valid && hub_nodes[k] != (int)node;
+        }
+    }
+    if (!valid) cnt = din = 0;
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+    if (valid) a1 = *reinterpret_cast<const f32x4*>(A1h + node * ldn + c);
+    f32x4 nf = {0.f, 0.f, 0.f, 0.f}, df = nf, nb = nf, db = nf;
+    const int cnt_w = max(__shfl(cnt, 0), __shfl(cnt, 32));
+    for (int base = 0; base < cnt_w; base += 32) {
+        const int j = base + gl;   // lane gl of a group owns item base + gl of ITS node
+        int my_p = 0, my_n = 0;
+        if (j < din) {
+            my_n = srt_src[ib + j];
+        } else if (j < cnt) {
+            my_p = out_pos[ob + j - din];
+            my_n = out_dst[ob + j - din];
+        }
+        const int m = max(min(32, cnt - base), 0), m_in = min(m, max(din - base, 0));
+        const int m_in_w = max(__shfl(m_in, 0), __shfl(m_in, 32)), m_out_w = max(__shfl(m - m_in, 0), __shfl(m - m_in, 32));
+        for (int j0 = 0; j0 < m_in_w; j0 += U) {   // in-edges: the rows follow from the CSR pointer alone - requested before the indices are awaited
+            f32x4 x[U], a[U];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                live[u] = j0 + u < m_in;
+                x[u] = load_e((int64_t)(ib + base + (live[u] ? j0 + u : 0)));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int nn = __shfl(my_n, 32 * grp + (live[u] ? j0 + u : 0));
+                a[u] = *reinterpret_cast<const f32x4*>(A2h + (int64_t)nn * ldn + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                f32x4 sg;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sg[k] = live[u] ? sigmoidf_(x[u][k]) : 0.f;
+                nf += sg * a[u];
+                df += sg;
+            }
+        }
+        for (int j0 = 0; j0 < m_out_w; j0 += U) {   // out-edges: item m_in + j0 + u of this batch
+            f32x4 x[U], a[U];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int item = m_in + j0 + u;
+                live[u] = item < m;
+                const int src_lane = 32 * grp + (live[u] ? item : (m > 0 ? m - 1 : 0));
+                const int pp = __shfl(my_p, src_lane), nn = __shfl(my_n, src_lane);
+                x[u] = load_e((int64_t)pp);
+                a[u] = *reinterpret_cast<const f32x4*>(A3h + (int64_t)nn * ldn + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                f32x4 sg;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sg[k] = live[u] ? sigmoidf_(x[u][k]) : 0.f;
+                nb += sg * a[u];
+                db += sg;
+            }
+        }
+    }
+    if (!valid) continue;
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = a1[k] + nf[k] / (df[k] + kAggEps) + nb[k] / (db[k] + kAggEps);
+    if (NORM == GNNOME_NORM_LAYER) {
+        float s1 = v[0] + v[1] + v[2] + v[3];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) s1 += __shfl_xor(s1, o);
+        const float mean = s1 * (1.0f / H);
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s2 += (v[k] - mean) * (v[k] - mean);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) s2 += __shfl_xor(s2, o);
+        const float rstd = rsqrtf(s2 * (1.0f / H) + kNormEps);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (v[k] - mean) * rstd;
+    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(h_in + node * ldh + c);
+    f32x4 y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f) + hi[k];
+    *reinterpret_cast<f32x4*>(h_out + node * H + c) = y;
+  }
+}
+
 template <int H>
 static int launch_agg(const float* e, int64_t n_out, const float* A1h, const float* A2h, const float* A3h, int ldn,
                       const int32_t* in_ptr, const int32_t* ss, const int32_t* out_ptr, const int32_t* out_pos,
@@ -526,6 +657,37 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
             case 6: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 0); break;   // the unsplit item loop (in-edge rows requested after the index wait)
             case 7: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 2); break;   // measurement only: out-edges alone
             case 8: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 3); break;   // no branches around dead items
+            case 11:   // ... walked as contiguous chunks by persistent workgroups (4 per CU)
+            case 12:   // ... with nontemporal e loads
+            case 13:   // the same, 8 workgroups per CU
+                if (H == 128) {
+                    const int64_t pblocks = ((node_end - node_begin + 1) / 2 + (kAggThreads / 64) - 1) / (kAggThreads / 64);
+                    const int per_cu = tuning(kTuneAggVariant) == 13 ? 8 : 4;
+                    const unsigned pgrid = (unsigned)std::min<int64_t>(pblocks, (int64_t)persistent_grid() * per_cu);
+                    if (tuning(kTuneAggVariant) == 11)
+                        hipLaunchKernelGGL((k_node_aggregate_pair<GNNOME_NORM_AFFINE, 4, true, false>), dim3(pgrid), dim3(kAggThreads), dyn, s, e, node_end, A1h, A2h, A3h, ldn,
+                                           in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift, (int)pblocks, hub_count, hub_nodes, node0);
+                    else
+                        hipLaunchKernelGGL((k_node_aggregate_pair<GNNOME_NORM_AFFINE, 4, true, true>), dim3(pgrid), dim3(kAggThreads), dyn, s, e, node_end, A1h, A2h, A3h, ldn,
+                                           in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift, (int)pblocks, hub_count, hub_nodes, node0);
+                } else {
+                    GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks);
+                }
+                break;
+            case 9:   // two nodes per wave (k_node_aggregate_pair), H = 128
+            case 10:
+                if (H == 128) {
+                    const int64_t pblocks = ((node_end - node_begin + 1) / 2 + (kAggThreads / 64) - 1) / (kAggThreads / 64);
+                    if (tuning(kTuneAggVariant) == 9)
+                        hipLaunchKernelGGL((k_node_aggregate_pair<GNNOME_NORM_AFFINE, 4>), dim3((unsigned)pblocks), dim3(kAggThreads), dyn, s, e, node_end, A1h, A2h, A3h, ldn,
+                                           in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift, (int)pblocks, hub_count, hub_nodes, node0);
+                    else
+                        hipLaunchKernelGGL((k_node_aggregate_pair<GNNOME_NORM_AFFINE, 2>), dim3((unsigned)pblocks), dim3(kAggThreads), dyn, s, e, node_end, A1h, A2h, A3h, ldn,
+                                           in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift, (int)pblocks, hub_count, hub_nodes, node0);
+                } else {
+                    GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks);
+                }
+                break;
             default: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks); break;
         }
         if (hub_pass) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, true, UD, 0, kFinGrid);

@@ -53,6 +53,9 @@ def test_gfa_similarity_sources(tmp_path):
     gfa.write_similarity_tags(path, tagged, sims)
     g = gfa.read_gfa(tagged, similarity=None)
     assert torch.equal(g["src"], c["src"]) and torch.allclose(g["overlap_similarity"].double(), c["overlap_similarity"].double(), atol=1e-7)
+    # an explicit aligner overrides the tags (the docstring's order)
+    g2 = gfa.read_gfa(tagged, similarity=lambda a, b, ol: 0.25)
+    assert bool((g2["overlap_similarity"][g2["overlap_length"] > 0] == 0.25).all())
 
 
 def test_dgl_graph_converter_and_missing_dgl(tmp_path):

@@ -360,6 +360,23 @@ def test_node_aggregate_hub_split_path(hidden, deg):
     assert torch.equal(got[mask.to(dev())], single[mask.to(dev())])
     _assert_close(single[hub], want[hub], scale=10.0)
     print(f"hub of 2 x {deg} edges, H={hidden}: split path {t_split * 1e3:.3f} ms, single wave {t_single * 1e3:.3f} ms")
+    # two streams at once (round 4: the hub scratch is per (device, stream), it used to be shared behind a "don't" contract): a second
+    # graph with its own hub aggregates on a side stream while this one runs on the current stream - both equal their solo results
+    src2, dst2 = src.clone(), dst.clone()
+    dst2[e_bg:e_bg + deg], src2[e_bg + deg:] = 99, 99
+    gv2 = ops.GraphViews(src2.to(dev()), dst2.to(dev()), n)
+    run2 = lambda: ops.node_aggregate(d["e"], d["P"][:, :H], d["P"][:, H:2 * H], d["P"][:, 2 * H:], gv2, d["h"], 0, d["scale"], d["shift"])  # noqa: E731
+    solo2 = run2()
+    side = torch.cuda.Stream(device=dev())
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(4):
+        with torch.cuda.stream(side):
+            b = run2()
+        a_ = run()
+        outs.append((a_, b))
+    torch.cuda.synchronize()
+    assert all(torch.equal(a_, got) and torch.equal(b, solo2) for a_, b in outs)
 
 
 @pytest.mark.parametrize("hidden", [64, 128, 256])

@@ -492,6 +492,51 @@ def test_bf16_activation_storage_training_step():
         step("fp8")
 
 
+def test_bf16_activation_storage_at_the_configs2_size_against_the_checker():
+    """BASELINE configs[2] says "bf16" - the bf16-storage step at ITS size (N = 1e5, E = 1e6, H = 128), not only
+    at 30k edges: the HIP step's loss against the checker backend's forward making the same roundings on the CPU (forward only: the
+    loss is what the checker is asked for), the step finite and repeatable, and its distance to the fp32 step inside the small test's bounds."""
+    import cpu_ops
+    from gnnome_amd import train as train_mod
+    from gnnome_amd.loss import bce_loss as hip_bce
+    n, e, hidden = 100_000, 1_000_000, 128
+    gr = make_graph(n, e, seed=1)
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(hidden, seed=5)
+    views = gnnome_amd.graph.views_for((gr["src"], gr["dst"], n), dev())
+    xd, ef, y, pw = x.to(dev()), gr["e"].to(dev()), gr["y"].to(dev()), gr["pos_weight"].to(dev())
+
+    def step(storage):
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch", dropout=0.0)
+        m.load_state_dict(sd)
+        m.activation_storage = storage
+        m = m.to(dev()).train()
+        logits = m(views, xd, ef)
+        loss = hip_bce(logits.squeeze(-1), y, pw)
+        loss.backward()
+        out = (loss.item(), logits.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+        del m, logits, loss
+        return out
+
+    l16, z16, g16 = step("bf16")
+    l16b, z16b, g16b = step("bf16")
+    assert l16 == l16b and torch.equal(z16, z16b) and all(torch.equal(g16[k], g16b[k]) and torch.isfinite(g16[k]).all() for k in g16)
+    l32, z32, g32 = step("fp32")
+    mc = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch", dropout=0.0)
+    mc.load_state_dict(sd)
+    mc.activation_storage = "bf16"
+    mc.train()
+    with torch.no_grad():
+        zck = train_mod.train_forward_on(mc, train_mod.WholeGraph(cpu_ops.CpuViews(gr["src"], gr["dst"], n), cpu_ops), x, gr["e"])
+        lck = F.binary_cross_entropy_with_logits(zck.squeeze(-1), gr["y"], pos_weight=gr["pos_weight"]).item()
+    print(f"bf16 storage at 1M edges: loss {l16:.7f}, checker {lck:.7f}, fp32 step {l32:.7f}")
+    assert abs(l16 - lck) <= 2e-5 * abs(lck)
+    assert (torch.sigmoid(z16.cpu()) - torch.sigmoid(zck)).abs().max().item() <= 2e-3     # (bf16 ties round differently on the two sides)
+    num = sum(((g16[k] - g32[k]).double() ** 2).sum().item() for k in g32) ** 0.5
+    den = sum((g32[k].double() ** 2).sum().item() for k in g32) ** 0.5
+    assert abs(l16 - l32) < 2e-3 * abs(l32) and (torch.sigmoid(z16) - torch.sigmoid(z32)).abs().max().item() < 2e-2 and num / den < 5e-2
+
+
 def test_training_step_full_size_properties():
     """BASELINE configs[2]'s shape (N = 1e5, E = 1e6, H = 128): a whole fwd + BCE + bwd step twice from the same state -
     same bits (logits, loss, all 142 gradients, BatchNorm buffers), everything finite, BatchNorm counters advanced as the

@@ -229,3 +229,33 @@ def test_banded_pass_is_exact_inside_its_band_and_hands_over_outside():
         got, _ = overlap.edit_distances(rd, s2, d2, o2, device=dev(), stats=st2)
         assert got.cpu().tolist() == w2, alphabet
         assert (st2["banded"] > 0) == banded, (alphabet, st2)
+
+
+@pytest.mark.gpu
+def test_endpoints_out_of_range_are_reported_by_the_kernel_itself():
+    """a caller of the C ABI (not of the Python wrapper, which checks) may hand over node ids outside [0, 2R): the
+    kernels must not index the offsets with them - the edge comes back as -1, its neighbours in the list are aligned as usual."""
+    import ctypes
+
+    from gnnome_amd import _lib, overlap
+    from gnnome_amd.ops import _ptr, _stream
+    rng = random.Random(5)
+    reads = _overlapping_reads(rng, [300, 400, 500, 350], 0.02)
+    src, dst, ol = [0, 2, 9, 4, -1, 1], [2, 4, 2, 800, 3, 3], [100, 150, 50, 60, 70, 80]
+    data, off = overlap.pack_reads(reads)
+    symtab, nsym = overlap.symbol_table(data)
+    d = dev()
+    t = lambda x, dt: torch.as_tensor(x, dtype=dt).to(d)  # noqa: E731
+    data, off, symtab = data.to(d), off.to(d), symtab.to(d)
+    s_, d_, o_ = t(src, torch.int32), t(dst, torch.int32), t(ol, torch.int32)
+    dist = torch.full((len(src),), -7, dtype=torch.int32, device=d)
+    lib = _lib.load()
+    need = ctypes.c_size_t(0)
+    _lib.check(lib.gnnome_overlap_workspace_bytes(ctypes.byref(need)), "ws")
+    ws = torch.empty(int(need.value), dtype=torch.uint8, device=d)
+    _lib.check(lib.gnnome_overlap_edit_distance(_ptr(data), _ptr(off), len(reads), _ptr(symtab), nsym, _ptr(s_), _ptr(d_), _ptr(o_), len(src),
+                                                _ptr(dist), None, _ptr(ws), ws.numel(), _stream(d)), "overlap_edit_distance")
+    good = [0, 1, 5]
+    want, _ = overlap_oracle.calculate_similarities(reads, [src[i] for i in good], [dst[i] for i in good], [ol[i] for i in good])
+    got = dist.cpu().tolist()
+    assert [got[i] for i in good] == want and [got[i] for i in (2, 3, 4)] == [-1, -1, -1]
