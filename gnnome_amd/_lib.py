@@ -36,6 +36,8 @@ SIGNATURES = {
     "gnnome_edge_gate_raw_stats_rows": [_i, ctypes.POINTER(_i)],
     "gnnome_edge_gate_raw_stats_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
     "gnnome_edge_gate_raw_stats_x16": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
+    "gnnome_edge_gate_bn_f32": [_p, _p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
+    "gnnome_edge_gate_bn_x16": [_p, _p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
     "gnnome_node_aggregate_raw_f32": [_p, _i, _l, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_colsum_workspace_bytes": [ctypes.POINTER(_sz)],
     "gnnome_colsum2_f32": [_p, _p, _l, _i, _p, _p, _p, _p, _sz, _p],
@@ -83,7 +85,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

@@ -57,7 +57,7 @@ struct GateBfArgs {
     GateEnc enc;              // mode 0 with the folded edge encoder
     GateBnBwd bnb;            // mode 3
 };
-int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& args, hipStream_t s, bool x16 = false);
+int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& args, hipStream_t s, bool x16 = false, int extra = 0);
 // H = 256, affine norm, e_out != e_in: barrier-free streaming gate (edge_gate_stream.hip)
 int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn, const int32_t* ss,
                        const int32_t* sd, const float* W3, int ldw, const float* scale, const float* shift, hipStream_t s);

@@ -681,8 +681,10 @@ static int raw_stats_impl(const float* e_in, void* x_out, int64_t num_edges, int
                           const float* W3, int ldw, const float* center, float* stats_partial, void* stream, bool x16) {
     using namespace gnnome;
     GN_REQUIRE(num_edges > 0, "edge_gate_raw_stats: needs at least one edge");
-    GN_REQUIRE(e_in && x_out && x_out != (const void*)e_in && B1h && B2h && srt_src && srt_dst && W3 && center && stats_partial,
+    GN_REQUIRE(e_in && x_out != (const void*)e_in && B1h && B2h && srt_src && srt_dst && W3 && center && stats_partial,
                "edge_gate_raw_stats: bad pointers");
+    // x_out == NULL: the statistics alone (the first pass of the two-pass training forward; hidden = 128, the plane form)
+    GN_REQUIRE(x_out || (hidden == 128 && tuning(kTuneGateVariant) == 0), "edge_gate_raw_stats: x_out may be NULL at hidden = 128 only (default kernels)");
     GN_REQUIRE(hidden == 64 || hidden == 128 || (hidden == 256 && !x16), "edge_gate_raw_stats: hidden=%d not in {64,128,256 (fp32)}", hidden);
     GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ldw >= hidden && ldw % 4 == 0, "edge_gate_raw_stats: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0) && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0),
@@ -698,7 +700,7 @@ static int raw_stats_impl(const float* e_in, void* x_out, int64_t num_edges, int
         GateBfArgs a = {};
         a.e_in = e_in; a.e_out = (float*)x_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
         a.srt_dst = srt_dst; a.W3 = W3; a.ldw = ldw; a.scale = center; a.stats = stats_partial;
-        return gate_bf_launch(hidden, 1, false, a, s, x16);
+        return gate_bf_launch(hidden, 1, false, a, s, x16, x_out == nullptr ? 1 : 0);
     }
     if (hidden == 128)
         return launch_ws_raw_stats<4, 1>(e_in, (float*)x_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, s);
@@ -715,6 +717,38 @@ extern "C" int gnnome_edge_gate_raw_stats_x16(const float* e_in, uint16_t* x_out
                                               const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
                                               const float* W3, int ldw, const float* center, float* stats_partial, void* stream) {
     return raw_stats_impl(e_in, x_out, num_edges, hidden, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, center, stats_partial, stream, true);
+}
+
+// The second pass of the two-pass training forward (hidden = 128): e_out = relu(xe * scale + shift) + e_in with the pre-normalisation rows
+// xe = e_in W3^T + B1h[src] + B2h[dst] ALSO written to x_out (fp32, or bf16 with x16: e_out is then computed from the rounded rows).
+static int gate_bn_impl(const float* e_in, float* e_out, void* x_out, int64_t num_edges, int hidden, const float* B1h, const float* B2h, int ld_node,
+                        const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw, const float* scale, const float* shift,
+                        void* stream, bool x16) {
+    using namespace gnnome;
+    GN_REQUIRE(num_edges >= 0, "edge_gate_bn: negative edge count");
+    if (num_edges == 0) return GNNOME_OK;
+    GN_REQUIRE(e_in && e_out && x_out && x_out != (const void*)e_in && x_out != (void*)e_out && B1h && B2h && srt_src && srt_dst && W3 && scale && shift,
+               "edge_gate_bn: bad pointers");
+    GN_REQUIRE(hidden == 128 && tuning(kTuneGateVariant) == 0, "edge_gate_bn: built at hidden = 128 (default kernels), got %d", hidden);
+    GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ldw >= hidden && ldw % 4 == 0, "edge_gate_bn: bad strides");
+    GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)e_out % 16 == 0) && ((uintptr_t)x_out % 16 == 0) && ((uintptr_t)W3 % 16 == 0) &&
+                   ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0), "edge_gate_bn: 16-byte alignment required");
+    GateBfArgs a = {};
+    a.e_in = e_in; a.e_out = e_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src; a.srt_dst = srt_dst;
+    a.W3 = W3; a.ldw = ldw; a.scale = scale; a.shift = shift; a.bnb.a_out = (float*)x_out;
+    return gate_bf_launch(hidden, 0, false, a, (hipStream_t)stream, x16, 1);
+}
+
+extern "C" int gnnome_edge_gate_bn_f32(const float* e_in, float* e_out, float* x_out, int64_t num_edges, int hidden, const float* B1h,
+                                       const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw,
+                                       const float* scale, const float* shift, void* stream) {
+    return gate_bn_impl(e_in, e_out, x_out, num_edges, hidden, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, scale, shift, stream, false);
+}
+
+extern "C" int gnnome_edge_gate_bn_x16(const float* e_in, float* e_out, uint16_t* x_out, int64_t num_edges, int hidden, const float* B1h,
+                                       const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw,
+                                       const float* scale, const float* shift, void* stream) {
+    return gate_bn_impl(e_in, e_out, x_out, num_edges, hidden, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, scale, shift, stream, true);
 }
 
 extern "C" int gnnome_edge_gate_encode_f32(const float* e_raw, const int32_t* srt_eid, const float* encW1, const float* encb1,

@@ -477,8 +477,12 @@ __device__ __forceinline__ void split4_planes(const f32x4 x, uint2& p1, uint2& p
 // stride a.ldn, C row stride a.ld_out, a.scale = bias (NULL: none).
 // F16 (round 4, the default for the forward modes 0, 1 and 4; gnnome_set_tuning(10, 1) = bf16x6): two fp16 planes and three MFMAs per
 // k step instead of three bf16 planes and six - the slot stays 26 KB (the x tile needs 17 KB of it either way).
-template <bool ENC, int MODE = 0, bool X16 = false, bool F16 = false>
+// EXTRA (round 4, the training forward in two passes instead of three - train.py): MODE 1 + EXTRA = the statistics alone, nothing stored;
+// MODE 0 + EXTRA = the gate with the pre-normalisation rows xe = x + G ALSO written out (to a.bnb.a_out; X16: as bf16, and e' is then
+// computed from the rounded values, like gnnome_bn_relu_res_x16 reading them back).
+template <bool ENC, int MODE = 0, bool X16 = false, bool F16 = false, int EXTRA = 0>
 __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
+    static_assert(EXTRA == 0 || ((MODE == 0 || MODE == 1) && !ENC), "EXTRA belongs to modes 0 and 1");
     static_assert(MODE >= 0 && MODE <= 4, "modes of the plane form");   // 2: C += A W^T (the residual GEMM; mode 3 without the BatchNorm step)
     static_assert(!ENC || MODE == 0, "the folded encoder belongs to the inference gate");
     static_assert(!F16 || MODE == 0 || MODE == 1 || MODE == 4, "fp16x3 is built for the forward modes (gradients need a scale)");
@@ -751,9 +755,14 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                     const int p = pb + u, row = r0 + p * RSTEP;
                     f32x4 y;
                     if (MODE == 0) {
+                        f32x4 xg = x[u] + gk[p];
+                        if (EXTRA) {
+                            if (X16) xg = unpack_bf16x4(pack_bf16x4(xg));
+                            if (row < valid) store4_as<X16>(a.bnb.a_out, obase + (off_row + (unsigned)(p * RSTEP * H)), xg);
+                        }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float t = (x[u][j] + gk[p][j]) * sc4[j] + sh4[j];
+                            const float t = xg[j] * sc4[j] + sh4[j];
                             // F16: an operand beyond fp16's range reaches here as inf / NaN and must not leave the relu as 0 (t - t is 0 iff t is finite)
                             y[j] = (!F16 || t - t == 0.f) ? fmaxf(t, 0.f) + ek[p][j] : __builtin_nanf("");
                         }
@@ -769,7 +778,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                                 const f32x4 dlt = y - sc4;
                                 st1 += dlt;
                                 st2 += dlt * dlt;
-                                store4_as<X16>(a.e_out, obase + (off_row + (unsigned)(p * RSTEP * H)), y);
+                                if (!EXTRA) store4_as<X16>(a.e_out, obase + (off_row + (unsigned)(p * RSTEP * H)), y);
                             } else {
                                 *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
                             }
@@ -807,17 +816,17 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
     }
 }
 
-template <bool ENC, int MODE = 0, bool X16 = false, bool F16 = false>
+template <bool ENC, int MODE = 0, bool X16 = false, bool F16 = false, int EXTRA = 0>
 static int launch_pl_arith(const GateBfArgs& args, hipStream_t s);
-template <bool ENC, int MODE = 0, bool X16 = false>
+template <bool ENC, int MODE = 0, bool X16 = false, int EXTRA = 0>
 static int launch_pl(const GateBfArgs& args, hipStream_t s) {
     // forward modes: fp16x3 unless gnnome_set_tuning(10, 1) asks for bf16x6 (the folded-encoder form keeps bf16x6; mode 1 with bf16 storage follows
     // the fp32-storage kernel, so that what it stores is that kernel's result rounded)
-    constexpr bool kForward = !ENC && (MODE == 1 || (!X16 && (MODE == 0 || MODE == 4)));
-    if (kForward && tuning(kTuneArith) == 0) return launch_pl_arith<ENC, kForward ? MODE : 0, kForward ? X16 : false, kForward>(args, s);
-    return launch_pl_arith<ENC, MODE, X16, false>(args, s);
+    constexpr bool kForward = !ENC && (MODE == 1 || (MODE == 0 && (EXTRA || !X16)) || (MODE == 4 && !X16));
+    if (kForward && tuning(kTuneArith) == 0) return launch_pl_arith<ENC, kForward ? MODE : 0, kForward ? X16 : false, kForward, kForward ? EXTRA : 0>(args, s);
+    return launch_pl_arith<ENC, MODE, X16, false, EXTRA>(args, s);
 }
-template <bool ENC, int MODE, bool X16, bool F16>
+template <bool ENC, int MODE, bool X16, bool F16, int EXTRA>
 static int launch_pl_arith(const GateBfArgs& args, hipStream_t s) {
     GateBfArgs a = args;
     const int64_t tiles = (a.E + 31) / 32;
@@ -828,7 +837,7 @@ static int launch_pl_arith(const GateBfArgs& args, hipStream_t s) {
     if (MODE == 1) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * kNumCUs * 8 * 2 * 128, s));   // idle waves leave zeros
     GN_REQUIRE(MODE != 4 || (a.num_cblocks >= 1 && a.num_cblocks <= persistent_grid() / kXcds && a.ldn >= 128 && a.ldn % 4 == 0 && a.ld_out % 4 == 0),
                "linear (K = 128): %d column blocks / strides %d, %d", a.num_cblocks, a.ldn, a.ld_out);
-    hipLaunchKernelGGL((k_edge_gate_pl<ENC, MODE, X16, F16>), dim3(persistent_grid()), dim3(768), 0, s, a);
+    hipLaunchKernelGGL((k_edge_gate_pl<ENC, MODE, X16, F16, EXTRA>), dim3(persistent_grid()), dim3(768), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
@@ -1057,8 +1066,13 @@ static int launch_bf(const GateBfArgs& args, hipStream_t s) {
     return GNNOME_OK;
 }
 
-int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStream_t s, bool x16) {
+int gate_bf_launch(int hidden, int mode, bool enc, const GateBfArgs& a, hipStream_t s, bool x16, int extra) {
     const bool planes = hidden == 128 && tuning(kTuneGateVariant) != 8;   // the plane form (k_edge_gate_pl), modes 0, 1 and 3
+    if (extra) {   // the two-pass training forward: statistics only (mode 1) / gate + xe out (mode 0); H = 128 plane form only
+        GN_REQUIRE(hidden == 128 && !enc && (mode == 0 || mode == 1), "edge-tile kernel: the two-pass training forward is built at hidden = 128");
+        if (mode == 1) return x16 ? launch_pl<false, 1, true, 1>(a, s) : launch_pl<false, 1, false, 1>(a, s);
+        return x16 ? launch_pl<false, 0, true, 1>(a, s) : launch_pl<false, 0, false, 1>(a, s);
+    }
     if (x16) {   // bf16 storage of xe / dxe: modes 1 and 3 only
         if (mode == 1 && planes) return launch_pl<false, 1, true>(a, s);
         if (mode == 3 && planes) return launch_pl<false, 3, true>(a, s);

@@ -159,9 +159,13 @@ class GraphViews:
 edge_gate_out_of_place_at_256 = True   # engine.gate_update: the H = 256 streaming gate needs out != e
 
 
+_TUNING = {}   # what set_tuning was last told, per key (the library keeps no getter)
+
+
 def set_tuning(key, value):
     """Select a kernel variant for A/B measurements (see gnnome_set_tuning in include/gnnome_hip.h)."""
     _lib.check(_lib.load().gnnome_set_tuning(int(key), int(value)), "set_tuning")
+    _TUNING[int(key)] = int(value)
 
 
 def encode(x, W1, b1, W2, b2, gather=None, rows=None):
@@ -500,6 +504,49 @@ def edge_gate_raw_moments(e, B1h, B2h, views, W3, storage=torch.float32):
           _ptr(B2h), ldn, _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(center), _ptr(partial))
     sums = _partial_sums(partial, H)
     return out, (sums[:H], sums[H:], center, E)
+
+
+def can_two_pass_gate(e, B1h, B2h, storage=None):
+    """The training forward's gate in two passes instead of three (round 4): statistics alone, then gate + xe out.  hidden = 128, the
+    default kernels (gnnome_set_tuning key 0 untouched), 16-byte aligned row tables."""
+    return (e.shape[1] == 128 and e.shape[0] > 0 and e.is_contiguous() and B1h.stride(0) % 4 == 0 and B2h.stride(0) % 4 == 0 and
+            B1h.data_ptr() % 16 == 0 and B2h.data_ptr() % 16 == 0 and _TUNING.get(0, 0) == 0)
+
+
+def edge_gate_moments_only(e, B1h, B2h, views, W3, storage=torch.float32):
+    """-> (d1, d2, center, E): edge_gate_raw_moments' statistics WITHOUT the [E,H] output (gnnome_edge_gate_raw_stats_f32 with x_out = NULL)."""
+    H, E = e.shape[1], e.shape[0]
+    e = _dense(e, "edge_gate_moments_only.e")
+    x16 = storage == torch.bfloat16
+    B1h, ldn = _rows(B1h, "edge_gate_moments_only.B1h")
+    B2h, _ = _rows(B2h, "edge_gate_moments_only.B2h")
+    W3, ldw = _rows(W3, "edge_gate_moments_only.W3")
+    center = torch.empty(H, dtype=torch.float32, device=e.device)
+    _call("gnnome_gate_center_f32", e.device, _ptr(e), E, H, _ptr(B1h), _ptr(B2h), ldn, _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(W3), ldw,
+          _ptr(center))
+    rows = ctypes.c_int(0)
+    _lib.check(_lib.load().gnnome_edge_gate_raw_stats_rows(H, ctypes.byref(rows)), "edge_gate_raw_stats_rows")
+    partial = torch.empty((rows.value, 2 * H), dtype=torch.float32, device=e.device)
+    _call("gnnome_edge_gate_raw_stats_x16" if x16 else "gnnome_edge_gate_raw_stats_f32", e.device, _ptr(e), None, E, H, _ptr(B1h),
+          _ptr(B2h), ldn, _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(center), _ptr(partial))
+    sums = _partial_sums(partial, H)
+    return sums[:H], sums[H:], center, E
+
+
+def edge_gate_bn(e, B1h, B2h, views, W3, scale, shift, storage=torch.float32):
+    """-> (e_new, xe): e_new = relu(xe * scale + shift) + e and xe = e W3^T + B1h[src] + B2h[dst] in ONE pass (gnnome_edge_gate_bn_f32):
+    the train-mode gate once the batch statistics are known.  storage = bfloat16: xe stored as bf16, e_new computed from the rounded rows."""
+    H, E = e.shape[1], e.shape[0]
+    e = _dense(e, "edge_gate_bn.e")
+    x16 = storage == torch.bfloat16
+    B1h, ldn = _rows(B1h, "edge_gate_bn.B1h")
+    B2h, _ = _rows(B2h, "edge_gate_bn.B2h")
+    W3, ldw = _rows(W3, "edge_gate_bn.W3")
+    e_new = torch.empty_like(e)
+    xe = torch.empty_like(e, dtype=torch.bfloat16 if x16 else torch.float32)
+    _call("gnnome_edge_gate_bn_x16" if x16 else "gnnome_edge_gate_bn_f32", e.device, _ptr(e), _ptr(e_new), _ptr(xe), E, H, _ptr(B1h), _ptr(B2h), ldn,
+          _ptr(views.srt_src), _ptr(views.srt_dst), _ptr(W3), ldw, _ptr(scale), _ptr(shift))
+    return e_new, xe
 
 
 def _partial_sums(partial, H):

@@ -136,6 +136,7 @@ def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out, stats=None, 
 
 
 ACTIVATION_STORAGE = ("fp32", "bf16")
+TWO_PASS_GATE = True   # the single-rank BatchNorm forward at hidden 128 as statistics pass + fused gate (tools/train_ab.py switches it for A/B runs)
 
 
 def _storage_dtype(model):
@@ -221,8 +222,23 @@ class _TrainStep(torch.autograd.Function):
             mean_e = rstd_e = sc_e = sh_e = mean_h = rstd_h = sc_h = sh_h = None
             if layer_norm and storage != torch.float32:
                 raise _no_bf16_storage()
-            path, xe, stats = _raw_gate(sh, conv, e, blk(P, "B1"), blk(P, "B2"), layer_norm, storage)
-            if layer_norm:   # per-row statistics: nothing crosses rows (or ranks), and there are no running buffers
+            # (fp32 storage only - measured, tools/train_two_pass_ab.py: 24.90 against 25.28 ms per step; with bf16 storage the third pass moves half
+            #  the bytes and the two forms are level, 24.2 against 24.1)
+            two_pass = (TWO_PASS_GATE and not layer_norm and not recompute and storage == torch.float32 and _can_fuse_bn(sh, conv.bn_e) and hasattr(ops, "edge_gate_bn") and
+                        ops.can_two_pass_gate(e, blk(P, "B1"), blk(P, "B2"), storage))
+            if two_pass:
+                # round 4: statistics alone (nothing stored), then the gate with the statistics folded in, which also leaves xe for the
+                # backward - the [E,H] tensor is written once and not read back in the forward (2 GB per layer instead of 2.5 at configs[2])
+                W3 = d(conv.B_3.weight)
+                path = "moments"
+                mean_e, rstd_e, sc_e, sh_e = _bn_train_fused(sh, conv.bn_e, ops.edge_gate_moments_only(e, blk(P, "B1"), blk(P, "B2"), views, W3, storage=storage),
+                                                             updates=2)
+                e_new, xe = ops.edge_gate_bn(e, blk(P, "B1"), blk(P, "B2"), views, W3, sc_e, sh_e, storage=storage)
+            else:
+                path, xe, stats = _raw_gate(sh, conv, e, blk(P, "B1"), blk(P, "B2"), layer_norm, storage)
+            if two_pass:
+                pass
+            elif layer_norm:   # per-row statistics: nothing crosses rows (or ranks), and there are no running buffers
                 e_new = ops.ln_relu_res(xe, d(conv.bn_e.weight), d(conv.bn_e.bias), e)
             else:
                 if path == "moments":

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 9
+#define GNNOME_ABI_VERSION 10
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -230,10 +230,18 @@ int gnnome_edge_gate_raw_f32(const float* e_in, float* x_out, int64_t num_edges,
  * FIXED order, e.g. gnnome_colsum2_f32) gives the sums the statistics need without a second pass over x_out.
  * center: any per-column value near the column mean (row 0 of x_out is one) - the shift keeps the second moment
  * free of cancellation. */
+/* x_out == NULL (hidden = 128): the statistics alone - the first pass of the two-pass training forward (round 4): the product is cheap on the
+ * matrix cores (fp16x3), a written and re-read [E,H] tensor is not.  The second pass is gnnome_edge_gate_bn_f32 below. */
 int gnnome_edge_gate_raw_stats_rows(int hidden, int* rows_host);
 int gnnome_edge_gate_raw_stats_f32(const float* e_in, float* x_out, int64_t num_edges, int hidden, const float* B1h,
                                    const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst,
                                    const float* W3, int ldw, const float* center, float* stats_partial, void* stream);
+/* e_out = relu(xe * scale + shift) + e_in  AND  x_out = xe = e_in W3^T + B1h[src] + B2h[dst]: the train-mode gate once the batch statistics are
+ * known (scale = gamma * rstd, shift = beta - mean * scale): what gnnome_edge_gate_raw_f32 + gnnome_bn_relu_res_f32 did in two passes over
+ * [E,H] (gated_gcn_full.py:97,104-110 under train()).  hidden = 128; e_out, x_out and e_in distinct. */
+int gnnome_edge_gate_bn_f32(const float* e_in, float* e_out, float* x_out, int64_t num_edges, int hidden, const float* B1h,
+                            const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw,
+                            const float* scale, const float* shift, void* stream);
 
 /* Gated aggregation without the node epilogue.
  *   mode 1: v_out = A1h + fwd + bwd (input of bn_h, gated_gcn_full.py:129); aux0 = fwd, aux1 = 1/(den_f+1e-6),
@@ -497,6 +505,10 @@ int gnnome_bfs_levels(const int32_t* ptr, const int32_t* adj, int64_t num_nodes,
 int gnnome_edge_gate_raw_stats_x16(const float* e_in, uint16_t* x_out, int64_t num_edges, int hidden, const float* B1h, const float* B2h,
                                    int ld_node, const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw,
                                    const float* center, float* stats_partial, void* stream);
+/* gnnome_edge_gate_bn_f32 with x_out stored as bf16; e_out is computed from the ROUNDED rows (what gnnome_bn_relu_res_x16 reads back). */
+int gnnome_edge_gate_bn_x16(const float* e_in, float* e_out, uint16_t* x_out, int64_t num_edges, int hidden, const float* B1h,
+                            const float* B2h, int ld_node, const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw,
+                            const float* scale, const float* shift, void* stream);
 int gnnome_bn_relu_res_x16(const uint16_t* x, const float* scale, const float* shift, const float* res, int64_t rows, int hidden,
                            float* out, void* stream);
 int gnnome_agg_edge_bwd_stats_x16(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf, const float* Tb,

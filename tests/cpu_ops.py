@@ -205,6 +205,19 @@ def can_fuse_gate_moments(e, B1h, B2h, storage=None):
     return e.shape[0] > 0
 
 
+def can_two_pass_gate(e, B1h, B2h, storage=None):
+    return e.shape[0] > 0 and e.shape[1] == 128
+
+
+def edge_gate_moments_only(e, B1h, B2h, views, W3, storage=torch.float32):
+    return edge_gate_raw_moments(e, B1h, B2h, views, W3, storage)[1]
+
+
+def edge_gate_bn(e, B1h, B2h, views, W3, scale, shift, storage=torch.float32):
+    xe = edge_gate_raw(e, B1h, B2h, views, W3).to(storage)
+    return bn_relu_res(xe, scale, shift, e), xe
+
+
 def bn_train_finish(moments, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, updates):
     d1, d2, c, rows = moments
     m1 = d1 / rows

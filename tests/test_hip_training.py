@@ -799,3 +799,25 @@ def test_dropout_training_step_matches_the_checker_backend_with_the_same_masks(m
     with torch.no_grad():
         a, b = m((gr["src"], gr["dst"], n), x.to(dev()), gr["e"].to(dev())), m((gr["src"], gr["dst"], n), x.to(dev()), gr["e"].to(dev()))
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
+def test_two_pass_gate_kernels_equal_the_three_pass_form(storage):
+    """Round 4: the training forward's gate as statistics-only pass + fused gate (gnnome_edge_gate_raw_stats with x_out = NULL,
+    gnnome_edge_gate_bn): the same statistics and the same xe bit for bit as the raw gate with statistics, e' equal to
+    gnnome_bn_relu_res on that xe to an fp32 rounding (the fused epilogue contracts the multiply-add), at a ragged size."""
+    n, e, H = 3000, 70_001, 128
+    g = torch.Generator().manual_seed(7)
+    src, dst = torch.randint(0, n, (e,), generator=g).int(), torch.randint(0, n, (e,), generator=g).int()
+    views = ops.GraphViews(src.to(dev()), dst.to(dev()), n)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev())  # noqa: E731
+    ee, P, W3 = 2 * r(e, H), r(n, 2 * H), (torch.randn(H, H, generator=g) / H ** 0.5).to(dev())
+    sc, sh = (0.5 + torch.rand(H, generator=g)).to(dev()), r(H)
+    xe3, (d1, d2, c, rows) = ops.edge_gate_raw_moments(ee, P[:, :H], P[:, H:], views, W3, storage=storage)
+    e3 = ops.bn_relu_res(xe3, sc, sh, ee)
+    m1, m2, c2, rows2 = ops.edge_gate_moments_only(ee, P[:, :H], P[:, H:], views, W3, storage=storage)
+    assert rows2 == rows == e and torch.equal(c2, c) and torch.equal(m1, d1) and torch.equal(m2, d2)
+    e2, xe2 = ops.edge_gate_bn(ee, P[:, :H], P[:, H:], views, W3, sc, sh, storage=storage)
+    assert xe2.dtype == storage and torch.equal(xe2, xe3)
+    assert (e2 - e3).abs().max().item() <= 1e-6 * max(1.0, e3.abs().max().item())
+    assert ops.can_two_pass_gate(ee, P[:, :H], P[:, H:], storage)
