@@ -91,3 +91,45 @@ def test_powers_of_two_commute_and_small_operands_keep_their_precision():
     assert np.max(np.abs(f16x3(tiny, w) - ref)) <= K * 2.0 ** -36
     big = np.full((4, K), 70000.0, np.float32)
     assert not np.isfinite(f16x3(big, w)).any()                                   # beyond fp16's range the result is loud, not wrong
+
+
+def test_whole_model_probabilities_with_emulated_products():
+    """DESIGN.md section 4's accuracy table, extended by fp16x3: the oracle's 8-layer model (models/full_graph.py:22-30 restated) with the six
+    H x H products of every layer replaced by the emulated split arithmetic, against an fp64 evaluation of the same model - max |dp| on
+    the edge probabilities is what BASELINE's 1e-4 bar is about.  fp16x3 must be no worse than the fp32 model and than bf16x6."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gnnome_amd.synth import make_graph, random_state_dict
+    from oracle.symgated_oracle import degree_features, model_from_state_dict
+    n, e, hidden = 2000, 20_000, 128
+    g = make_graph(n, e, seed=3)
+    x = degree_features(g["src"], g["dst"], n)
+    sd = random_state_dict(hidden, seed=3)
+    graph = (g["src"], g["dst"], n)
+    with torch.no_grad():
+        p64 = torch.sigmoid(model_from_state_dict(sd, dtype=torch.float64).eval()(graph, x.double(), g["e"].double())).squeeze(-1)
+
+    def run(product):
+        m = model_from_state_dict(sd).eval()
+        if product is not None:
+            for conv in m.gnn.convs:
+                for name in ("A_1", "A_2", "A_3", "B_1", "B_2", "B_3"):
+                    lin = getattr(conv, name)
+                    w, b = lin.weight.detach().numpy(), lin.bias.detach()
+                    lin.forward = (lambda inp, w=w, b=b: torch.from_numpy(product(inp.numpy(), w)) + b)
+        with torch.no_grad():
+            p = torch.sigmoid(m(graph, x, g["e"])).squeeze(-1)
+        return (p.double() - p64).abs().max().item()
+
+    def k128(fn):
+        return lambda a, w: fn(np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(w, dtype=np.float32))
+
+    global K
+    old_k, K = K, hidden
+    try:
+        d32, d6, d16 = run(None), run(k128(bf16x6)), run(k128(f16x3))
+    finally:
+        K = old_k
+    print(f"max |dp| against fp64: fp32 model {d32:.2e}, bf16x6 {d6:.2e}, fp16x3 {d16:.2e}")
+    assert d16 <= 2 * max(d32, d6) + 1e-7 and d16 < 1e-5
