@@ -64,7 +64,10 @@ const char* gnnome_last_error(void);
  *   key 7 aggregation variant: 1-5 items in flight / occupancy A/B, 6 unsplit item loop
  *   key 8 reference-order kernels: 0 the fp32 matrix cores (v_mfma_f32_32x32x2_f32 as a k-ascending fma chain), 1 the
  *                             scalar-fed VALU chains of round 2 (same bits)
- *   key 9 overlap edit distance: 0 banded (Ukkonen) pass first, the full matrix for what exceeds the band; 1 full matrix only */
+ *   key 9 overlap edit distance: 0 banded (Ukkonen) pass first, the full matrix for what exceeds the band; 1 full matrix only
+ *   key 10 forward arithmetic : 0 fp16x3 on the f16 matrix cores for the forward's dense products at H = 128 / 256 (round 4; see
+ *                             gnnome_linear_f32), 1 bf16x6 everywhere (round 3's arithmetic; the plane-form kernels at H = 256)
+ *   key 7 also: 9 / 10 two nodes per wave (U = 4 / 2), 11-13 persistent contiguous chunks (measured negatives) */
 int gnnome_set_tuning(int key, int value);
 
 /* Measurement only: when set to a device buffer of 256 x 8 int64, every launch of the edge-tile kernel leaves, per
@@ -111,6 +114,12 @@ int gnnome_encode_f32(const float* in, int64_t rows, int in_features, const int3
  * any fp32 dot product - but the fp32 number produced is not the one a k-ordered fma chain produces (see
  * gnnome_linear_ref_f32 for that).  The exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32) stay selectable with
  * gnnome_set_tuning(2, 2).
+ * Round 4: where the output is whole 128-column blocks (K = 128 with Nout >= 256, K = 256) - the node projections - and in the forward modes of
+ * the edge gate at H = 128 / 256 the product runs as "fp16x3" on the f16 matrix cores (v_mfma_f32_32x32x16_f16): every fp32 operand as TWO fp16
+ * planes x1 = RN16(x), x2 = RN16((x - x1) * 2048) and three of the four plane products, the two small ones in a second fp32 accumulator that is
+ * folded in with 2^-11; dropped terms <= 3 * 2^-22 |a b| per product, measured no further from an fp64 product than an fp32 GEMM
+ * (tests/test_f16x3_model.py: 8e-8 of sum |a b| against 3.3e-7 at K = 256).  Operands must lie inside fp16's range, |x| < 65504: an element beyond it
+ * makes its output row NaN (never a wrong finite value).  gnnome_set_tuning(10, 1) keeps bf16x6 there too.
  *   K % 32 == 0; bias may be NULL; A and W 16-byte aligned with lda, ldw % 4 == 0
  */
 int gnnome_linear_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias,
