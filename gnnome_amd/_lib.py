@@ -69,6 +69,7 @@ SIGNATURES = {
     "gnnome_bn_bwd_dgrad_f32": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_bn_bwd_dgrad_out_f32": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_bn_bwd_dgrad_x16": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "gnnome_bn_bwd_dgrad_out_x16": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_agg_edge_bwd_stats_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_agg_edge_bwd_stats_x16": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_bn_bwd_terms_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p],

@@ -67,9 +67,9 @@ int gate_stream_launch(const float* e_in, float* e_out, int64_t E, const float* 
 int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, float* C, hipStream_t s);
 int stream_linear_acc_256(const float* A, int64_t M, const float* W, int ldw, float* C, hipStream_t s);   // edge_gate_stream.hip
 // H = 256 in the wave-specialised plane form (edge_gate_pl256.hip): modes 0 (gate), 1 (raw gate, optional statistics), 2 (C += A W^T)
-int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s);
+int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s, bool x16 = false);   // x16: mode 1 (xe out as bf16), mode 3 (xe in / dxe out as bf16)
 // the same tiles in fp16x3 arithmetic with LDS-DMA tile loads (edge_tile_f16.hip; modes 0, 1, 4): the default, gnnome_set_tuning(10, 1) = bf16x6
-int gate_f16_launch(int mode, const GateBfArgs& a, int grid, hipStream_t s);
+int gate_f16_launch(int mode, const GateBfArgs& a, int grid, hipStream_t s, bool x16 = false);
 int gate_pl256_stats_rows();
 void hub_cache_invalidate();        // node_aggregate.hip: forget the hub list of the previous graph (called when views are built)
 long long* gate_profile_buffer();   // gnnome_debug_gate_profile's buffer (edge_gate_bf.hip), NULL in normal use

@@ -685,7 +685,7 @@ static int raw_stats_impl(const float* e_in, void* x_out, int64_t num_edges, int
                "edge_gate_raw_stats: bad pointers");
     // x_out == NULL: the statistics alone (the first pass of the two-pass training forward; hidden = 128, the plane form)
     GN_REQUIRE(x_out || (hidden == 128 && tuning(kTuneGateVariant) == 0), "edge_gate_raw_stats: x_out may be NULL at hidden = 128 only (default kernels)");
-    GN_REQUIRE(hidden == 64 || hidden == 128 || (hidden == 256 && !x16), "edge_gate_raw_stats: hidden=%d not in {64,128,256 (fp32)}", hidden);
+    GN_REQUIRE(hidden == 64 || hidden == 128 || hidden == 256, "edge_gate_raw_stats: hidden=%d not in {64,128,256}", hidden);
     GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ldw >= hidden && ldw % 4 == 0, "edge_gate_raw_stats: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0) && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0),
                "edge_gate_raw_stats: 16-byte alignment required");
@@ -694,7 +694,7 @@ static int raw_stats_impl(const float* e_in, void* x_out, int64_t num_edges, int
         GateBfArgs a = {};
         a.e_in = e_in; a.e_out = (float*)x_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src;
         a.srt_dst = srt_dst; a.W3 = W3; a.ldw = ldw; a.scale = center; a.stats = stats_partial;
-        return gate_pl256_launch(1, a, s);
+        return gate_pl256_launch(1, a, s, x16);
     }
     if (tuning(kTuneGateVariant) == 0 || tuning(kTuneGateVariant) == 8 || x16) {
         GateBfArgs a = {};

@@ -1139,9 +1139,23 @@ extern "C" int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows
 
 // The same pass at hidden = 256, OUT OF PLACE: two workgroups (column halves) read whole rows of C while each writes its half, so the
 // updated rows go to C_out != C_in (edge_gate_pl256.hip, mode 3).
+static int bn_bwd_dgrad_out_impl(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
+                                 const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
+                                 const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream, bool x16);
 extern "C" int gnnome_bn_bwd_dgrad_out_f32(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
                                            const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
                                            const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream) {
+    return bn_bwd_dgrad_out_impl(C_in, C_out, X, rows, rows_once, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, false);
+}
+// X (the xe rows) and dxe as bf16 (round 4: bf16 activation storage at hidden = 256)
+extern "C" int gnnome_bn_bwd_dgrad_out_x16(const float* C_in, float* C_out, const uint16_t* X, int64_t rows, int64_t rows_once, int hidden,
+                                           const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
+                                           const float* mean, const float* rstd, const float* W, int ldw, uint16_t* dxe, void* stream) {
+    return bn_bwd_dgrad_out_impl(C_in, C_out, (const float*)X, rows, rows_once, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, (float*)dxe, stream, true);
+}
+static int bn_bwd_dgrad_out_impl(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
+                                 const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
+                                 const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream, bool x16) {
     using namespace gnnome;
     GN_REQUIRE(rows >= 0 && hidden == 256, "bn_bwd_dgrad_out: hidden=%d (256 only; 64 / 128 update C in place: gnnome_bn_bwd_dgrad_f32)", hidden);
     GN_REQUIRE(rows_once >= 0 && rows_once <= rows, "bn_bwd_dgrad_out: rows_once=%lld outside [0, rows]", (long long)rows_once);
@@ -1150,8 +1164,9 @@ extern "C" int gnnome_bn_bwd_dgrad_out_f32(const float* C_in, float* C_out, cons
                    ldw >= hidden && ldw % 4 == 0, "bn_bwd_dgrad_out: bad arguments");
     GN_REQUIRE(((uintptr_t)C_in % 16 == 0) && ((uintptr_t)C_out % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)dxe % 16 == 0) &&
                    ((uintptr_t)W % 16 == 0), "bn_bwd_dgrad_out: tensors must be 16-byte aligned");
+    (void)x16;
     GateBfArgs g = {};
     g.e_in = X; g.e_out = C_out; g.E = rows; g.B1h = C_in; g.ldn = hidden; g.W3 = W; g.ldw = ldw;
     g.bnb = GateBnBwd{a, c1, c2, mean, rstd, scale, shift, dxe, rows_once};
-    return gate_pl256_launch(3, g, (hipStream_t)stream);
+    return gate_pl256_launch(3, g, (hipStream_t)stream, x16);
 }

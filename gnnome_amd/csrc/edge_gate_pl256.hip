@@ -96,8 +96,10 @@ __device__ __forceinline__ bf16x8_t as_bf8(const uint4 v) { return __builtin_bit
 // MODE 3: MODE 2 with A = BatchNorm-backward(old C rows, xe rows at e_in) computed by the load waves and written to bnb.a_out
 // MODE 4: C[M, 128 * num_cblocks] = A[M,256] W^T + bias (a.e_in = A with row stride a.ldn, a.e_out = C with row stride a.ld_out, a.scale = bias):
 //         the node projection [N,256] -> [N,1280] and the scorer's node halves at this width
-template <int MODE, int PROBE = 0>   // PROBE (measurement only, wrong results): 1 = no MFMAs, 2 = no plane reads either
+// X16 (MODE 3, round 4): the xe rows are read and the dxe rows written as bf16 (the product C += dxe W^T uses the unrounded dxe - common.h)
+template <int MODE, int PROBE = 0, bool X16 = false>   // PROBE (measurement only, wrong results): 1 = no MFMAs, 2 = no plane reads either
 __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
+    static_assert(!X16 || MODE == 3, "bf16 storage in this kernel: mode 3 only");
     constexpr int H = 256, HC = 128, TM = 32, KS = H / 16, PLD = 2 * H + 16, PLANE = TM * PLD, SLOTB = 3 * PLANE, LDK = HC + 4, XT = TM * LDK;
     constexpr int NPF = 16, NPE = 8;   // pieces per lane: fetch mapping (whole rows), epilogue mapping (this workgroup's column half)
     __shared__ __attribute__((aligned(16))) unsigned char ring[2 * SLOTB];
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
 #pragma unroll
             for (int p = 0; p < NPF; ++p) {   // rows past the end of the list read the last valid row (never stored)
                 const int64_t row = row0 + min(16 * r0f + p, valid - 1);
-                av[p] = *reinterpret_cast<const f32x4*>(a.e_in + row * lda + 4 * c4f);
+                av[p] = load4_as<X16>(a.e_in, row * lda + 4 * c4f);
                 if (MODE == 3) dyv[p] = *reinterpret_cast<const f32x4*>(a.B1h + row * H + 4 * c4f);
             }
         };
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                 const f32x4 kh = *reinterpret_cast<const f32x4*>(norm_lds + 6 * H + 4 * c4f);
                 const int valid3 = tile_valid(r);
                 const int64_t once3 = a.bnb.n_once - (int64_t)tile_of(r) * TM;   // rows of this tile that get the mean terms
-                float* aout = a.bnb.a_out + (int64_t)tile_of(r) * TM * H + 4 * c4f;
+                const int64_t aoff = (int64_t)tile_of(r) * TM * H + 4 * c4f;
                 const bool mine = (c4f >> 5) == hh;
 #pragma unroll
                 for (int p = 0; p < NPF; ++p) {
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                         t[j] = ka[j] * (gm - on * (k1[j] + (av[p][j] - km[j]) * kr[j] * k2[j]));
                     }
                     av[p] = t;
-                    if (mine && row < valid3) *reinterpret_cast<f32x4*>(aout + (int64_t)row * H) = t;
+                    if (mine && row < valid3) store4_as<X16>(a.bnb.a_out, aoff + (int64_t)row * H, t);
                 }
             }
 #pragma unroll
@@ -446,7 +448,7 @@ int grid_pl256() {
     return g < 16 ? 16 : g;
 }
 
-template <int MODE, int PROBE = 0>
+template <int MODE, int PROBE = 0, bool X16 = false>
 int launch_pl256(const GateBfArgs& args, hipStream_t s) {
     GateBfArgs a = args;
     const int64_t tiles = (a.E + 31) / 32;
@@ -460,7 +462,7 @@ int launch_pl256(const GateBfArgs& args, hipStream_t s) {
     if (MODE == 1 && a.stats != nullptr) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * (size_t)grid_pl256() * 4 * 2 * 256, s));   // idle waves / the other half
     if (PROBE == 0 && (MODE == 0 || MODE == 1 || MODE == 4) && tuning(kTuneArith) == 0)   // the shipped default: fp16x3 + LDS-DMA (edge_tile_f16.hip)
         return gate_f16_launch(MODE, a, grid_pl256(), s);
-    hipLaunchKernelGGL((k_edge_gate_pl256<MODE, PROBE>), dim3(grid_pl256()), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((k_edge_gate_pl256<MODE, PROBE, X16>), dim3(grid_pl256()), dim3(512), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
@@ -471,7 +473,16 @@ int launch_pl256(const GateBfArgs& args, hipStream_t s) {
 // mode 2: C += A W^T (a.e_in = A, a.e_out = a.B1h = C); mode 3: C_out = C_in + BatchNormBackward(C_in, X) W^T with dxe written out
 // (a.e_in = X, a.B1h = C_in, a.e_out = C_out != C_in, a.bnb)
 int gate_pl256_stats_rows() { return grid_pl256() * 4; }
-int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s) {
+int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s, bool x16) {
+    if (x16) {   // bf16 storage of xe / dxe at H = 256 (round 4)
+        if (mode == 3) return launch_pl256<3, 0, true>(a, s);
+        GN_REQUIRE(mode == 1 && tuning(kTuneArith) == 0, "edge-tile kernel (H = 256): bf16 storage exists for modes 1 (fp16x3 kernel) and 3");
+        GateBfArgs b = a;
+        b.num_tiles = (int)((a.E + 31) / 32);
+        b.prof = gate_profile_buffer();
+        if (b.stats != nullptr) GN_HIP(hipMemsetAsync(b.stats, 0, sizeof(float) * (size_t)grid_pl256() * 4 * 2 * 256, s));
+        return gate_f16_launch(1, b, grid_pl256(), s, true);
+    }
     if (mode == 0 && tuning(kTuneGateAblation) == 8) return launch_pl256<0, 1>(a, s);   // measurement only: the kernel without its MFMAs
     if (mode == 0) return launch_pl256<0>(a, s);
     if (mode == 1) return launch_pl256<1>(a, s);

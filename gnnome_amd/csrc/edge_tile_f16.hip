@@ -108,8 +108,10 @@ __device__ __forceinline__ h8_t as_h8(const uint4 v) { return __builtin_bit_cast
 // MODE 4: C[M, 128 * num_cblocks] = A[M,256] W^T + bias (a.e_in = A with row stride a.ldn, a.e_out = C with row stride a.ld_out, a.scale = bias)
 // PROBE (measurement only, wrong results; gnnome_set_tuning(1, 100 + mask)): 1 no DMA inside the loop, 2 no plane conversion inside the loop,
 // 4 no MFMAs, 8 no gathers / residual loads, 16 no stores
-template <int MODE, int PROBE = 0>
+// X16 (MODE 1): xe stored as bf16 (rounded to nearest even; the statistics are those of the rounded values - common.h)
+template <int MODE, int PROBE = 0, bool X16 = false>
 __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
+    static_assert(!X16 || MODE == 1, "bf16 storage belongs to the raw gate");
     constexpr int H = 256, HC = 128, TM = 32, KS = H / 16, NS = 4;
     constexpr int RSB = 4 * H + 16, SLOTB = TM * RSB;   // a raw row in LDS: 1024 bytes + 16 (consecutive rows start 4 banks apart)
     constexpr int LDK = HC + 4, XT = TM * LDK;
@@ -346,6 +348,11 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
                     } else {
                         y = x[p] + (g1[S][p] + g2[S][p]);
                     }
+                    uint2 pk = {0u, 0u};
+                    if (X16) {
+                        pk = pack_bf16x4(y);
+                        y = unpack_bf16x4(pk);
+                    }
                     if (FULL || rl + p < valid) {
                         if (MODE == 1) {
                             const f32x4 dlt = y - sc4;
@@ -354,6 +361,8 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
                         }
                         if (PROBE & 16)
                             asm volatile("" ::"v"(y));
+                        else if (X16)
+                            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.e_out) + ((int64_t)tile_of(i) * TM + rl + p) * ldo + colh + 4 * c4) = pk;
                         else
                             *reinterpret_cast<f32x4*>(out + (int64_t)p * ldo) = y;
                     }
@@ -404,10 +413,10 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
     }
 }
 
-template <int MODE, int PROBE = 0>
+template <int MODE, int PROBE = 0, bool X16 = false>
 int launch_f16(const GateBfArgs& args, int grid, hipStream_t s) {
     GateBfArgs a = args;
-    hipLaunchKernelGGL((k_edge_tile_f16<MODE, PROBE>), dim3(grid), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((k_edge_tile_f16<MODE, PROBE, X16>), dim3(grid), dim3(512), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
@@ -415,7 +424,11 @@ int launch_f16(const GateBfArgs& args, int grid, hipStream_t s) {
 }  // namespace
 
 // called by gate_pl256_launch (edge_gate_pl256.hip) with the arguments checked and num_tiles / prof filled in
-int gate_f16_launch(int mode, const GateBfArgs& a, int grid, hipStream_t s) {
+int gate_f16_launch(int mode, const GateBfArgs& a, int grid, hipStream_t s, bool x16) {
+    if (x16) {
+        GN_REQUIRE(mode == 1, "edge-tile kernel (H = 256, fp16x3): bf16 storage exists for the raw gate (mode 1) only");
+        return launch_f16<1, 0, true>(a, grid, s);
+    }
     if (mode == 0 && tuning(kTuneGateAblation) >= 100) {   // measurement only (tools/gate_time.py --ablations 101,102,...)
         switch (tuning(kTuneGateAblation) - 100) {
             case 1: return launch_f16<0, 1>(a, grid, s);

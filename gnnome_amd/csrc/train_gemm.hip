@@ -179,7 +179,7 @@ constexpr int kW2Tile = 256, kW2Rows = 16;
 constexpr int kW2ColBytes = 2 * kW2Rows + 16;        // one column of one bf16 plane: 16 rows + 16 bytes of pad (48 B: conflict-free b128 reads)
 constexpr int kW2Plane = kW2Tile * kW2ColBytes;      // 12 KB; A and B, three planes each = 72 KB per buffer, two buffers
 
-template <int ABL = 0>   // ABL: measurement only (1 = no re-fetch, 2 = no MFMAs, 4 = no staging)
+template <int ABL = 0, bool X16 = false>   // ABL: measurement only (1 = no re-fetch, 2 = no MFMAs, 4 = no staging); X16: A stored as bf16 (round 4)
 __global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int lda, int Ka, const float* __restrict__ B, int ldb, int Kb,
                                                              int64_t R, int64_t rows_per_chunk, float* __restrict__ partial,
                                                              float* __restrict__ colsum_part, long long* prof) {
@@ -197,13 +197,14 @@ __global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int ld
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int c4 = tid & 63, rr = tid >> 6;   // 64 float4 per 256-wide row; rows 4 rr .. 4 rr + 3 of the slab
-    const float* a_col = a_op.blk[0];
+    const float* a_col = a_op.blk[0];   // (X16: the block pointers are bf16 rows; a_off counts elements either way)
+    int64_t a_off = 0;
     {
         const int ca = i0 + 4 * c4, which = ca / a_op.width;
 #pragma unroll
         for (int k = 1; k < kWgBlocks; ++k)
             if (which == k) a_col = a_op.blk[k];
-        a_col += ca - which * a_op.width;
+        a_off = ca - which * a_op.width;
     }
     const float* b_col = B + j0 + 4 * c4;
     const bool sums = colsum_part != nullptr && blockIdx.y == 0;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int ld
     const int rr_s = __builtin_amdgcn_readfirstlane(rr);
     auto fetch_row = [&](int64_t r0, int t, f32x4& a_dst, f32x4& b_dst) {
         const int64_t rc = min(r0 + 4 * rr_s + t, r_end - 1);
-        a_dst = *reinterpret_cast<const f32x4*>(a_col + rc * lda);
+        a_dst = load4_as<X16>(a_col, a_off + rc * lda);
         b_dst = *reinterpret_cast<const f32x4*>(b_col + rc * ldb);
     };
     auto fetch = [&](int64_t r0, f32x4 (&av)[4], f32x4 (&bv)[4]) {
@@ -632,7 +633,7 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
         return GNNOME_EWORKSPACE;
     }
     float* partial = (float*)workspace;
-    if (!x16 && wgrad256_chunks(rows, Ka, Kb, nullptr) > 0 && (a_op.width % kW2Tile == 0) && tuning(kTuneGateExperiment) != 78 &&
+    if (wgrad256_chunks(rows, Ka, Kb, nullptr) > 0 && (a_op.width % kW2Tile == 0) && tuning(kTuneGateExperiment) != 78 &&
         tuning(kTuneLinearVariant) == 0) {   // (key 4 = 78 or any non-default key 2: the 128 x 128 tile kernel, for A/B runs and cross-checks)
         // whole 256-column tiles over many rows: the 256 x 256 kernel, one workgroup per CU (fewer, longer chunks than the workspace was sized for)
         int64_t rp = 0;
@@ -643,21 +644,24 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
             return GNNOME_EWORKSPACE;
         }
         float* cpart = colsum ? partial + (size_t)ch * Ka * Kb : nullptr;
-#define GN_W256(ABLV)                                                                                                                        \
+#define GN_W256(ABLV) GN_W256X(ABLV, false)
+#define GN_W256X(ABLV, X16V)                                                                                                                 \
     {                                                                                                                                       \
         /* the attribute is per device and per function: one flag per device ordinal (set once, outside any stream capture's first use) */  \
         static std::atomic<bool> attr_set[64];                                                                                              \
         int dev_ = 0;                                                                                                                       \
         GN_HIP(hipGetDevice(&dev_));                                                                                                        \
         if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_].load(std::memory_order_acquire)) {                                                    \
-            GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad256_partial<ABLV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+            GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad256_partial<ABLV, X16V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        12 * kW2Plane));                                                                                     \
             if (dev_ >= 0 && dev_ < 64) attr_set[dev_].store(true, std::memory_order_release);                                              \
         }                                                                                                                                   \
-        hipLaunchKernelGGL(k_wgrad256_partial<ABLV>, dim3(Ka / kW2Tile, Kb / kW2Tile, (unsigned)ch), dim3(256), 12 * kW2Plane, s, a_op, lda, \
+        hipLaunchKernelGGL((k_wgrad256_partial<ABLV, X16V>), dim3(Ka / kW2Tile, Kb / kW2Tile, (unsigned)ch), dim3(256), 12 * kW2Plane, s, a_op, lda, \
                            Ka, B, ldb, Kb, rows, rp, partial, cpart, gate_profile_buffer());                                                \
     }
-        switch (tuning(kTuneGateAblation)) {
+        if (x16) {
+            GN_W256X(0, true);
+        } else switch (tuning(kTuneGateAblation)) {
             case 1: GN_W256(1); break;
             case 2: GN_W256(2); break;
             case 4: GN_W256(4); break;
@@ -665,6 +669,7 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
             default: GN_W256(0); break;
         }
 #undef GN_W256
+#undef GN_W256X
         GN_LAUNCH_CHECK();
         const int64_t elems2 = (int64_t)Ka * Kb;
         const int cb2 = (int)((elems2 + 63) / 64), sb2 = colsum ? (Ka + 63) / 64 : 0;

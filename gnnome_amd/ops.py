@@ -560,8 +560,8 @@ def _partial_sums(partial, H):
 
 
 def can_fuse_gate_moments(e, B1h, B2h, storage=torch.float32):
-    """H = 256 (round 3: the plane form's raw mode, edge_gate_pl256.hip) with fp32 storage only."""
-    widths = (64, 128, 256) if storage == torch.float32 else (64, 128)
+    """H in {64, 128, 256}; bf16 storage at 256 (round 4) runs on the fp16x3 kernel only (not under set_tuning(10, 1))."""
+    widths = (64, 128, 256) if storage == torch.float32 or _TUNING.get(10, 0) == 0 else (64, 128)
     return (e.shape[1] in widths and e.shape[0] > 0 and B1h.stride(0) % 4 == 0 and B1h.data_ptr() % 16 == 0 and
             B2h.data_ptr() % 16 == 0)
 
@@ -774,9 +774,8 @@ def agg_edge_bwd(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de):
 
 
 def can_fuse_bn_bwd_dgrad(de, W, xe=None):
-    """H = 256 (round 3, edge_gate_pl256.hip mode 3): fp32 storage only, and the update is out of place under the hood."""
-    widths = (64, 128, 256) if xe is None or xe.dtype == torch.float32 else (64, 128)
-    return de.shape[1] in widths and de.shape[0] > 0 and de.is_contiguous() and W.stride(0) % 4 == 0
+    """H = 256 (edge_gate_pl256.hip mode 3; bf16 storage since round 4): the update is out of place under the hood."""
+    return de.shape[1] in (64, 128, 256) and de.shape[0] > 0 and de.is_contiguous() and W.stride(0) % 4 == 0
 
 
 def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None):
@@ -790,10 +789,8 @@ def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None
     if de.shape[1] == 256:
         # two workgroups per row at this width: the kernel writes the updated rows to a fresh buffer, which then BECOMES de
         # (Tensor.set_: same tensor object, new storage - the caller's `de` is updated "in place" as at the other widths)
-        if x16:
-            raise TypeError("bn_bwd_dgrad: bf16 activation storage is not built at hidden = 256")
         out = torch.empty_like(de)
-        _call("gnnome_bn_bwd_dgrad_out_f32", de.device, _ptr(de), _ptr(out), _ptr(xe), de.shape[0], once, 256, _ptr(scale), _ptr(shift), _ptr(a),
+        _call("gnnome_bn_bwd_dgrad_out_x16" if x16 else "gnnome_bn_bwd_dgrad_out_f32", de.device, _ptr(de), _ptr(out), _ptr(xe), de.shape[0], once, 256, _ptr(scale), _ptr(shift), _ptr(a),
               _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))
         if de._base is not None or de.storage_offset() != 0:   # a view of somebody else's storage: set_ would leave that storage unchanged
             de.copy_(out)

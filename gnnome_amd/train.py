@@ -186,7 +186,7 @@ def _raw_gate(sh, conv, e, B1h, B2h, layer_norm, storage, path=None):
 
 
 def _no_bf16_storage():
-    return ValueError('activation_storage="bf16" is built for the fused single-rank BatchNorm step at hidden_features 64 / 128 '
+    return ValueError('activation_storage="bf16" is built for the fused single-rank BatchNorm step at hidden_features 64 / 128 / 256 '
                       "(normalization='batch', momentum set, one process); use \"fp32\" here")
 
 

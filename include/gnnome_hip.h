@@ -527,6 +527,11 @@ int gnnome_agg_edge_bwd_stats_x16(const float* e, int64_t num_edges, int hidden,
 int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift, const float* a,
                             const float* c1, const float* c2, const float* mean, const float* rstd, const float* W, int ldw,
                             uint16_t* dxe, void* stream);
+/* hidden = 256 (round 4): the out-of-place form, gnnome_bn_bwd_dgrad_out_f32 with X and dxe as bf16; gnnome_edge_gate_raw_stats_x16 and
+ * gnnome_wgrad_x16 take hidden / Ka = 256 as well (the raw gate on the fp16x3 kernel: not under gnnome_set_tuning(10, 1)). */
+int gnnome_bn_bwd_dgrad_out_x16(const float* C_in, float* C_out, const uint16_t* X, int64_t rows, int64_t rows_once, int hidden,
+                                const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
+                                const float* mean, const float* rstd, const float* W, int ldw, uint16_t* dxe, void* stream);
 int gnnome_segment_sum2_x16(const uint16_t* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
                             int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream);
 int gnnome_wgrad_x16(const uint16_t* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C, int ldc,
