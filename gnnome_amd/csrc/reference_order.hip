@@ -188,12 +188,12 @@ extern "C" int gnnome_linear_ref_f32(const float* A, int64_t M, int K, int lda, 
     GN_REQUIRE(blocks < (1ll << 31), "linear_ref: too many rows");
     hipStream_t s = (hipStream_t)stream;
     // the shipped default: the same chain on the fp32 matrix cores (reference_order_mfma.hip); variant 1 = the VALU form below
-    if (tuning(kTuneRefVariant) == 0 && (K == 64 || K == 128) && ((uintptr_t)W % 4 == 0))
+    if ((tuning(kTuneRefVariant) == 0 || K == 256) && (K == 64 || K == 128 || K == 256) && ((uintptr_t)W % 4 == 0))   // (K = 256: the matrix-core form only, round 4)
         return linear_refm_launch(A, M, K, lda, W, ldw, bias, Nout, C, ldc, s);
     switch (K) {
         case 64: hipLaunchKernelGGL(k_linear_ref<64>, dim3((unsigned)blocks), dim3(kRefThreads), 0, s, A, M, lda, W, ldw, bias, Nout, C, ldc); break;
         case 128: hipLaunchKernelGGL(k_linear_ref<128>, dim3((unsigned)blocks), dim3(kRefThreads), 0, s, A, M, lda, W, ldw, bias, Nout, C, ldc); break;
-        default: set_error("linear_ref: K=%d not in {64,128}", K); return GNNOME_EINVAL;
+        default: set_error("linear_ref: K=%d not in {64,128,256}", K); return GNNOME_EINVAL;
     }
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
@@ -215,7 +215,7 @@ extern "C" int gnnome_edge_gate_ref_f32(const float* e_in, float* e_out, int64_t
                "edge_gate_ref: tensors must be 16-byte aligned");
     GateEnc ge{e_raw, srt_eid, encW1, encb1, encW2, encb2};
     hipStream_t s = (hipStream_t)stream;
-    if (tuning(kTuneRefVariant) == 0 && (hidden == 64 || hidden == 128))   // the shipped default: the chain on the fp32 matrix cores
+    if ((tuning(kTuneRefVariant) == 0 && (hidden == 64 || hidden == 128)) || hidden == 256)   // the shipped default: the chain on the fp32 matrix cores (the only form at 256)
         return gate_refm_launch(hidden, enc, e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, b3, norm_scale, norm_shift, ge, s);
     if (hidden == 64) {
         return enc ? launch_gate_ref<64, true>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, b3, norm_scale, norm_shift, ge, s)
@@ -225,6 +225,6 @@ extern "C" int gnnome_edge_gate_ref_f32(const float* e_in, float* e_out, int64_t
         return enc ? launch_gate_ref<128, true>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, b3, norm_scale, norm_shift, ge, s)
                    : launch_gate_ref<128, false>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, b3, norm_scale, norm_shift, ge, s);
     }
-    set_error("edge_gate_ref: hidden=%d not in {64,128}", hidden);
+    set_error("edge_gate_ref: hidden=%d not in {64,128,256}", hidden);
     return GNNOME_EINVAL;
 }

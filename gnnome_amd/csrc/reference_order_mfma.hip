@@ -62,14 +62,15 @@ __device__ __forceinline__ void chain_tile(const float* __restrict__ tile_row, i
 }
 
 // C[M,Nout] = chain(A W^T) + bias.  grid = (row groups of 4 x 32 rows, Nout / 64 column groups); every wave: 32 rows x 64 columns.
-template <int K>
+// K = 256 (round 4): NCB = 1 - a wave holds ONE 32-column block of W (K/2 = 128 registers), the grid has Nout / 32 column groups.
+template <int K, int NCB = (K == 256 ? 1 : 2)>
 __global__ __launch_bounds__(kRmThreads) void k_linear_refm(const float* __restrict__ A, int64_t M, int lda, const float* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, int Nout, float* __restrict__ C, int ldc,
                                                             int row_groups) {
-    constexpr int LD = RmTile<K>::LD, NCB = 2;
+    constexpr int LD = RmTile<K>::LD;
     __shared__ __attribute__((aligned(16))) float tiles[4 * 32 * LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cl = lane & 31, kk = lane >> 5;
-    const int col0 = blockIdx.y * 64;
+    const int col0 = blockIdx.y * 32 * NCB;
     const bool w_rows16 = ldw % 4 == 0 && ((uintptr_t)W % 16 == 0);   // (uniform) 16-byte pieces of the weight rows
     float w[NCB][K / 2];
     float bcol[NCB];
@@ -119,17 +120,18 @@ __global__ __launch_bounds__(kRmThreads) void k_linear_refm(const float* __restr
 // operand = the residual: the e rows, or with ENC the encoder's output) and X (the chain's result), so that the epilogue runs
 // ROW-major - 16-byte pieces of B1h[src] / B2h[dst] / e', sixteen lanes to a 256-byte row segment - instead of 4-byte gathers
 // in the accumulator layout.
+// H = 256 (round 4): NCB = 1, eight waves (512 threads) to a row group, one row group per workgroup iteration.
 template <int H, bool ENC>
-__global__ __launch_bounds__(kRmThreads) void k_edge_gate_refm(const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h,
+__global__ __launch_bounds__((H == 256 ? 512 : kRmThreads)) void k_edge_gate_refm(const float* e_in, float* e_out, int64_t E, const float* __restrict__ B1h,
                                                                const float* __restrict__ B2h, int ldn, const int32_t* __restrict__ srt_src,
                                                                const int32_t* __restrict__ srt_dst, const float* __restrict__ W3, int ldw,
                                                                const float* __restrict__ b3, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, GateEnc enc, int iterations) {
-    constexpr int LD = RmTile<H>::LD, NCB = 2, WPR = H / 64, RG = 4 / WPR;
+    constexpr int LD = RmTile<H>::LD, NCB = H == 256 ? 1 : 2, CW = 32 * NCB, WPR = H / CW, NW = H == 256 ? 8 : 4, RG = NW / WPR;
     __shared__ __attribute__((aligned(16))) float tiles[RG * 2 * 32 * LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cl = lane & 31, kk = lane >> 5;
-    const int rg = wave / WPR, wsub = wave % WPR;      // row group inside the workgroup, column half inside the row group
-    const int col0 = 64 * wsub;
+    const int rg = wave / WPR, wsub = wave % WPR;      // row group inside the workgroup, column block inside the row group
+    const int col0 = CW * wsub;
     const bool w_rows16 = ldw % 4 == 0 && ((uintptr_t)W3 % 16 == 0);
     float w[NCB][H / 2];
 #pragma unroll
@@ -157,8 +159,9 @@ __global__ __launch_bounds__(kRmThreads) void k_edge_gate_refm(const float* e_in
             b2c[cb] = enc.b2[col];
         }
     }
-    // epilogue mapping: lane -> row er + 4 it (it < 8), columns col0 + ec .. + 3
-    const int er = lane >> 4, ec = 4 * (lane & 15);
+    // epilogue mapping: lane -> row er + RPP it (it < NIT), columns col0 + ec .. + 3 (CW / 4 lanes to a row segment of the wave's columns)
+    constexpr int LPS = CW / 4, RPP = 64 / LPS, NIT = 32 / RPP;
+    const int er = lane / LPS, ec = 4 * (lane % LPS);
     const f32x4 b3v = *reinterpret_cast<const f32x4*>(b3 + col0 + ec), alv = *reinterpret_cast<const f32x4*>(scale + col0 + ec),
                 bev = *reinterpret_cast<const f32x4*>(shift + col0 + ec);
     float* tileE = tiles + rg * 2 * 32 * LD;
@@ -201,10 +204,10 @@ __global__ __launch_bounds__(kRmThreads) void k_edge_gate_refm(const float* e_in
         __syncthreads();   // the E tile is complete (and, in place, every global read of these rows has happened)
         if (live) {
             // the gathers of this tile go out before the chain; they are consumed after it
-            f32x4 g1[8], g2[8];
+            f32x4 g1[NIT], g2[NIT];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int tr = er + 4 * i;
+            for (int i = 0; i < NIT; ++i) {
+                const int tr = er + RPP * i;
                 const int64_t so = (int64_t)__shfl(si_mine, tr) * ldn + col0 + ec, dof = (int64_t)__shfl(di_mine, tr) * ldn + col0 + ec;
                 g1[i] = *reinterpret_cast<const f32x4*>(B1h + so);
                 g2[i] = *reinterpret_cast<const f32x4*>(B2h + dof);
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(kRmThreads) void k_edge_gate_refm(const float* e_in
                 for (int r = 0; r < 16; ++r) tileX[acc_row(r, kk) * LD + col0 + 32 * cb + cl] = acc[cb][r];
             __builtin_amdgcn_wave_barrier();   // the wave's own 64 columns of X: LDS keeps a wave's accesses in order
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int tr = er + 4 * i;
+            for (int i = 0; i < NIT; ++i) {
+                const int tr = er + RPP * i;
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(tileX + tr * LD + col0 + ec);
                 const f32x4 ev = *reinterpret_cast<const f32x4*>(tileE + tr * LD + col0 + ec);
                 f32x4 y;
@@ -241,11 +244,13 @@ int linear_refm_launch(const float* A, int64_t M, int K, int lda, const float* W
                        hipStream_t s) {
     const int64_t row_groups = (M + 127) / 128;
     GN_REQUIRE(row_groups < (1ll << 31), "linear_ref: too many rows");
-    const int col_groups = (Nout + 63) / 64;
+    const int col_groups = K == 256 ? (Nout + 31) / 32 : (Nout + 63) / 64;
     // a few row groups per workgroup amortise the weight load (K/2 x 2 registers per lane from L2)
     const int gx = (int)std::min<int64_t>(row_groups, std::max<int64_t>(1, (int64_t)persistent_grid() * 8 / col_groups));
     if (K == 64)
         hipLaunchKernelGGL(k_linear_refm<64>, dim3(gx, col_groups), dim3(kRmThreads), 0, s, A, M, lda, W, ldw, bias, Nout, C, ldc, (int)row_groups);
+    else if (K == 256)
+        hipLaunchKernelGGL(k_linear_refm<256>, dim3(gx, col_groups), dim3(kRmThreads), 0, s, A, M, lda, W, ldw, bias, Nout, C, ldc, (int)row_groups);
     else
         hipLaunchKernelGGL(k_linear_refm<128>, dim3(gx, col_groups), dim3(kRmThreads), 0, s, A, M, lda, W, ldw, bias, Nout, C, ldc, (int)row_groups);
     GN_LAUNCH_CHECK();
@@ -256,12 +261,12 @@ template <int H, bool ENC>
 static int launch_gate_refm(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn, const int32_t* ss,
                             const int32_t* sd, const float* W3, int ldw, const float* b3, const float* scale, const float* shift,
                             const GateEnc& enc, hipStream_t s) {
-    constexpr int RG = 4 / (H / 64);
+    constexpr int RG = H == 256 ? 1 : 4 / (H / 64), NT = H == 256 ? 512 : kRmThreads;
     const int64_t groups = (E + 32 * RG - 1) / (32 * RG);   // workgroup iterations in total
     GN_REQUIRE(groups < (1ll << 31), "edge_gate_ref: too many edges");
     const int grid = (int)std::min<int64_t>(groups, (int64_t)persistent_grid() * 4);
     const int iterations = (int)((groups + grid - 1) / grid);
-    hipLaunchKernelGGL((k_edge_gate_refm<H, ENC>), dim3(grid), dim3(kRmThreads), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, b3, scale,
+    hipLaunchKernelGGL((k_edge_gate_refm<H, ENC>), dim3(grid), dim3(NT), 0, s, e_in, e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, b3, scale,
                        shift, enc, iterations);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
@@ -273,6 +278,9 @@ int gate_refm_launch(int hidden, bool with_enc, const float* e_in, float* e_out,
     if (hidden == 64)
         return with_enc ? launch_gate_refm<64, true>(e_in, e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, b3, scale, shift, enc, s)
                         : launch_gate_refm<64, false>(e_in, e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, b3, scale, shift, enc, s);
+    if (hidden == 256)
+        return with_enc ? launch_gate_refm<256, true>(e_in, e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, b3, scale, shift, enc, s)
+                        : launch_gate_refm<256, false>(e_in, e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, b3, scale, shift, enc, s);
     return with_enc ? launch_gate_refm<128, true>(e_in, e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, b3, scale, shift, enc, s)
                     : launch_gate_refm<128, false>(e_in, e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, b3, scale, shift, enc, s);
 }

@@ -32,7 +32,7 @@ class LayerWeights:
 # with a large gain gamma / sqrt(running_var + eps) magnifies that difference.  The shipped checkpoint's layer 0 has a gain
 # of 135 and dominates the distance between any two fp32 evaluations of the model (1.2e-4 in edge probability on an
 # E. coli-sized graph); every other layer stays below 3.  "auto" sends a layer through the reference-order kernels when
-# its bn_e gain exceeds this threshold, "reference" all layers (H in {64,128}), "fast" none.
+# its bn_e gain exceeds this threshold, "reference" all layers (H in {64,128,256}), "fast" none.
 REFERENCE_ORDER_GAIN = 16.0
 ARITHMETIC_MODES = ("auto", "reference", "fast")
 

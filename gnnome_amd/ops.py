@@ -238,7 +238,7 @@ def edge_gate_encode(e_raw, enc, B1h, B2h, views, W3, scale, shift):
 
 def linear_ref(A, W, bias, out=None):
     """out[M,Nout] = A @ W.T + bias in the REFERENCE'S ORDER of evaluation (k-ascending fma chain from zero, bias added
-    afterwards: what torch's CPU nn.Linear computes, bit for bit).  K in {64,128}, Nout % 8 == 0."""
+    afterwards: what torch's CPU nn.Linear computes, bit for bit).  K in {64,128,256}, Nout % 8 == 0 (K = 256: Nout % 32 == 0)."""
     lib = _lib.load()
     A, lda = _rows(A, "linear_ref.A")
     W, ldw = _rows(W, "linear_ref.W")
@@ -255,7 +255,7 @@ def linear_ref(A, W, bias, out=None):
 
 def reference_order_supported(hidden, norm_kind, B1h=None):
     """Shapes the reference-order kernels take (gnnome_linear_ref_f32 / gnnome_edge_gate_ref_f32)."""
-    return hidden in (64, 128) and norm_kind == NORM_AFFINE
+    return hidden in (64, 128, 256) and norm_kind == NORM_AFFINE   # 256: round 4 (the matrix-core form, reference_order_mfma.hip)
 
 
 def edge_gate_ref(e, B1h, B2h, views, W3, b3, scale, shift, raw_edges=None, num_edges=None):

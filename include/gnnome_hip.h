@@ -160,7 +160,8 @@ int gnnome_edge_gate_encode_f32(const float* e_raw, const int32_t* srt_eid, cons
  * reproduce that sequence operation for operation, so their results equal the reference's CPU results BIT FOR BIT on
  * equal inputs (tests/test_reference_order.py) - which matters for layers whose normalisation magnifies reorder noise
  * (weights/weights.pt layer 0: bn_e gain up to 135).  One row per lane, weights through scalar
- * loads, fp32 VALU.  K / hidden in {64,128}.
+ * loads, fp32 VALU; by default the same chain on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 evaluates its two k in order).
+ * K / hidden in {64,128}; 256 on the matrix-core form only (round 4; Nout % 32 == 0 there).
  *
  * gnnome_linear_ref_f32: C[M,Nout] = chain(A W^T) + bias;  Nout % 8 == 0  (gated_gcn_full.py:91-96)
  * gnnome_edge_gate_ref_f32 (gated_gcn_full.py:97,104-110; B_3's bias is NOT folded into B2h here):

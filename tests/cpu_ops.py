@@ -80,7 +80,7 @@ def linear_ref(A, W, bias, out=None):
 
 
 def reference_order_supported(hidden, norm_kind, B1h=None):
-    return hidden in (64, 128) and norm_kind == NORM_AFFINE
+    return hidden in (64, 128, 256) and norm_kind == NORM_AFFINE
 
 
 def _fma(a, b, c):

@@ -138,7 +138,7 @@ def dev():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m,k,nout", [(1000, 64, 320), (30_001, 64, 320), (777, 128, 640), (5, 64, 8), (4097, 128, 128)])
+@pytest.mark.parametrize("m,k,nout", [(1000, 64, 320), (30_001, 64, 320), (777, 128, 640), (5, 64, 8), (4097, 128, 128), (2049, 256, 1280), (33, 256, 128)])
 def test_linear_ref_equals_torch_cpu_bit_for_bit(m, k, nout):
     from gnnome_amd import ops
     g = torch.Generator().manual_seed(m + k)
@@ -146,8 +146,11 @@ def test_linear_ref_equals_torch_cpu_bit_for_bit(m, k, nout):
     want = _chain(A, W, b)
     assert _same_bits(ops.linear_ref(A.to(dev()), W.to(dev()), b.to(dev())), want)
     assert _same_bits(ops.linear_ref(A.to(dev()), W.to(dev()), None), _chain(A, W))
-    if m >= 64:   # and that IS what torch's CPU nn.Linear returns (MKL's full row panels; see the module docstring)
+    if m >= 64 and k <= 128:   # and that IS what torch's CPU nn.Linear returns (MKL's full row panels; see the module docstring)
         assert (F.linear(A, W, b) != want).float().mean().item() < 0.02
+    # (K = 256, round 4: whether MKL keeps the 256 products of an output in ONE chain depends on the host - the build container's Intel
+    #  host does, bit for bit; the GPU pool's EPYC hosts split k into panels and 88 % of the outputs differ from the chain.  At this width
+    #  "the reference's fp32 result" is host-dependent; the kernels implement the single chain, which is also what K <= 128 gives everywhere.)
     # strided output block and strided weight rows (the [N,5H] projection, column blocks of predictor.W1)
     P = torch.zeros(m, nout + 64, device=dev())
     ops.linear_ref(A.to(dev()), W.to(dev()), b.to(dev()), out=P[:, 64:])
@@ -178,7 +181,7 @@ def test_encoder_equals_torch_cpu_bit_for_bit(hidden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hidden,n,e", [(64, 500, 7001), (128, 300, 2500), (64, 10, 3)])
+@pytest.mark.parametrize("hidden,n,e", [(64, 500, 7001), (128, 300, 2500), (64, 10, 3), (256, 300, 2501)])   # 256: round 4
 def test_edge_gate_ref_equals_the_reference_sequence(hidden, n, e):
     from gnnome_amd import ops
     g = torch.Generator().manual_seed(hidden + e)
@@ -268,6 +271,44 @@ def test_ecoli_sized_graph_shipped_weights(shipped_weights, kind):
     # the distance to the truth is the model's own fp32 noise, whichever fp32 evaluation is taken
     assert res["auto_vs_fp64"] < 3 * max(res["oracle32_vs_fp64"], 5e-5), res
     assert res["fast_vs_fp64"] < 3 * max(res["oracle32_vs_fp64"], 5e-5), res
+
+
+@pytest.mark.gpu
+def test_high_gain_layer_at_hidden_256():
+    """VERDICT r3 missing item 5 / next-round item 8: no H = 256 checkpoint exists, so a synthetic one stands in - random-init weights whose
+    layer-0 bn_e has channels with running_var ~ 5e-5, i.e. a gain gamma / sqrt(var + eps) of ~130 like the shipped H = 64 checkpoint's.
+    "auto" must send that layer (and only that one) through the reference-order kernels and land on the REFERENCE's fp32 result (the torch-CPU
+    oracle) far inside the 1e-4 bar; "reference" likewise; and every mode stays within the model's own fp32 noise of the fp64 truth."""
+    from gnnome_amd.synth import random_state_dict
+    from gnnome_amd import engine
+    hidden, n, e = 256, 6000, 60_000
+    sd = random_state_dict(hidden, seed=4)
+    g = torch.Generator().manual_seed(9)
+    rv = sd["gnn.convs.0.bn_e.running_var"].clone()
+    hot = torch.randperm(hidden, generator=g)[:24]
+    rv[hot] = 5e-5 * (0.5 + torch.rand(24, generator=g))
+    sd["gnn.convs.0.bn_e.running_var"] = rv
+    sd["gnn.convs.0.bn_e.weight"] = sd["gnn.convs.0.bn_e.weight"].abs() + 0.5
+    gr = make_graph(n, e, seed=2, kind="banded")
+    x = degree_features(gr["src"], gr["dst"], n)
+    graph = (gr["src"], gr["dst"], n)
+    with torch.no_grad():
+        ref32 = model_from_state_dict(sd).eval()(graph, x, gr["e"])
+        ref64 = model_from_state_dict(sd, dtype=torch.float64).eval()(graph, x.double(), gr["e"].double()).float()
+    m = gnnome_amd.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch").eval()
+    m.load_state_dict(sd)
+    m.to(dev())
+    res = {"oracle32_vs_fp64": _dprob(ref32, ref64)}
+    for mode in ("auto", "reference", "fast"):
+        m.arithmetic = mode
+        out = m(graph, x.to(dev()), gr["e"].to(dev()))
+        res[mode + "_vs_oracle32"] = _dprob(out, ref32)
+        res[mode + "_vs_fp64"] = _dprob(out, ref64)
+        if mode == "auto":   # layer 0, and only layer 0, runs in the reference's order
+            assert [lw.ref for lw in engine.Prepared(m, dev()).layers] == [True] + [False] * 7
+    _record("high_gain_layer_h256", nodes=n, edges=e, **res)
+    assert res["auto_vs_oracle32"] < AUTO_TOL and res["reference_vs_oracle32"] < AUTO_TOL, res
+    assert all(res[k + "_vs_fp64"] < 3 * max(res["oracle32_vs_fp64"], 5e-5) for k in ("auto", "reference", "fast")), res
 
 
 @pytest.mark.gpu
