@@ -125,14 +125,37 @@ __device__ __forceinline__ void score_split8(const f32x4 lo4, const f32x4 hi4, u
     p3 = make_uint4(l3.x, l3.y, h3.x, h3.y);
 }
 
-template <int K>
+// fp16x3 (round 4; see edge_tile_f16.hip's header): two fp16 planes per operand, three f16 MFMAs per k step, the two small products in a second
+// accumulator folded in with 2^-11.  F16 = true also runs the 64 -> 32 product on the f16 matrix cores (it was 32 exact-fp32 MFMAs = 2048 matrix-pipe
+// cycles per 32-edge tile, now 12 f16 MFMAs = 384) and lets W1e fit LDS at K = 256 (two planes: 68 KB), so that width streams too.
+typedef _Float16 sc_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sc_h8 __attribute__((ext_vector_type(8)));
+typedef float sc_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void score_split8h(const f32x4 lo, const f32x4 hi, uint4& p1, uint4& p2) {
+    unsigned a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const sc_f2 v = j < 2 ? sc_f2{lo[2 * j], lo[2 * j + 1]} : sc_f2{hi[2 * j - 4], hi[2 * j - 3]};
+        const sc_h2 x1 = __builtin_convertvector(v, sc_h2);
+        const sc_f2 big = v * 2048.f;
+        const sc_f2 r = {__builtin_fmaf((float)x1[0], -2048.f, big[0]), __builtin_fmaf((float)x1[1], -2048.f, big[1])};   // exact
+        const sc_h2 x2 = __builtin_convertvector(r, sc_h2);
+        a[j] = __builtin_bit_cast(unsigned, x1);
+        b[j] = __builtin_bit_cast(unsigned, x2);
+    }
+    p1 = make_uint4(a[0], a[1], a[2], a[3]);
+    p2 = make_uint4(b[0], b[1], b[2], b[3]);
+}
+
+template <int K, bool F16 = false>
 __global__ __launch_bounds__(512) void k_edge_score_ws(
     const float* __restrict__ e, int64_t E, const float* __restrict__ Ps, const float* __restrict__ Qd, int ldn,
     const int32_t* __restrict__ srt_src, const int32_t* __restrict__ srt_dst, const int32_t* __restrict__ srt_eid,
     const float* __restrict__ W1e, int ldw1, const float* __restrict__ W2, const float* __restrict__ b2,
     const float* __restrict__ W3, const float* __restrict__ b3, float* __restrict__ logits, int num_tiles, int tiles_per_group) {
     constexpr int NW = 8, HS = 64, PLD = 2 * K + 16, PB = HS * PLD, KS = K / 16, LDZ = HS + 4, BATCH = 2;
-    __shared__ __attribute__((aligned(16))) unsigned char Wp[3 * PB];
+    static_assert(F16 || K <= 128, "three bf16 planes of W1e fit LDS up to K = 128");
+    __shared__ __attribute__((aligned(16))) unsigned char Wp[(F16 ? 2 : 3) * PB];
     __shared__ __attribute__((aligned(16))) float W2s[32 * LDZ];
     __shared__ __attribute__((aligned(16))) float Zall[NW * 32 * LDZ];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,15 +165,29 @@ __global__ __launch_bounds__(512) void k_edge_score_ws(
         const int row = f / (K / 8), c8 = f % (K / 8);
         const float* src = W1e + (int64_t)row * ldw1 + 8 * c8;
         uint4 p1, p2, p3;
-        score_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), p1, p2, p3);
         unsigned char* dst = Wp + row * PLD + 16 * c8;
+        if (F16) {
+            score_split8h(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), p1, p2);
+        } else {
+            score_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), p1, p2, p3);
+            *reinterpret_cast<uint4*>(dst + 2 * PB) = p3;
+        }
         *reinterpret_cast<uint4*>(dst) = p1;
         *reinterpret_cast<uint4*>(dst + PB) = p2;
-        *reinterpret_cast<uint4*>(dst + 2 * PB) = p3;
     }
     for (int i = tid; i < 32 * HS; i += 64 * NW) W2s[(i / HS) * LDZ + (i % HS)] = W2[i];
     const float bias2 = b2[cl], w3 = W3[cl], bias3 = b3[0];
     __syncthreads();   // the only barrier
+    // F16: this lane's B fragments of W2 (output column cl, k = 16 q + 8 half .. + 7) as two fp16 planes, for the whole launch
+    uint4 w2a[HS / 16], w2b[HS / 16];
+    if (F16) {
+#pragma unroll
+        for (int q = 0; q < HS / 16; ++q) {
+            const float* wr = W2s + cl * LDZ + 16 * q + 8 * half;
+            score_split8h(*reinterpret_cast<const f32x4*>(wr), *reinterpret_cast<const f32x4*>(wr + 4), w2a[q], w2b[q]);
+        }
+    }
+    auto h8 = [](const uint4 v) { return __builtin_bit_cast(sc_h8, v); };
 
     auto bf = [](const uint4 v) { return __builtin_bit_cast(tile_bf16x8, v); };
     float* Zs = Zall + wave * 32 * LDZ;
@@ -170,9 +207,9 @@ __global__ __launch_bounds__(512) void k_edge_score_ws(
         }
         // e rows -> fragments (8 consecutive k of one row per lane and K = 16 step), BATCH steps in flight ahead of the MFMAs
         const float* ap = e + (row0 + min(cl, valid - 1)) * K + 8 * half;
-        f32x16 acc0, acc1;
+        f32x16 acc0, acc1, acc0c, acc1c;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc0c[r] = acc1c[r] = 0.f;
         f32x4 x[BATCH][2];
 #pragma unroll
         for (int q = 0; q < BATCH; ++q) {
@@ -192,8 +229,20 @@ __global__ __launch_bounds__(512) void k_edge_score_ws(
 #pragma unroll
             for (int q = 0; q < BATCH; ++q) {
                 uint4 a1, a2, a3;
-                score_split8(x[q][0], x[q][1], a1, a2, a3);
                 const unsigned char* w = wp + 32 * (hq + q);
+                if (F16) {
+                    score_split8h(x[q][0], x[q][1], a1, a2);
+                    const uint4 u1 = *reinterpret_cast<const uint4*>(w), u2 = *reinterpret_cast<const uint4*>(w + PB);
+                    const uint4 v1 = *reinterpret_cast<const uint4*>(w + 32 * PLD), v2 = *reinterpret_cast<const uint4*>(w + 32 * PLD + PB);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a1), h8(u1), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a1), h8(v1), acc1, 0, 0, 0);
+                    acc0c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a1), h8(u2), acc0c, 0, 0, 0);
+                    acc1c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a1), h8(v2), acc1c, 0, 0, 0);
+                    acc0c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a2), h8(u1), acc0c, 0, 0, 0);
+                    acc1c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a2), h8(v1), acc1c, 0, 0, 0);
+                    continue;
+                }
+                score_split8(x[q][0], x[q][1], a1, a2, a3);
                 const uint4 u1 = *reinterpret_cast<const uint4*>(w), u2 = *reinterpret_cast<const uint4*>(w + PB),
                             u3 = *reinterpret_cast<const uint4*>(w + 2 * PB);
                 const uint4 v1 = *reinterpret_cast<const uint4*>(w + 32 * PLD), v2 = *reinterpret_cast<const uint4*>(w + 32 * PLD + PB),
@@ -224,6 +273,13 @@ __global__ __launch_bounds__(512) void k_edge_score_ws(
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             g[i] = *reinterpret_cast<const f32x4*>(Ps + (int64_t)si[i] * ldn + 4 * gc4) + *reinterpret_cast<const f32x4*>(Qd + (int64_t)di[i] * ldn + 4 * gc4);
+        if (F16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0[r] += acc0c[r] * (1.0f / 2048.f);
+                acc1[r] += acc1c[r] * (1.0f / 2048.f);
+            }
+        }
         // e W1e^T -> the wave's LDS tile (accumulator layout), then relu(. + G) row-wise in place
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -243,14 +299,31 @@ __global__ __launch_bounds__(512) void k_edge_score_ws(
         f32x16 acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = bias2;
-        const float* zp = Zs + cl * LDZ + 4 * half;
-        const float* w2p = W2s + cl * LDZ + 4 * half;
+        if (F16) {
+            f32x16 acc2c;
 #pragma unroll
-        for (int q = 0; q < HS / 8; ++q) {
-            const f32x4 za = *reinterpret_cast<const f32x4*>(zp + 8 * q);
-            const f32x4 wb = *reinterpret_cast<const f32x4*>(w2p + 8 * q);
+            for (int r = 0; r < 16; ++r) acc2c[r] = 0.f;
+            const float* zq = Zs + cl * LDZ + 8 * half;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(za[k], wb[k], acc2, 0, 0, 0);
+            for (int q = 0; q < HS / 16; ++q) {
+                uint4 z1, z2;
+                score_split8h(*reinterpret_cast<const f32x4*>(zq + 16 * q), *reinterpret_cast<const f32x4*>(zq + 16 * q + 4), z1, z2);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(z1), h8(w2a[q]), acc2, 0, 0, 0);
+                acc2c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(z1), h8(w2b[q]), acc2c, 0, 0, 0);
+                acc2c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(z2), h8(w2a[q]), acc2c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] += acc2c[r] * (1.0f / 2048.f);
+        } else {
+            const float* zp = Zs + cl * LDZ + 4 * half;
+            const float* w2p = W2s + cl * LDZ + 4 * half;
+#pragma unroll
+            for (int q = 0; q < HS / 8; ++q) {
+                const f32x4 za = *reinterpret_cast<const f32x4*>(zp + 8 * q);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w2p + 8 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(za[k], wb[k], acc2, 0, 0, 0);
+            }
         }
         float mine = 0.f;
 #pragma unroll
@@ -269,7 +342,7 @@ __global__ __launch_bounds__(512) void k_edge_score_ws(
     }
 }
 
-template <int K>
+template <int K, bool F16 = false>
 static int launch_score_ws(const float* e, int64_t E, const float* Ps, const float* Qd, int ldn, const int32_t* ss,
                            const int32_t* sd, const int32_t* se, const float* W1e, int ldw1, const float* W2, const float* b2,
                            const float* W3, const float* b3, float* logits, hipStream_t s) {
@@ -278,7 +351,7 @@ static int launch_score_ws(const float* e, int64_t E, const float* Ps, const flo
     int groups = persistent_grid();
     if (groups > (tiles + 7) / 8) groups = (int)((tiles + 7) / 8);
     const int tpg = (int)((tiles + groups - 1) / groups);
-    hipLaunchKernelGGL((k_edge_score_ws<K>), dim3(groups), dim3(512), 0, s, e, E, Ps, Qd, ldn, ss, sd, se, W1e, ldw1, W2, b2, W3, b3, logits,
+    hipLaunchKernelGGL((k_edge_score_ws<K, F16>), dim3(groups), dim3(512), 0, s, e, E, Ps, Qd, ldn, ss, sd, se, W1e, ldw1, W2, b2, W3, b3, logits,
                        (int)tiles, tpg);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
@@ -323,10 +396,15 @@ extern "C" int gnnome_edge_score_f32(const float* e, int64_t num_edges, int hidd
     GN_REQUIRE(((uintptr_t)e % 16 == 0) && ((uintptr_t)W1e % 16 == 0), "edge_score: e and W1e must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     // inference at hs = 64: the weight-stationary streaming kernel (gnnome_set_tuning(2, 1) = the tile kernels keeps the old one)
-    if (z1_out == nullptr && hidden_edge_scores == 64 && (hidden == 64 || hidden == 128) && ld_node % 4 == 0 &&
+    const bool f16 = tuning(kTuneArith) == 0;   // fp16x3 (round 4): at H = 128 / 256; gnnome_set_tuning(10, 1) = bf16x6 (H <= 128)
+    if (z1_out == nullptr && hidden_edge_scores == 64 && (hidden == 64 || hidden == 128 || (hidden == 256 && f16)) && ld_node % 4 == 0 &&
         ((uintptr_t)Ps % 16 == 0) && ((uintptr_t)Qd % 16 == 0) && tuning(kTuneLinearVariant) != 1) {
-        if (hidden == 128) return launch_score_ws<128>(e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s);
-        return launch_score_ws<64>(e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s);
+        if (hidden == 256) return launch_score_ws<256, true>(e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s);
+        if (hidden == 128)
+            return f16 ? launch_score_ws<128, true>(e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s)
+                       : launch_score_ws<128>(e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s);
+        return f16 ? launch_score_ws<64, true>(e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s)
+                   : launch_score_ws<64>(e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s);
     }
     switch (hidden) {
         case 64: return dispatch_hs<2>(hidden_edge_scores, e, num_edges, Ps, Qd, ld_node, srt_src, srt_dst, srt_eid, W1e, ldw1, W2, b2, W3, b3, logits, s, z1_out);
