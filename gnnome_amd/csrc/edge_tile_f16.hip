@@ -107,7 +107,7 @@ __device__ __forceinline__ h8_t as_h8(const uint4 v) { return __builtin_bit_cast
 // MODE 1: xe = e W3^T + B1h[src] + B2h[dst] and its shifted column sums (training forward; a.scale = the centres, a.stats out)
 // MODE 4: C[M, 128 * num_cblocks] = A[M,256] W^T + bias (a.e_in = A with row stride a.ldn, a.e_out = C with row stride a.ld_out, a.scale = bias)
 // PROBE (measurement only, wrong results; gnnome_set_tuning(1, 100 + mask)): 1 no DMA inside the loop, 2 no plane conversion inside the loop,
-// 4 no MFMAs, 8 no gathers / residual loads, 16 no stores
+// 4 no MFMAs, 8 no gathers / residual loads, 16 no stores, 32 (correct results) B2h[dst] fetched for every piece
 // X16 (MODE 1): xe stored as bf16 (rounded to nearest even; the statistics are those of the rounded values - common.h)
 template <int MODE, int PROBE = 0, bool X16 = false>
 __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
@@ -270,6 +270,8 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
         const int ew = wave - 4;
         const int c4 = lane & 31, hl = 4 * (lane >> 5), rl = 8 * ew + hl;   // piece p: tile row rl + p, columns colh + 4 c4 .. + 3
         f32x4 g1[3][NP], g2[3][NP], ek[3][NP];
+        unsigned g2_fresh[3] = {0u, 0u, 0u};   // (wave-uniform) bit p: B2h[dst] was fetched for piece p of the set
+        constexpr bool FRESH_G2 = !(PROBE & 32);
         int si[3], di[3];   // lane l: the endpoints of tile row 8 ew + l % 8 (one load per array, wave and tile)
         auto fetch_index = [&](auto set, int r) {
             constexpr int S = decltype(set)::value;
@@ -288,11 +290,20 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
             }
             const int64_t row0 = (int64_t)tile_of(r) * TM;
             const int valid = tile_valid(r);
+            int dprev = -1;
+            g2_fresh[S] = 0;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int sp = __shfl(si[S], hl + p), dp = __shfl(di[S], hl + p);
                 g1[S][p] = *reinterpret_cast<const f32x4*>(a.B1h + (int64_t)sp * a.ldn + colh + 4 * c4);
-                g2[S][p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)dp * a.ldn + colh + 4 * c4);
+                // B2h[dst]: the rows are destination-sorted and a lane's pieces are consecutive rows - the row is fetched again only when some
+                // lane of the wave needs a new one (a wave-uniform branch; the skipped pieces are filled in from their predecessors when consumed)
+                const bool fresh = p == 0 || dp != dprev;
+                if (!FRESH_G2 || __builtin_amdgcn_ballot_w64(fresh) != 0) {
+                    g2[S][p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)dp * a.ldn + colh + 4 * c4);
+                    g2_fresh[S] |= 1u << p;
+                }
+                dprev = dp;
                 if (MODE == 0) ek[S][p] = *reinterpret_cast<const f32x4*>(a.e_in + (row0 + min(rl + p, valid - 1)) * H + colh + 4 * c4);
             }
         };
@@ -329,6 +340,12 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
             flag_bump(drained0, lane);
             const int valid = tile_valid(i);
+            if (MODE != 4 && FRESH_G2) {
+                const unsigned fr = __builtin_amdgcn_readfirstlane(g2_fresh[S]);
+#pragma unroll
+                for (int p = 1; p < NP; ++p)
+                    if (!((fr >> p) & 1u)) g2[S][p] = g2[S][p - 1];   // same destination as the row above: the same B2h row
+            }
             float* out = a.e_out + ((int64_t)tile_of(i) * TM + rl) * ldo + colh + 4 * c4;
             auto pieces = [&](auto full_tile) {
                 constexpr bool FULL = decltype(full_tile)::value;
@@ -440,6 +457,7 @@ int gate_f16_launch(int mode, const GateBfArgs& a, int grid, hipStream_t s, bool
             case 16: return launch_f16<0, 16>(a, grid, s);
             case 24: return launch_f16<0, 24>(a, grid, s);
             case 31: return launch_f16<0, 31>(a, grid, s);
+            case 32: return launch_f16<0, 32>(a, grid, s);   // B2h[dst] fetched for every piece (the form before the destination-run skip)
             default: break;
         }
     }
