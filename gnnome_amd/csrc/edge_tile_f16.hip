@@ -125,7 +125,8 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned full0 = lds_addr(&flags[0]), done0 = lds_addr(&flags[NS]), drained0 = lds_addr(&flags[NS + 1]), landed0 = lds_addr(&flags[NS + 2]);
     // MODE 4 (no gathers, no residual: the epilogue waves only add a bias and store): THEY turn the landed rows into planes, the compute waves
-    // keep DMA + MFMA.  (In the gate the same split made the epilogue waves the long pole: 1.68 against 1.34 ms per launch.)
+    // keep DMA + MFMA.  (In the gate the same split made the epilogue waves the long pole: 1.68 against 1.34 ms per launch.  Letting the epilogue waves
+    // issue the DMA of their rows as well - they have no other loads in this mode - measured level: 0.66 against 0.63-0.66 ms per projection.)
     constexpr bool EPI_CONV = MODE == 4;
     // the work distribution of k_edge_gate_pl256: pairs of workgroups on one XCD (blocks b and b + 8 share b % 8) take the two column
     // halves of the same tiles; mode 4: the a.num_cblocks workgroups of an XCD that share idx / num_cblocks walk the same tiles
