@@ -25,7 +25,8 @@
 //     no other wave involved, so the split is done once per workgroup (a first version let every compute wave split the whole tile on the
 //     fly from the fp32 slot: 24 VALU operations per k step and wave, and a lone wave issues one instruction every four cycles - 3340
 //     cycles per tile in the loop against 1536 of MFMA, measured);
-//     (moving this conversion to the epilogue waves made THEM the long pole: 1.68 against 1.34 ms per launch, measured);
+//     (moving this conversion to the epilogue waves made THEM the long pole: 1.68 against 1.34 ms per launch, measured; the raw rows through
+//     registers - global_load_dwordx4 during tile j, ds_write_b128 during tile j + 1 - instead of LDS-DMA: 1.437 against 1.369 ms, the DMA is not what binds);
 //   * the MFMA loop then reads a fragment per plane and step (two ds_read_b128) and issues three MFMAs; W3's two planes for the wave's
 //     32 output columns live in 128 registers;
 //   * the four EPILOGUE waves never touch a tile: they gather G = B1h[src] + B2h[dst] and the residual two tiles ahead into three
