@@ -70,6 +70,7 @@ int stream_linear_acc_256(const float* A, int64_t M, const float* W, int ldw, fl
 int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s, bool x16 = false);   // x16: mode 1 (xe out as bf16), mode 3 (xe in / dxe out as bf16)
 // the same tiles in fp16x3 arithmetic with LDS-DMA tile loads (edge_tile_f16.hip; modes 0, 1, 4): the default, gnnome_set_tuning(10, 1) = bf16x6
 int gate_f16_launch(int mode, const GateBfArgs& a, int grid, hipStream_t s, bool x16 = false);
+int gate_enc256_launch(const GateBfArgs& a, hipStream_t s);   // layer 0 at H = 256 with the edge encoder folded (edge_gate_bf.hip -> edge_tile_f16.hip mode 5)
 int gate_pl256_stats_rows();
 void hub_cache_invalidate();        // node_aggregate.hip: forget the hub list of the previous graph (called when views are built)
 long long* gate_profile_buffer();   // gnnome_debug_gate_profile's buffer (edge_gate_bf.hip), NULL in normal use

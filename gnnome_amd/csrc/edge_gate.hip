@@ -761,11 +761,19 @@ extern "C" int gnnome_edge_gate_encode_f32(const float* e_raw, const int32_t* sr
     if (num_edges == 0) return GNNOME_OK;
     GN_REQUIRE(e_raw && srt_eid && encW1 && encb1 && encW2 && encb2 && e_out && B1h && B2h && srt_src && srt_dst && W3 &&
                    norm_scale && norm_shift, "edge_gate_encode: null pointer");
-    GN_REQUIRE(hidden == 64 || hidden == 128, "edge_gate_encode: hidden=%d not in {64,128}", hidden);
+    GN_REQUIRE(hidden == 64 || hidden == 128 || (hidden == 256 && tuning(kTuneArith) == 0 && tuning(kTuneGateVariant) == 0),
+               "edge_gate_encode: hidden=%d not in {64,128,256 (default kernels)}", hidden);
     GN_REQUIRE(ld_node % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0) && ((uintptr_t)W3 % 16 == 0),
                "edge_gate_encode: alignment");
     const GateEnc enc = {e_raw, srt_eid, encW1, encb1, encW2, encb2};
     hipStream_t s = (hipStream_t)stream;
+    if (hidden == 256) {
+        GN_REQUIRE((uintptr_t)e_out % 16 == 0, "edge_gate_encode: e_out must be 16-byte aligned");
+        GateBfArgs a = {};
+        a.e_out = e_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src; a.srt_dst = srt_dst;
+        a.W3 = W3; a.ldw = ldw; a.scale = norm_scale; a.shift = norm_shift; a.enc = enc;
+        return gate_enc256_launch(a, s);
+    }
     if (tuning(kTuneGateVariant) == 0 || tuning(kTuneGateVariant) == 7 || tuning(kTuneGateVariant) == 8) {
         GateBfArgs a = {};
         a.e_out = e_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src; a.srt_dst = srt_dst;

@@ -1050,6 +1050,28 @@ static int launch_enc16(const GateBfArgs& args, hipStream_t s) {
     return GNNOME_OK;
 }
 
+// H = 256 (round 4): the same fold on the fp16x3 edge-tile kernel (edge_tile_f16.hip, mode 5)
+static EncFoldScratch g_enc_fold256[16];
+int gate_enc256_launch(const GateBfArgs& args, hipStream_t s) {
+    GateBfArgs a = args;
+    const int64_t tiles = (a.E + 31) / 32;
+    GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
+    a.num_tiles = (int)tiles;
+    a.prof = g_gate_prof;
+    int dev = 0;
+    GN_HIP(hipGetDevice(&dev));
+    GN_REQUIRE(dev >= 0 && dev < 16, "edge_gate_encode: device index %d", dev);
+    if (!g_enc_fold256[dev].w23) GN_HIP(hipMalloc(&g_enc_fold256[dev].w23, sizeof(float) * (256 * 16 + 256)));
+    float* w23 = g_enc_fold256[dev].w23;
+    hipLaunchKernelGGL(k_fold_encoder, dim3((256 * 17 + 3) / 4), dim3(256), 0, s, a.W3, a.ldw, a.enc.W2, a.enc.b2, 256, w23, w23 + 256 * 16);
+    GN_LAUNCH_CHECK();
+    a.enc.W23 = w23;
+    a.enc.b23 = w23 + 256 * 16;
+    int g = persistent_grid();
+    g -= g % 16;   // pairs of workgroups per XCD (as grid_pl256)
+    return gate_f16_launch(5, a, g < 16 ? 16 : g, s);
+}
+
 template <int CB, int RB, int MODE, bool ENC, bool X16 = false>
 static int launch_bf(const GateBfArgs& args, hipStream_t s) {
     using P = GateBF<CB, RB>;

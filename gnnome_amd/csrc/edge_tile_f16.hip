@@ -107,18 +107,23 @@ __device__ __forceinline__ h8_t as_h8(const uint4 v) { return __builtin_bit_cast
 // MODE 0: e' = relu((e W3^T + B1h[src] + B2h[dst]) * scale + shift) + e    (gated_gcn_full.py:97,104-110)
 // MODE 1: xe = e W3^T + B1h[src] + B2h[dst] and its shifted column sums (training forward; a.scale = the centres, a.stats out)
 // MODE 4: C[M, 128 * num_cblocks] = A[M,256] W^T + bias (a.e_in = A with row stride a.ldn, a.e_out = C with row stride a.ld_out, a.scale = bias)
+// MODE 5: MODE 0 for layer 0 with the edge encoder folded ALGEBRAICALLY (as k_edge_gate_enc16 does at H = 128; full_graph.py:27 + gated_gcn_full.py:97,104-110):
+//         e0 = t W2^T + b2 with t = relu(W1 e_raw + b1) only 16 wide, so e0 W3^T = t (W3 W2)^T + W3 b2 - the gate's product and the residual are both K = 16
+//         products of one [32 x 16] tile t that every compute wave builds in registers from the raw edge features; no e tile, no DMA, nothing read from HBM
+//         but two floats per edge and the gathers (a.enc: e_raw, srt_eid, W1, b1, W2, b2 and W23 = W3 W2, b23 = W3 b2 from k_fold_encoder)
 // PROBE (measurement only, wrong results; gnnome_set_tuning(1, 100 + mask)): 1 no DMA inside the loop, 2 no plane conversion inside the loop,
 // 4 no MFMAs, 8 no gathers / residual loads, 16 no stores, 32 (correct results) B2h[dst] fetched for every piece
 // X16 (MODE 1): xe stored as bf16 (rounded to nearest even; the statistics are those of the rounded values - common.h)
 template <int MODE, int PROBE = 0, bool X16 = false>
 __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
     static_assert(!X16 || MODE == 1, "bf16 storage belongs to the raw gate");
+    constexpr bool ENC = MODE == 5, GATE = MODE == 0 || MODE == 5;
     constexpr int H = 256, HC = 128, TM = 32, KS = H / 16, NS = 4;
     constexpr int RSB = 4 * H + 16, SLOTB = TM * RSB;   // a raw row in LDS: 1024 bytes + 16 (consecutive rows start 4 banks apart)
     constexpr int LDK = HC + 4, XT = TM * LDK;
     constexpr int NP = 4;   // epilogue pieces per lane and tile: a wave owns 8 rows x 128 columns
-    __shared__ __attribute__((aligned(16))) unsigned char ring[NS * SLOTB];
-    __shared__ __attribute__((aligned(16))) float xt[XT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring[ENC ? 16 : NS * SLOTB];
+    __shared__ __attribute__((aligned(16))) float xt[ENC ? 2 * XT : XT];   // ENC: the x tile and the e0 tile
     __shared__ __attribute__((aligned(16))) float norm_lds[2 * HC];
     __shared__ unsigned flags[2 * NS + 2];   // full[NS], done, drained, landed[NS] (EPI_CONV)
 
@@ -152,12 +157,69 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
     } else {
         for (int i = tid; i < 2 * HC; i += 512) {
             const int q = i / HC, c = i % HC;
-            norm_lds[i] = q == 0 ? (a.scale ? a.scale[colh + c] : 0.f) : (MODE == 0 ? a.shift[colh + c] : 0.f);
+            // ENC: x lacks W3 b2 (= b23): (x + b23 + G) scale + shift = (x + G) scale + (shift + b23 scale)
+            norm_lds[i] = q == 0 ? (a.scale ? a.scale[colh + c] : 0.f)
+                                 : (MODE == 0 ? a.shift[colh + c] : (ENC ? __builtin_fmaf(a.enc.b23[colh + c], a.scale[colh + c], a.shift[colh + c]) : 0.f));
         }
     }
     __syncthreads();
 
-    if (wave < 4) {
+    if (ENC && wave < 4) {
+        // ------------------------------------------------------------------ compute wave, folded encoder: t in registers, two K = 16 products
+        const int cl = lane & 31, half = lane >> 5, col = colh + 32 * wave + cl;
+        h8_t wxa, wxb, wea, web;   // this lane's B fragments (column col, k = 8 half .. + 7) of W23 and of W2
+        {
+            const float* p23 = a.enc.W23 + col * 16 + 8 * half;
+            const float* p2 = a.enc.W2 + col * 16 + 8 * half;
+            split8h(f32x4{p23[0], p23[1], p23[2], p23[3]}, f32x4{p23[4], p23[5], p23[6], p23[7]}, wxa, wxb);
+            split8h(f32x4{p2[0], p2[1], p2[2], p2[3]}, f32x4{p2[4], p2[5], p2[6], p2[7]}, wea, web);
+        }
+        const float b2c = a.enc.b2[col];
+        float w1a[8], w1b[8], b1v[8];   // hidden units 8 half .. + 7 of the edge encoder's first layer (in_features = 2)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            w1a[k] = a.enc.W1[2 * (8 * half + k)], w1b[k] = a.enc.W1[2 * (8 * half + k) + 1], b1v[k] = a.enc.b1[8 * half + k];
+        }
+        auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
+        float* X = xt + 4 * half * LDK + 32 * wave + cl;
+        auto raw_of = [&](int r, float& x0, float& x1) {   // the raw features of tile row cl of tile ordinal r
+            const int64_t row = (int64_t)tile_of(r) * TM + min(cl, tile_valid(r) - 1);
+            const int64_t eid = a.enc.srt_eid[row];
+            x0 = a.enc.e_raw[2 * eid], x1 = a.enc.e_raw[2 * eid + 1];
+        };
+        float r0 = 0.f, r1 = 0.f;
+        raw_of(0, r0, r1);
+#pragma unroll 1
+        for (int j = 0; j < n; ++j) {
+            float n0 = 0.f, n1 = 0.f;
+            raw_of(j + 1, n0, n1);   // (ordinals past the end repeat the last tile)
+            f32x4 tl, th;   // t = relu(W1 e_raw + b1) in the reference's order (k_edge_gate_enc16)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tl[k] = fmaxf(__builtin_fmaf(r1, w1b[k], r0 * w1a[k]) + b1v[k], 0.f);
+                th[k] = fmaxf(__builtin_fmaf(r1, w1b[4 + k], r0 * w1a[4 + k]) + b1v[4 + k], 0.f);
+            }
+            h8_t ta, tb;
+            split8h(tl, th, ta, tb);
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            f32x16 xm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta, wxa, z, 0, 0, 0);
+            f32x16 xc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta, wxb, z, 0, 0, 0);
+            xc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tb, wxa, xc, 0, 0, 0);
+            f32x16 em = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta, wea, z, 0, 0, 0);
+            f32x16 ec = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta, web, z, 0, 0, 0);
+            ec = __builtin_amdgcn_mfma_f32_32x32x16_f16(tb, wea, ec, 0, 0, 0);
+            flag_wait(drained0, 4u * (unsigned)j);   // x(j - 1) and e0(j - 1) have been read by all four epilogue waves
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                X[crow(r) * LDK] = xm[r] + xc[r] * kLoInv;
+                X[XT + crow(r) * LDK] = (em[r] + ec[r] * kLoInv) + b2c;
+            }
+            flag_bump(done0, lane);
+            r0 = n0, r1 = n1;
+        }
+    } else if (!ENC && wave < 4) {
         // ------------------------------------------------------------------ compute wave: DMA in, planes in place, 32 rows x 32 columns of MFMA
         const int cl = lane & 31, half = lane >> 5, col = colh + 32 * wave + cl;
         h8_t w1[KS], w2[KS];
@@ -306,7 +368,7 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
                     g2_fresh[S] |= 1u << p;
                 }
                 dprev = dp;
-                if (MODE == 0) ek[S][p] = *reinterpret_cast<const f32x4*>(a.e_in + (row0 + min(rl + p, valid - 1)) * H + colh + 4 * c4);
+                if (MODE == 0) ek[S][p] = *reinterpret_cast<const f32x4*>(a.e_in + (row0 + min(rl + p, valid - 1)) * H + colh + 4 * c4);   // (ENC: e0 comes out of LDS with x)
             }
         };
         // EPI_CONV: rows 8 ew .. 8 ew + 7 of tile ordinal r become planes in place (all 64 lanes read a row before any of them writes it)
@@ -328,7 +390,7 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
         f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1;   // MODE 1: this lane's running shifted sums of its four columns
         long long t_done = 0, t_epi = 0, t_issue = 0, t0 = 0, t1 = 0;
         const f32x4 sc4 = *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4);   // MODE 0: scale; 1: centres; 4: bias
-        const f32x4 sh4 = MODE == 0 ? *reinterpret_cast<const f32x4*>(norm_lds + HC + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 sh4 = GATE ? *reinterpret_cast<const f32x4*>(norm_lds + HC + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
         const float* Xs = xt + rl * LDK + 4 * c4;
         auto tile = [&](auto set, int i) {
             constexpr int S = decltype(set)::value, S2 = (S + 2) % 3;
@@ -339,6 +401,11 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
             f32x4 x[NP];
 #pragma unroll
             for (int p = 0; p < NP; ++p) x[p] = *reinterpret_cast<const f32x4*>(Xs + p * LDK);
+            if (ENC) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) ek[S][p] = *reinterpret_cast<const f32x4*>(Xs + XT + p * LDK);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ek[S][0]), "+v"(ek[S][1]), "+v"(ek[S][2]), "+v"(ek[S][3]));
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
             flag_bump(drained0, lane);
             const int valid = tile_valid(i);
@@ -354,7 +421,7 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     f32x4 y;
-                    if (MODE == 0) {
+                    if (GATE) {
                         const f32x4 g = g1[S][p] + g2[S][p];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -466,6 +533,7 @@ int gate_f16_launch(int mode, const GateBfArgs& a, int grid, hipStream_t s, bool
     if (mode == 0) return launch_f16<0>(a, grid, s);
     if (mode == 1) return launch_f16<1>(a, grid, s);
     if (mode == 4) return launch_f16<4>(a, grid, s);
+    if (mode == 5) return launch_f16<5>(a, grid, s);
     set_error("edge-tile kernel (H = 256, fp16x3): mode %d is not built", mode);
     return GNNOME_EINVAL;
 }

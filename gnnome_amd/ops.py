@@ -214,7 +214,8 @@ def edge_gate(e, B1h, B2h, views, W3, norm_kind, scale, shift, out=None, num_edg
 
 def can_fuse_edge_encoder(e_raw, enc, hidden, norm_kind, B1h):
     """The layer-0 gate can produce the encoded edge tile itself (gnnome_edge_gate_encode_f32)."""
-    return (e_raw.dim() == 2 and e_raw.shape[1] == 2 and enc[0].shape == (16, 2) and hidden in (64, 128)
+    widths = (64, 128, 256) if _TUNING.get(10, 0) == 0 and _TUNING.get(0, 0) == 0 else (64, 128)   # 256: round 4, the fp16x3 kernel's mode 5
+    return (e_raw.dim() == 2 and e_raw.shape[1] == 2 and enc[0].shape == (16, 2) and hidden in widths
             and norm_kind == NORM_AFFINE and e_raw.shape[0] > 0 and B1h.stride(0) % 4 == 0 and B1h.data_ptr() % 16 == 0)
 
 

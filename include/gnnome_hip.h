@@ -143,7 +143,8 @@ int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num_edges, int
 /* Layer-0 form of the gate with the edge encoder folded in (models/full_graph.py:27 + gated_gcn_full.py:97-110):
  *   e0[p,:]    = encW2 * relu(encW1 * e_raw[srt_eid[p],:] + encb1) + encb2          (in_features 2, hidden_ne 16)
  *   e_out[p,:] = relu(norm_e(B1h[srt_src[p],:] + B2h[srt_dst[p],:] + e0[p,:]*W3^T)) + e0[p,:]
- * e0 is produced tile by tile in LDS and never touches HBM.  hidden in {64,128}, affine norm only.
+ * e0 is produced tile by tile in LDS and never touches HBM.  hidden in {64,128}, affine norm only; 256 since round 4 (the encoder folded
+ * algebraically into a K = 16 product on the fp16x3 edge-tile kernel; default kernels only).
  * At hidden = 128 the encoder is folded algebraically: with t = relu(encW1 * e_raw + encb1) (16 wide), e0*W3^T = t*(W3*encW2)^T +
  * W3*encb2, so the gate's product and the residual e0 are two K = 16 products of one tile; W3*encW2 and W3*encb2 are recomputed at
  * every call (fp32, fixed summation tree) into a small per-device buffer - calls on DIFFERENT streams of one device must not

@@ -484,7 +484,7 @@ def test_edge_score_streaming_kernel_against_the_tile_kernel(hidden, e):
         assert torch.equal(got, run())
 
 
-@pytest.mark.parametrize("hidden", [64, 128])
+@pytest.mark.parametrize("hidden", [64, 128, 256])   # 256: round 4, mode 5 of the fp16x3 edge-tile kernel
 @pytest.mark.parametrize("e_count", [777, 90_001])
 def test_edge_gate_with_folded_encoder(hidden, e_count):
     n, H = 600, hidden
@@ -501,6 +501,12 @@ def test_edge_gate_with_folded_encoder(hidden, e_count):
     assert ops.can_fuse_edge_encoder(e_raw.to(dev()), enc_d, H, 0, d["P"][:, 3 * H:4 * H])
     got = ops.edge_gate_encode(e_raw.to(dev()), enc_d, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], d["scale"], d["shift"])
     _assert_close(got, want, scale=20.0)
+    assert torch.equal(got, ops.edge_gate_encode(e_raw.to(dev()), enc_d, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], d["scale"], d["shift"]))
+    if hidden == 256:   # against the unfused pair on the same device: encoder, then the gate
+        e0d = ops.encode(e_raw.to(dev()), *enc_d, gather=gv.srt_eid)
+        two = ops.edge_gate(e0d, d["P"][:, 3 * H:4 * H], d["P"][:, 4 * H:], gv, d["W3"], 0, d["scale"], d["shift"], out=torch.empty_like(e0d))
+        assert (got - two).abs().max().item() <= 2e-5 * max(1.0, two.abs().max().item())
+        return
     alts = []
     try:  # the exact-fp32-MFMA generation of the kernel, slot hand-over by LDS counters (5) or workgroup barriers (6);
           # 8 = the second-generation bf16x6 kernel with the folded encoder (the default is its plane form)
