@@ -485,7 +485,7 @@ def test_edge_score_streaming_kernel_against_the_tile_kernel(hidden, e):
 
 
 @pytest.mark.parametrize("hidden", [64, 128, 256])   # 256: round 4, mode 5 of the fp16x3 edge-tile kernel
-@pytest.mark.parametrize("e_count", [777, 90_001])
+@pytest.mark.parametrize("e_count", [5, 777, 90_001])
 def test_edge_gate_with_folded_encoder(hidden, e_count):
     n, H = 600, hidden
     src, dst, t = _layer_inputs(hidden, n, e_count, seed=hidden + 5)

@@ -31,6 +31,46 @@ for it in range(launches):
     sc, sh = (0.5 + torch.rand(H, generator=gen)).to(dev), torch.randn(H, generator=gen).to(dev)
     B1, B2 = P[:, 3 * H:4 * H], P[:, 4 * H:]
     mode = it % 6
+    if it % 5 == 4:
+        # round 4: the fp16x3 + LDS-DMA edge-tile kernel at H = 256 (edge_tile_f16.hip: counters AND a counted vmcnt) - gate, raw gate + statistics,
+        # node projection, folded-encoder gate - against round 3's bf16x6 plane form / the unfused pair
+        H2 = 256
+        e2 = (3.0 * torch.randn(E, H2, generator=gen)).to(dev)
+        P2 = torch.randn(n, 2 * H2, generator=gen).to(dev)
+        W32 = (torch.randn(H2, H2, generator=gen) / H2 ** 0.5).to(dev)
+        sc2, sh2 = (0.5 + torch.rand(H2, generator=gen)).to(dev), torch.randn(H2, generator=gen).to(dev)
+        sub = (it // 5) % 4
+        if sub == 0:
+            got = ops.edge_gate(e2, P2[:, :H2], P2[:, H2:], views, W32, 0, sc2, sh2, out=torch.full_like(e2, float("nan")))
+            ops.set_tuning(10, 1)
+            want = ops.edge_gate(e2, P2[:, :H2], P2[:, H2:], views, W32, 0, sc2, sh2, out=torch.empty_like(e2))
+            ops.set_tuning(10, 0)
+        elif sub == 1:
+            got, mean, var = ops.edge_gate_raw_stats(e2, P2[:, :H2], P2[:, H2:], views, W32)
+            ops.set_tuning(10, 1)
+            want = ops.edge_gate_raw(e2, P2[:, :H2], P2[:, H2:], views, W32)
+            ops.set_tuning(10, 0)
+            m2, _ = ops.batch_stats(want)
+            assert (mean - m2).abs().max().item() < 1e-3 * max(1.0, m2.abs().max().item()), (it, E, "mean at 256")
+        elif sub == 2:
+            nb = int(torch.randint(1, 11, (1,), generator=gen))
+            Wp = (torch.randn(nb * 128, H2, generator=gen) / H2 ** 0.5).to(dev)
+            bp = torch.randn(nb * 128, generator=gen).to(dev)
+            wide = torch.full((E, nb * 128 + 64), 7.0, device=dev)
+            got = ops.linear(e2, Wp, bp, out=wide[:, 64:]).double()
+            assert (wide[:, :64] == 7.0).all(), (it, E, "columns outside the output written (K = 256)")
+            want = e2.double() @ Wp.double().t() + bp.double()
+        else:
+            e_raw = torch.randn(E, 2, generator=gen).to(dev)
+            enc = tuple(t.to(dev) for t in (torch.randn(16, 2, generator=gen), torch.randn(16, generator=gen), torch.randn(H2, 16, generator=gen) / 4,
+                                            torch.randn(H2, generator=gen)))
+            got = ops.edge_gate_encode(e_raw, enc, P2[:, :H2], P2[:, H2:], views, W32, sc2, sh2)
+            e0 = ops.encode(e_raw, *enc, gather=views.srt_eid)
+            want = ops.edge_gate(e0, P2[:, :H2], P2[:, H2:], views, W32, 0, sc2, sh2, out=torch.empty_like(e0))
+        err = ((got - want).abs() / max(1.0, want.abs().max().item())).max().item()
+        worst = max(worst, err)
+        assert err < 2.5e-5, (it, E, 256, sub, err)
+        continue
     if mode == 3 and H == 128:   # the node projection on the plane form (mode 4 of k_edge_gate_pl): every row count, strided output
         rows = E
         A = (3.0 * torch.randn(rows, H, generator=gen)).to(dev)
