@@ -639,7 +639,9 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
     // kernel sits at the HBM rate this access pattern sustains) - but with 2 items the 8 resident waves per SIMD widen the
     // window of nodes in flight and the out-edge pass finds fewer of its rows still in L2: 979 MB fetched per launch against
     // 764 MB.  4 % of launch time is not worth 28 % more HBM traffic.
-    constexpr int UD = H == 256 ? 8 : 4;
+    // H = 256 (one 1 KB row per load instruction): 2 since round 4 - measured inside the 2.5M-edge forward 1.036 (U = 8) / 0.980 (2) / 0.969 ms (1) per launch,
+    // the same bits (one lane group: the items are added in list order whatever U)
+    constexpr int UD = H == 256 ? 2 : 4;
     constexpr int kFinGrid = kHubCap / (kAggThreads / 64);
     if (mode == 1) {
         GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 1, false, UD, 0, blocks);
