@@ -182,17 +182,19 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
         }
         auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
         float* X = xt + 4 * half * LDK + 32 * wave + cl;
-        auto raw_of = [&](int r, float& x0, float& x1) {   // the raw features of tile row cl of tile ordinal r
-            const int64_t row = (int64_t)tile_of(r) * TM + min(cl, tile_valid(r) - 1);
-            const int64_t eid = a.enc.srt_eid[row];
-            x0 = a.enc.e_raw[2 * eid], x1 = a.enc.e_raw[2 * eid + 1];
-        };
+        // the raw features of tile row cl: two dependent loads (edge id, then the two floats) - the edge id is fetched TWO tiles ahead, the features one
+        // (a tile lasts ~1 us here: with both one tile ahead the chain of two memory round trips was exposed in every tile)
+        auto eid_of = [&](int r) { return a.enc.srt_eid[(int64_t)tile_of(r) * TM + min(cl, tile_valid(r) - 1)]; };
         float r0 = 0.f, r1 = 0.f;
-        raw_of(0, r0, r1);
+        {
+            const int64_t e0i = eid_of(0);
+            r0 = a.enc.e_raw[2 * e0i], r1 = a.enc.e_raw[2 * e0i + 1];
+        }
+        int eid_next = eid_of(1);
 #pragma unroll 1
         for (int j = 0; j < n; ++j) {
-            float n0 = 0.f, n1 = 0.f;
-            raw_of(j + 1, n0, n1);   // (ordinals past the end repeat the last tile)
+            const int eid_after = eid_of(j + 2);   // (ordinals past the end repeat the last tile)
+            const float n0 = a.enc.e_raw[2 * (int64_t)eid_next], n1 = a.enc.e_raw[2 * (int64_t)eid_next + 1];
             f32x4 tl, th;   // t = relu(W1 e_raw + b1) in the reference's order (k_edge_gate_enc16)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
             }
             flag_bump(done0, lane);
             r0 = n0, r1 = n1;
+            eid_next = eid_after;
         }
     } else if (!ENC && wave < 4) {
         // ------------------------------------------------------------------ compute wave: DMA in, planes in place, 32 rows x 32 columns of MFMA
@@ -533,6 +536,8 @@ int gate_f16_launch(int mode, const GateBfArgs& a, int grid, hipStream_t s, bool
     if (mode == 0) return launch_f16<0>(a, grid, s);
     if (mode == 1) return launch_f16<1>(a, grid, s);
     if (mode == 4) return launch_f16<4>(a, grid, s);
+    if (mode == 5 && tuning(kTuneGateAblation) == 308) return launch_f16<5, 8>(a, grid, s);    // measurement only: no gathers
+    if (mode == 5 && tuning(kTuneGateAblation) == 316) return launch_f16<5, 16>(a, grid, s);   // measurement only: no stores
     if (mode == 5) return launch_f16<5>(a, grid, s);
     set_error("edge-tile kernel (H = 256, fp16x3): mode %d is not built", mode);
     return GNNOME_EINVAL;
