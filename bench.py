@@ -430,7 +430,8 @@ def _partitioned_train_record(gnnome_amd, gdist, ops, g, n, e, hidden, dev, rank
                                f"BCEWithLogits(pos_weight) + backward + Adam, fp32, random-init weights seed 1",
                    "parallelism": f"dst-range x{world}, halo all_to_all per layer both ways, BatchNorm statistics merged over ranks, "
                                   f"one flat gradient all-reduce ({n_params * 4} B) per step; {transport}"},
-        "loss": float(loss), "ranks_in_step": in_step, "recompute_gate": bool(getattr(model, "recompute_gate", False)), "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+        "loss": float(loss), "ranks_in_step": in_step, "recompute_gate": bool(getattr(model, "recompute_gate", False)),
+        "activation_storage": getattr(model, "activation_storage", "fp32"), "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
         "hbm_roofline_frac_3xBfwd": 3 * b_fwd / (ms * 1e-3) / (world * HBM_PEAK), "mfma_f32_frac_3xFfwd": 3 * f_fwd / (ms * 1e-3) / (world * MFMA_F32_PEAK),
         "rank0": {"owned_nodes": plan.n_own, "halo_nodes": plan.n_local - plan.n_own, "local_edges": plan.views.num_edges,
                   "owned_in_edges": plan.n_score, "rows_sent_per_layer": int(sum(plan.send_counts)),
@@ -647,6 +648,8 @@ def main():
         if args.mode == "train":
             model.train()
             model.recompute_gate = args.recompute_gate
+            if args.storage == "bf16" and not args.recompute_gate:   # (alternatives: nothing is stored when xe is recomputed)
+                model.activation_storage = "bf16"   # partitions too since round 4
         node_perm = None
         if args.node_order == "locality":   # the order needs the whole graph once; every rank computes the same permutation on its GPU
             from gnnome_amd import node_order as _order

@@ -178,7 +178,13 @@ def _raw_gate(sh, conv, e, B1h, B2h, layer_norm, storage, path=None):
         xe, mom = ops.edge_gate_raw_moments(e, B1h, B2h, views, W3, storage=storage)
         return path, xe, mom
     if storage != torch.float32:
-        raise _no_bf16_storage()
+        # bf16 storage off the fused single-rank path (round 4: partitions - BatchNorm statistics cross ranks, so they cannot come out of the
+        # gate's own pass): the rows rounded by the same kernel, the statistics of the ROUNDED owned rows from a second pass over them
+        if not ops.can_fuse_gate_moments(e, B1h, B2h, storage):
+            raise _no_bf16_storage()
+        xe, _ = ops.edge_gate_raw_moments(e, B1h, B2h, views, W3, storage=storage)
+        m_e, v_e = ops.batch_stats(xe[:sh.e_own].float())   # (a transient fp32 copy of the owned rows; freed before the next layer)
+        return path, xe, (m_e, v_e)
     if recomputing and sh.e_own != e.shape[0]:   # a partition's forward took edge_gate_raw + batch_stats(owned rows): the gate alone
         return path, ops.edge_gate_raw(e, B1h, B2h, views, W3), None
     xe, m_e, v_e = ops.edge_gate_raw_stats(e, B1h, B2h, views, W3, rows_stats=sh.e_own)
@@ -186,8 +192,8 @@ def _raw_gate(sh, conv, e, B1h, B2h, layer_norm, storage, path=None):
 
 
 def _no_bf16_storage():
-    return ValueError('activation_storage="bf16" is built for the fused single-rank BatchNorm step at hidden_features 64 / 128 / 256 '
-                      "(normalization='batch', momentum set, one process); use \"fp32\" here")
+    return ValueError('activation_storage="bf16" is built for BatchNorm models at hidden_features 64 / 128 / 256 (single rank: fused; partitions: round 4); '
+                      "normalization='layer' and the recomputed gate take \"fp32\"")
 
 
 class _TrainStep(torch.autograd.Function):

@@ -77,6 +77,7 @@ def worker(rank, world, port, case, out_dir):
             import torch.nn.functional as F
             m.train()
             m.recompute_gate = bool(g.get("recompute_gate"))
+            m.activation_storage = g.get("activation_storage", "fp32")
             runner = gdist.PartitionedRunner(m, part, g["x"], g["e"], where, ops=backend)
             logits = runner.train_forward()
             loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), g["y"], pos_weight=g["pos_weight"])

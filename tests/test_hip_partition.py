@@ -174,6 +174,41 @@ def test_two_ranks_training_step_h256_matches_oracle_autograd(tmp_path):
     _check_partitioned_step(outs, om, want, want_loss, rtol=3e-2)
 
 
+@pytest.mark.parametrize("hidden", [128, 256])
+def test_two_ranks_training_step_with_bf16_activation_storage(tmp_path, hidden):
+    """Round 4: activation_storage = "bf16" on a partition (two ranks sharing the GPU, HIP kernels): against the SINGLE-rank bf16 step on the
+    same GPU - same roundings of xe / dxe, the BatchNorm statistics summed across the cut in another order."""
+    import torch.nn.functional as F
+    import gnnome_amd
+    from gnnome_amd.synth import make_graph
+    from oracle.symgated_oracle import degree_features
+    n, e = 3000, 30_000
+    gr = make_graph(n, e, seed=9)
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(hidden, seed=3)
+    dev = torch.device("cuda", 0)
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch", dropout=0.0)
+    m.load_state_dict(sd)
+    m.activation_storage = "bf16"
+    m.to(dev).train()
+    one = m((gr["src"].to(dev), gr["dst"].to(dev), n), x.to(dev), gr["e"].to(dev))
+    loss1 = F.binary_cross_entropy_with_logits(one.squeeze(-1), gr["y"].to(dev), pos_weight=gr["pos_weight"].to(dev))
+    loss1.backward()
+    g1 = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], y=gr["y"], pos_weight=gr["pos_weight"], hidden=hidden, layers=8,
+                state_dict=sd, train=True, device="cuda", activation_storage="bf16")
+    outs = _run(2, case, tmp_path)
+    assert sum(o["n_score"] for o in outs) == e and all(o["n_local"] > o["n_own"] for o in outs)
+    for o in outs:
+        assert abs(o["loss"].item() - loss1.item()) <= 1e-4 * abs(loss1.item())
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(one.detach().squeeze(-1).cpu())).abs().max().item() < 2e-3
+        num = sum(((o["grads"][k] - g1[k]).double() ** 2).sum().item() for k in g1) ** 0.5
+        den = sum((g1[k].double() ** 2).sum().item() for k in g1) ** 0.5
+        assert num / den < 1e-2, num / den
+    for k in outs[0]["grads"]:
+        assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k
+
+
 def test_three_ranks_training_step_h128_on_a_mostly_cut_graph(tmp_path):
     """uniform graph at H = 128 on THREE ranks sharing the GPU: two thirds of the edges are cut (live on two ranks), so most gradient
     rows are assembled from partial sums (the fused BatchNorm-backward + data-gradient pass with rows_once < rows, halo gradients
