@@ -36,6 +36,36 @@ class LayerWeights:
 REFERENCE_ORDER_GAIN = 16.0
 ARITHMETIC_MODES = ("auto", "reference", "fast")
 
+# Widths the kernels are built for.  The reference takes any hidden_features / hidden_edge_scores (configs/hyperparameters.py:22-24);
+# an eval-mode BatchNorm model of another width runs on the next built width with ZERO-PADDED parameters, which is exact: a padded
+# channel has zero weights, zero bias and a zero affine norm, so it stays 0.0 through relu + residual, enters every product as a
+# zero addend at the END of the k-ascending sums, and the aggregation's padded columns are sums of 0.5 * 0.0.  (LayerNorm's statistics run
+# over the row, and train-mode parameters are read from the module itself: both stay with the built widths.)
+BUILT_HIDDEN = (64, 128, 256)
+BUILT_SCORE_HIDDEN = (32, 64, 128)
+
+
+def padded_width(width, built=BUILT_HIDDEN, what="hidden_features"):
+    for b in built:
+        if width <= b:
+            return b
+    raise ValueError(f"{what}={width}: the HIP kernels are built for widths up to {built[-1]}")
+
+
+def _pad(t, *shape):
+    """t in the leading corner of a zero tensor of `shape` (t itself when it already has that shape)."""
+    if tuple(t.shape) == tuple(shape):
+        return t
+    out = t.new_zeros(shape)
+    out[tuple(slice(0, n) for n in t.shape)] = t
+    return out
+
+
+def _refuse_padded_layer_norm(norm_module, width, padded):
+    if padded != width and not isinstance(norm_module, torch.nn.BatchNorm1d):
+        raise ValueError(f"normalization='layer' at hidden_features={width}: LayerNorm's statistics run over the row, so the zero-padding "
+                         f"that serves other widths does not apply - the kernels are built for {BUILT_HIDDEN}")
+
 
 class Prepared:
     """Device-resident, kernel-ready copies of a model's parameters (eval semantics)."""
@@ -46,11 +76,13 @@ class Prepared:
 
         arithmetic = getattr(model, "arithmetic", "auto")
         self.device = device
-        self.hidden = model.linear2_node.out_features
+        self.model_hidden = model.linear2_node.out_features
+        self.hidden = H = padded_width(self.model_hidden)    # the width every kernel of the stack runs at (see BUILT_HIDDEN)
+        ne = model.linear2_node.in_features
         self.enc_node = tuple(dev(t) for t in (model.linear1_node.weight, model.linear1_node.bias,
-                                               model.linear2_node.weight, model.linear2_node.bias))
+                                               _pad(model.linear2_node.weight.detach(), H, ne), _pad(model.linear2_node.bias.detach(), H)))
         self.enc_edge = tuple(dev(t) for t in (model.linear1_edge.weight, model.linear1_edge.bias,
-                                               model.linear2_edge.weight, model.linear2_edge.bias))
+                                               _pad(model.linear2_edge.weight.detach(), H, ne), _pad(model.linear2_edge.bias.detach(), H)))
         self.layers = [prepare_layer(conv, device, arithmetic) for conv in model.gnn.convs]
         self.predictor = prepare_predictor(model.predictor, device)
 
@@ -71,7 +103,8 @@ def _norm_affine(norm_module, device):
         beta = norm_module.bias.detach().float().cpu()
         scale = gamma * (1.0 / torch.sqrt(var + norm_module.eps))
         shift = (beta.double() - mean.double() * scale.double()).float()   # one rounding of the exact fma argument
-        return NORM_AFFINE, dev(scale), dev(shift)
+        width = padded_width(scale.numel())
+        return NORM_AFFINE, dev(_pad(scale, width)), dev(_pad(shift, width))
     if isinstance(norm_module, torch.nn.LayerNorm):
         if abs(norm_module.eps - 1e-5) > 1e-12:
             raise ValueError("LayerNorm eps other than 1e-5 is not supported by the HIP kernels")
@@ -87,21 +120,25 @@ def prepare_layer(conv, device, arithmetic=None):
     if arithmetic not in ARITHMETIC_MODES:
         raise ValueError(f"arithmetic must be one of {ARITHMETIC_MODES}, got {arithmetic!r}")
     lw = LayerWeights()
-    lw.Wcat = dev(torch.cat([conv.A_1.weight, conv.A_2.weight, conv.A_3.weight, conv.B_1.weight, conv.B_2.weight], 0))
-    lw.W3 = dev(conv.B_3.weight)
-    lw.b3 = dev(conv.B_3.bias)
+    width = conv.B_3.weight.shape[0]
+    hidden = padded_width(width)
+    _refuse_padded_layer_norm(conv.bn_e, width, hidden)
+    W = lambda lin: _pad(lin.weight.detach(), hidden, hidden)  # noqa: E731
+    b = lambda lin: _pad(lin.bias.detach(), hidden)  # noqa: E731
+    lw.Wcat = dev(torch.cat([W(conv.A_1), W(conv.A_2), W(conv.A_3), W(conv.B_1), W(conv.B_2)], 0))
+    lw.W3 = dev(W(conv.B_3))
+    lw.b3 = dev(b(conv.B_3))
     lw.norm, lw.scale_e, lw.shift_e = _norm_affine(conv.bn_e, device)
     kind_h, lw.scale_h, lw.shift_h = _norm_affine(conv.bn_h, device)
     assert kind_h == lw.norm
-    hidden = conv.B_3.weight.shape[0]
     lw.gain_e = float(lw.scale_e.abs().max()) if lw.norm == NORM_AFFINE and lw.scale_e.numel() else 0.0
     can = hip_ops.reference_order_supported(hidden, lw.norm)
     lw.ref = can and (arithmetic == "reference" or (arithmetic == "auto" and lw.gain_e > REFERENCE_ORDER_GAIN))
     if lw.ref:
-        lw.bcat = dev(torch.cat([conv.A_1.bias, conv.A_2.bias, conv.A_3.bias, conv.B_1.bias, conv.B_2.bias], 0))
+        lw.bcat = dev(torch.cat([b(conv.A_1), b(conv.A_2), b(conv.A_3), b(conv.B_1), b(conv.B_2)], 0))
     else:
         # B_3's bias rides on the B2h rows: B1h[src] + (B2h[dst] + b3) + e*W3^T
-        lw.bcat = dev(torch.cat([conv.A_1.bias, conv.A_2.bias, conv.A_3.bias, conv.B_1.bias, conv.B_2.bias + conv.B_3.bias], 0))
+        lw.bcat = dev(torch.cat([b(conv.A_1), b(conv.A_2), b(conv.A_3), b(conv.B_1), b(conv.B_2) + b(conv.B_3)], 0))
     return lw
 
 
@@ -109,17 +146,21 @@ def prepare_predictor(pred, device):
     def dev(t):
         return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
-    hs, h3 = pred.W1.weight.shape
-    hidden = h3 // 3
+    hs_model, h3 = pred.W1.weight.shape
+    width = h3 // 3
     if pred.W2.out_features != 32 or pred.W3.in_features != 32 or pred.W3.out_features != 1:
         raise ValueError("ScorePredictor tail must be hs -> 32 -> 1 (score_predictor.py:9-10)")
-    W1 = dev(pred.W1.weight)
+    hidden, hs = padded_width(width), padded_width(hs_model, BUILT_SCORE_HIDDEN, "hidden_edge_scores")
+    # W1 acts on [x[src] | x[dst] | e]: each of its three [hs, H] blocks padded on its own (zero rows for the padded score
+    # channels - relu(0) = 0 meets a zero column of W2 -, zero columns for the padded hidden channels)
+    W1 = dev(torch.cat([_pad(pred.W1.weight.detach()[:, i * width:(i + 1) * width], hs, hidden) for i in range(3)], 1))
+    b1 = _pad(pred.W1.bias.detach(), hs)
     # node halves stacked into one [2*hs, H] projection: rows 0..hs-1 act on x[src], rows hs.. on x[dst] (+ b1)
     W_nodes = torch.cat([W1[:, :hidden], W1[:, hidden:2 * hidden]], 0).contiguous()
-    b_nodes = torch.cat([torch.zeros_like(pred.W1.bias), pred.W1.bias]).detach()
+    b_nodes = torch.cat([torch.zeros_like(b1), b1])
     return {
-        "hidden": hidden, "hs": hs, "W_nodes": W_nodes, "b_nodes": dev(b_nodes), "W1_e": W1[:, 2 * hidden:],
-        "W2": dev(pred.W2.weight), "b2": dev(pred.W2.bias),
+        "hidden": hidden, "hs": hs, "model_hidden": width, "W_nodes": W_nodes, "b_nodes": dev(b_nodes), "W1_e": W1[:, 2 * hidden:],
+        "W2": dev(_pad(pred.W2.weight.detach(), 32, hs)), "b2": dev(pred.W2.bias),
         "W3": dev(pred.W3.weight.reshape(-1)), "b3": dev(pred.W3.bias.reshape(-1)), "_W1": W1,
     }
 
@@ -355,6 +396,9 @@ def layer_forward_edge_id_order(conv, g, h, e):
     with torch.no_grad():
         hd = h.detach().to(device=device, dtype=torch.float32).contiguous()
         ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
+        width, hidden = hd.shape[1], lw.W3.shape[0]
+        if hidden != width:    # a width between the built ones: zero columns in, sliced off again below (BUILT_HIDDEN)
+            hd, ed = F.pad(hd, (0, hidden - width)), F.pad(ed, (0, hidden - width))
         es = hip_ops.gather_rows(ed, views.srt_eid)
         if views.node_gather is not None:   # views over renumbered nodes: rows in, rows out in the caller's numbering
             hd = hip_ops.gather_rows(hd, views.node_gather)
@@ -363,6 +407,8 @@ def layer_forward_edge_id_order(conv, g, h, e):
             h_new = h_new.index_select(0, views.node_perm)
         e_new = torch.empty_like(es)
         e_new[views.srt_eid.long()] = es
+        if hidden != width:
+            h_new, e_new = h_new[:, :width].contiguous(), e_new[:, :width].contiguous()
         h_new = F.dropout(h_new, conv.dropout, training=conv.training)
     views.check_range()   # deferred endpoint check of a fresh graph (GraphViews validate="lazy")
     return h_new.to(out_device), e_new.to(out_device)
@@ -377,6 +423,8 @@ def score_forward_edge_id_order(pred, graph, x, e):
     with torch.no_grad():
         xd = x.detach().to(device=device, dtype=torch.float32).contiguous()
         ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
+        if pw["hidden"] != pw["model_hidden"]:
+            xd, ed = (F.pad(t, (0, pw["hidden"] - pw["model_hidden"])) for t in (xd, ed))
         es = hip_ops.gather_rows(ed, views.srt_eid)
         if views.node_gather is not None:
             xd = hip_ops.gather_rows(xd, views.node_gather)

@@ -25,9 +25,11 @@ class SymGatedGCN(nn.Module):
                              "(layers/processor.py:12-14); unequal widths are not supported")
         if not residual:
             raise ValueError("residual=False is never used by the reference drivers and is not supported")
-        if in_channels not in (64, 128, 256):
-            raise ValueError(f"hidden_features={in_channels}: the HIP kernels are built for 64 (the reference's default, "
-                             "configs/hyperparameters.py:22), 128 and 256")
+        # built widths: 64 (the reference's default, configs/hyperparameters.py:22), 128, 256; other widths up to 256 run zero-padded
+        # on the next built one in eval mode with BatchNorm (engine.BUILT_HIDDEN) - refused here where that does not apply
+        if engine.padded_width(in_channels) != in_channels and normalization == "layer":
+            raise ValueError(f"hidden_features={in_channels} with normalization='layer': the HIP kernels are built for "
+                             f"{engine.BUILT_HIDDEN}; other widths run zero-padded, which LayerNorm's row statistics do not allow")
         self.dropout = dropout if dropout else 0.0
         self.normalization = normalization
         self.residual = residual
@@ -70,9 +72,10 @@ class SymGatedGCN_processor(nn.Module):
 class ScorePredictor(nn.Module):
     def __init__(self, in_features, hidden_edge_scores):
         super().__init__()
-        if in_features not in (64, 128, 256) or hidden_edge_scores not in (32, 64, 128):
-            raise ValueError(f"ScorePredictor({in_features}, {hidden_edge_scores}): the HIP kernels are built for "
-                             "in_features in {64,128,256} and hidden_edge_scores in {32,64,128} (reference default 64, 64)")
+        # built: in_features in {64,128,256}, hidden_edge_scores in {32,64,128} (reference default 64, 64); anything below the largest
+        # runs zero-padded on the next built width (engine.prepare_predictor), anything above is refused here
+        engine.padded_width(in_features)
+        engine.padded_width(hidden_edge_scores, engine.BUILT_SCORE_HIDDEN, "hidden_edge_scores")
         self.W1 = nn.Linear(3 * in_features, hidden_edge_scores)
         self.W2 = nn.Linear(hidden_edge_scores, 32)
         self.W3 = nn.Linear(32, 1)

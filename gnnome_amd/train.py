@@ -456,6 +456,12 @@ def train_forward_on(model, shard, x_local, e_local):
     e_local are the input features of the shard's nodes / edges (local edge-id order).  Returns logits[E_global, 1],
     complete on every rank, differentiable w.r.t. the model's parameters; the parameter gradients that
     `backward()` leaves in `.grad` are already summed over ranks."""
+    from .engine import BUILT_HIDDEN, BUILT_SCORE_HIDDEN
+    H, hs = model.linear2_node.out_features, model.predictor.W1.out_features
+    if H not in BUILT_HIDDEN or hs not in BUILT_SCORE_HIDDEN:
+        # (inference pads other widths with zeros, engine.BUILT_HIDDEN; the step reads the module's own parameters)
+        raise NotImplementedError(f"train mode at hidden_features={H}, hidden_edge_scores={hs}: the training step is built for "
+                                  f"hidden_features in {BUILT_HIDDEN} and hidden_edge_scores in {BUILT_SCORE_HIDDEN}")
     names = [n for n, _ in model.named_parameters()]
     params = [p for _, p in model.named_parameters()]
     if any(p.device != x_local.device for p in params):

@@ -531,7 +531,7 @@ def test_gather_rows():
 # ------------------------------------------------------------------------------------ whole model
 
 def _model(sd, hidden, normalization="batch", layers=8):
-    m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, layers, 64, normalization).eval()
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, layers, sd["predictor.W1.weight"].shape[0], normalization).eval()
     m.load_state_dict(sd)
     return m.to(dev())
 
@@ -575,6 +575,57 @@ def test_goldens_wider_hidden_and_layernorm():
     sd = {k: v for k, v in random_state_dict(64, seed=g["seed"]).items() if "running_" not in k and "num_batches" not in k}
     out = _model(sd, 64, "layer")((g["src"], g["dst"], g["num_nodes"]), g["x"].to(dev()), g["e"].to(dev()))
     assert _prob_diff(out, g["logits"]) < PROB_TOL
+
+
+def test_widths_between_the_built_ones():
+    """hidden_features / hidden_edge_scores the kernels are not built for (the reference takes any, configs/hyperparameters.py:22-24) run on the
+    next built width with zero-padded parameters (engine.BUILT_HIDDEN): the reference's own logits (golden G11), the oracle at 20k / 200k, the
+    layer- and predictor-level entries at their reference shapes, the hipGraph replay and the partitioned runner."""
+    from gnnome_amd import dist as gdist
+    from gnnome_amd.capture import CapturedForward
+    g = load_golden("g11_widths.pt")
+    graph = (g["src"], g["dst"], g["num_nodes"])
+    for case in g["cases"]:
+        sd = random_state_dict(case["hidden"], num_layers=case["layers"], hidden_edge_scores=case["hs"], seed=case["seed"])
+        m = _model(sd, case["hidden"], layers=case["layers"])
+        out = m(graph, g["x"].to(dev()), g["e"].to(dev()))
+        assert out.shape == case["logits"].shape and _prob_diff(out, case["logits"]) < PROB_TOL
+        cap = CapturedForward(m, graph, g["x"].to(dev()), g["e"].to(dev()))
+        assert torch.equal(cap(), out)
+    # layer- and predictor-level API: [N,96] / [E,96] rows in and out, against the oracle's layer
+    hidden, hs = 96, 48
+    sd = random_state_dict(hidden, num_layers=2, hidden_edge_scores=hs, seed=3)
+    om = model_from_state_dict(sd).eval()
+    m = _model(sd, hidden, layers=2)
+    gen = torch.Generator().manual_seed(2)
+    h = torch.randn(g["num_nodes"], hidden, generator=gen)
+    e = torch.randn(g["src"].numel(), hidden, generator=gen)
+    with torch.no_grad():
+        wh, we = om._layer_forward(om.gnn.convs[0], g["src"].long(), g["dst"].long(), g["num_nodes"], h, e)
+        ws = om._score(g["src"].long(), g["dst"].long(), h, e)
+        gh, ge = m.gnn.convs[0](graph, h.to(dev()), e.to(dev()))
+        gs = m.predictor(graph, h.to(dev()), e.to(dev()))
+    assert gh.shape == wh.shape and ge.shape == we.shape and gs.shape == ws.shape
+    _assert_close(gh, wh.double(), tol=2e-5)
+    _assert_close(ge, we.double(), tol=2e-5)
+    _assert_close(gs, ws.double(), tol=2e-5)
+    # mid size against the oracle, and the same model through the partitioned kernel sequence (dist.py)
+    n, ec = 20000, 200000
+    gr = make_graph(n, ec, seed=4, kind="banded")
+    x = degree_features(gr["src"], gr["dst"], n)
+    for hidden, hs in ((96, 48), (200, 100)):
+        sd = random_state_dict(hidden, num_layers=4, hidden_edge_scores=hs, seed=5)
+        with torch.no_grad():
+            want = model_from_state_dict(sd).eval()((gr["src"], gr["dst"], n), x, gr["e"])
+        m = _model(sd, hidden, layers=4)
+        got = m((gr["src"], gr["dst"], n), x.to(dev()), gr["e"].to(dev()))
+        assert _prob_diff(got, want) < PROB_TOL
+        part = gdist.PartitionedGraph.from_global(gr["src"], gr["dst"], n, 0, 1, dev())
+        assert torch.equal(gdist.PartitionedRunner(m, part, x, gr["e"], dev()).forward(), got)
+    # refused: train mode at such a width
+    m.train()
+    with pytest.raises(NotImplementedError, match="train mode at hidden_features=200"):
+        m((gr["src"], gr["dst"], n), x.to(dev()), gr["e"].to(dev()))
 
 
 def test_golden_reversed_graph_both_ways():

@@ -78,7 +78,7 @@ def test_no_cpu_fallback():
 
 def _host_forward(sd, g, normalization="batch", reverse=False, layers=8):
     hidden = sd["linear2_node.weight"].shape[0]
-    m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, layers, 64, normalization).eval()
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, layers, sd["predictor.W1.weight"].shape[0], normalization).eval()
     m.load_state_dict(sd)
     prep = engine.Prepared(m, CPU)
     views = cpu_ops.CpuViews(g["src"], g["dst"], g["num_nodes"])
@@ -113,6 +113,34 @@ def test_host_sequence_layernorm_and_reversed_graph():
     _close(_host_forward(sd, g), g["logits"])
     # dgl.reverse(g, True, True) (train.py:165) through the free "transposed" views
     _close(_host_forward(sd, g, reverse=True), g["logits_rev"])
+
+
+def test_widths_between_the_built_ones_run_zero_padded():
+    """hidden_features / hidden_edge_scores outside {64,128,256} / {32,64,128} (the reference takes any): eval-mode BatchNorm models
+    run on the next built width with zero-padded parameters - against the reference's own logits (golden G11) - and the cases
+    padding cannot serve are refused: LayerNorm (row statistics), train mode, widths above the largest built one."""
+    g = load_golden("g11_widths.pt")
+    for case in g["cases"]:
+        sd = random_state_dict(case["hidden"], num_layers=case["layers"], hidden_edge_scores=case["hs"], seed=case["seed"])
+        _close(_host_forward(sd, g, layers=case["layers"]), case["logits"], tol=2e-6)
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, case["hidden"], 16, case["layers"], case["hs"], "batch").eval()
+        m.load_state_dict(sd)
+        prep = engine.Prepared(m, CPU)
+        H, hs = engine.padded_width(case["hidden"]), engine.padded_width(case["hs"], engine.BUILT_SCORE_HIDDEN)
+        assert prep.hidden == H and prep.model_hidden == case["hidden"] and prep.predictor["hs"] == hs
+        assert prep.layers[0].Wcat.shape == (5 * H, H) and prep.predictor["W_nodes"].shape == (2 * hs, H)
+        assert list(m.state_dict().keys()) == list(sd.keys())     # the module itself keeps the reference's shapes
+    assert [engine.padded_width(w) for w in (1, 64, 65, 128, 129, 256)] == [64, 64, 128, 128, 256, 256]
+    with pytest.raises(ValueError, match="up to 256"):
+        gnnome_amd.models.SymGatedGCNModel(2, 2, 257, 16, 1, 64, "batch")
+    with pytest.raises(ValueError, match="up to 128"):
+        gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 1, 129, "batch")
+    with pytest.raises(ValueError, match="LayerNorm"):
+        gnnome_amd.models.SymGatedGCNModel(2, 2, 96, 16, 1, 64, "layer")
+    from gnnome_amd.train import train_forward_on
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 96, 16, 1, 64, "batch").train()
+    with pytest.raises(NotImplementedError, match="train mode at hidden_features=96"):
+        train_forward_on(m, None, torch.zeros(2, 2), torch.zeros(1, 2))
 
 
 def test_views_definition():

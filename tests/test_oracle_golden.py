@@ -45,6 +45,21 @@ def test_g2_uniform_per_layer(shipped_weights):
         assert abs(e.double().sum().item() - want["e_sum"]) <= 1e-6 * e.double().abs().sum().item() + 1e-6
 
 
+def test_g11_widths_between_the_built_ones():
+    """hidden_features / hidden_edge_scores the HIP kernels are not built for (the reference takes any): the oracle pinned there too,
+    so that the padded HIP path (engine.BUILT_HIDDEN) has a checker at those widths."""
+    g = load_golden("g11_widths.pt")
+    for case in g["cases"]:
+        sd = random_state_dict(case["hidden"], num_layers=case["layers"], hidden_edge_scores=case["hs"], seed=case["seed"])
+        m = model_from_state_dict(sd).eval()
+        tr = []
+        with torch.no_grad():
+            out = m((g["src"], g["dst"], g["num_nodes"]), g["x"], g["e"], trace=tr)
+        _check(out, case["logits"])
+        assert torch.allclose(tr[-1][0][:32], case["h_final_rows"], atol=1e-5, rtol=1e-5)
+        assert torch.allclose(tr[-1][1][:32], case["e_final_rows"], atol=1e-4, rtol=1e-5)
+
+
 def test_g3_train_step_grads_and_bn_buffers():
     g = load_golden("g3_train_h64.pt")
     m = OracleModel(2, 2, 64, 16, 8, 64, "batch", dropout=0.0)
