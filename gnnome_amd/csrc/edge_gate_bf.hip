@@ -565,18 +565,31 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
             f32x16 acc, accC;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f, accC[r] = 0.f;
-            uint4 c1 = *reinterpret_cast<const uint4*>(ap), c2 = *reinterpret_cast<const uint4*>(ap + PLANE), c3 = c1;
-            if (!F16) c3 = *reinterpret_cast<const uint4*>(ap + 2 * PLANE);
+            // Plane fragments PD k steps ahead of their MFMAs.  F16 (round 4): three steps - hipcc had sunk the one-step-ahead reads to two MFMAs
+            // (~70 cycles) before their use, an LDS read under this kernel's traffic takes longer than that, and the matrix pipe idled at every wait
+            // (1205 cycles per tile for 24 MFMAs of 32); the scheduling barriers keep the reads where they are written.
+            constexpr int PD = F16 ? 3 : 1;
+            uint4 f1[KS], f2[KS], f3[F16 ? 1 : KS];
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                f1[q] = *reinterpret_cast<const uint4*>(ap + 32 * q);
+                f2[q] = *reinterpret_cast<const uint4*>(ap + 32 * q + PLANE);
+                if (!F16) f3[q] = *reinterpret_cast<const uint4*>(ap + 32 * q + 2 * PLANE);
+            }
 #pragma unroll
             for (int q = 0; q < KS; ++q) {
-                const int qn = q + 1 < KS ? q + 1 : q;
-                const uint4 n1 = *reinterpret_cast<const uint4*>(ap + 32 * qn), n2 = *reinterpret_cast<const uint4*>(ap + 32 * qn + PLANE);
-                uint4 n3 = n1;
-                if (!F16) n3 = *reinterpret_cast<const uint4*>(ap + 32 * qn + 2 * PLANE);
+                if (q + PD < KS) {
+                    f1[q + PD] = *reinterpret_cast<const uint4*>(ap + 32 * (q + PD));
+                    f2[q + PD] = *reinterpret_cast<const uint4*>(ap + 32 * (q + PD) + PLANE);
+                    if (!F16) f3[q + PD] = *reinterpret_cast<const uint4*>(ap + 32 * (q + PD) + 2 * PLANE);
+                }
+                if (F16) __builtin_amdgcn_sched_barrier(0);
+                const uint4 c1 = f1[q], c2 = f2[q], c3 = F16 ? c1 : f3[F16 ? 0 : q];
                 if (F16) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c1), as_h8(w1[q]), acc, 0, 0, 0);
                     accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c1), as_h8(w2[q]), accC, 0, 0, 0);
                     accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c2), as_h8(w1[q]), accC, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 } else {
                     // smallest terms first
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c3), as_bf(w1[q]), acc, 0, 0, 0);
@@ -586,9 +599,6 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w2[q]), acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(c1), as_bf(w1[q]), acc, 0, 0, 0);
                 }
-                c1 = n1;
-                c2 = n2;
-                c3 = n3;
             }
             if (F16) {
 #pragma unroll
@@ -734,6 +744,11 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
             flag_bump_bf(full0 + 4 * group, lane);
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_split += t1 - t0; t0 = t1; }
             if (r + RING < n) issue_early(r + RING);
+            // MODE 4 (round 4): the A rows of this group's NEXT tile are requested here, ahead of the wait for the compute waves and of the epilogue's
+            // stores - the loads then precede those stores in the in-order memory counter and have ~5000 cycles to arrive (phase counters before:
+            // 2040 cycles per own tile waiting for rows requested after the epilogue); the other modes hold too many registers across the epilogue
+            constexpr bool kFetchAhead = MODE == 4;
+            if (kFetchAhead && r + RING < n && !(a.xp & 32)) fetch_e(r + RING);
             flag_wait_bf(done0 + 4 * group, 4u * use, a.xp & 3);
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_done += t1 - t0; t0 = t1; }
             const int valid = tile_valid(r);
@@ -790,7 +805,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_epi += t1 - t0; }
             if (r + RING < n) {   // (woven into the epilogue piece by piece, the e-row fetch made the epilogue 1200 cycles longer and
                                   //  arrived no earlier: loads and stores share one in-order counter)
-                if (!ENC) fetch_e(r + RING);
+                if (!ENC && !(kFetchAhead && !(a.xp & 32))) fetch_e(r + RING);
                 issue_late(r + RING);
                 if (ENC) encode_pending();
             }

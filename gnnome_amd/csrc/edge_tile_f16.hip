@@ -295,18 +295,32 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
             f32x16 accM, accC;
 #pragma unroll
             for (int r = 0; r < 16; ++r) accM[r] = 0.f, accC[r] = 0.f;
-            uint4 c1 = *reinterpret_cast<const uint4*>(ap), c2 = *reinterpret_cast<const uint4*>(ap + 2 * H);
+            // Plane fragments PD k steps ahead of their MFMAs, and the scheduling barriers that keep them there: hipcc sinks LDS reads to the
+            // instruction before their use, and a read issued one or two MFMAs ahead had every k step wait for its LDS round trip (2963 cycles
+            // per tile in this loop for 48 MFMAs of 32 - the matrix pipe idle half of the time).
+            constexpr int PD = 3;
+            uint4 f1[KS], f2[KS];
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                f1[q] = *reinterpret_cast<const uint4*>(ap + 32 * q);
+                f2[q] = *reinterpret_cast<const uint4*>(ap + 32 * q + 2 * H);
+            }
             f32x4 raw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < KS; ++q) {
-                const int qn = q + 1 < KS ? q + 1 : q;
-                const uint4 n1 = *reinterpret_cast<const uint4*>(ap + 32 * qn), n2 = *reinterpret_cast<const uint4*>(ap + 32 * qn + 2 * H);
+                if (q + PD < KS) {
+                    f1[q + PD] = *reinterpret_cast<const uint4*>(ap + 32 * (q + PD));
+                    f2[q + PD] = *reinterpret_cast<const uint4*>(ap + 32 * (q + PD) + 2 * H);
+                }
                 if ((q & 1) == 0) {
                     if (!(PROBE & 1)) dma_piece();
                     if (!(PROBE & 2) && !EPI_CONV) raw = row_read(j + 1, q >> 1);        // tile j + 1, this wave's row q / 2 ...
-                } else {
-                    if (!(PROBE & 2) && !EPI_CONV) row_write(j + 1, q >> 1, raw);        // ... becomes planes a step later
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if ((q & 1) != 0) {
+                    if (!(PROBE & 2) && !EPI_CONV) row_write(j + 1, q >> 1, raw);        // ... becomes planes a step later (under this step's MFMAs)
+                }
+                const uint4 c1 = f1[q], c2 = f2[q];
                 if (PROBE & 4) {
                     accM[q] += __uint_as_float(c1.x ^ c2.y ^ __builtin_bit_cast(uint4, w1[q]).x ^ __builtin_bit_cast(uint4, w2[q]).y);
                 } else {
@@ -314,8 +328,7 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
                     accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c1), w2[q], accC, 0, 0, 0);
                     accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c2), w1[q], accC, 0, 0, 0);
                 }
-                c1 = n1;
-                c2 = n2;
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (!EPI_CONV) flag_bump(full0 + 4 * ((j + 1) % NS), lane);   // my rows of tile j + 1 are planes, my reads of tile j are issued
             if (a.prof) { asm volatile("" ::"v"(accM[0])); t1 = __builtin_readcyclecounter(); t_loop += t1 - t0; t0 = t1; }

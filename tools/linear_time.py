@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Launch time of the node projection [N,H] x [H,5H] (gnnome_linear_f32) per kernel variant (gnnome_set_tuning key 2)."""
+"""Launch time of the node projection [N,H] x [H,5H] (gnnome_linear_f32) per kernel variant (gnnome_set_tuning key 2, or the key given as the
+fourth argument: `linear_time.py 128 100000 0,1 11` = stores from the compute waves against the x-tile route)."""
 import os
 import sys
 
@@ -12,6 +13,7 @@ dev = torch.device("cuda", 0)
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
 variants = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "0,4,5,3,2".split(","))]
+key = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 gen = torch.Generator(device=dev).manual_seed(0)
 h = torch.randn(n, H, device=dev, generator=gen)
 W = torch.randn(5 * H, H, device=dev, generator=gen)
@@ -20,7 +22,7 @@ out = torch.empty(n, 5 * H, device=dev)
 ref = None
 for rnd in range(3):
     for v in variants:
-        ops.set_tuning(2, v)
+        ops.set_tuning(key, v)
         for _ in range(3):
             ops.linear(h, W, b, out=out)
         evs = []
@@ -35,4 +37,4 @@ for rnd in range(3):
         if ref is None:
             ref = out.clone()
         print(f"round {rnd} variant {v}: median {ts[len(ts) // 2]:.4f} ms  min {ts[0]:.4f} ms  max|diff to variant {variants[0]}| {(out - ref).abs().max().item():.2e}", flush=True)
-ops.set_tuning(2, 0)
+ops.set_tuning(key, 0)

@@ -53,6 +53,19 @@ __global__ __launch_bounds__(256) void k_read_rows(const f32x4* __restrict__ buf
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = acc[0];
 }
 
+// write side (round 4): the set split over the workgroups and written once with 16-byte stores, wave-contiguous 1 KB per instruction;
+// `read_every` > 0 also reads one 16-byte piece per `read_every` written (read_every = 5: the node projection's 1 : 5 mix of h rows in, P rows out)
+__global__ __launch_bounds__(256) void k_write_split(f32x4* __restrict__ buf, const f32x4* __restrict__ src, size_t n_vec, int read_every) {
+    const size_t per = (n_vec + gridDim.x - 1) / gridDim.x;
+    const size_t lo = per * blockIdx.x, hi = lo + per < n_vec ? lo + per : n_vec;
+    f32x4 v = {1.f, 2.f, 3.f, 4.f};
+    size_t k = 0;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256, ++k) {
+        if (read_every > 0 && k % read_every == 0) v += src[(lo / read_every + k / read_every * 256 + threadIdx.x) % ((1ull << 30) / 16)];   // (src is 1 GB)
+        buf[i] = v;
+    }
+}
+
 int main() {
     const size_t max_bytes = 2ull << 30;
     f32x4* buf;
@@ -106,6 +119,37 @@ int main() {
             const double moved = (double)grid * 4 * rows_per_wave * 512.0;   // rows_per_wave rows per wave (2 per instruction)
             printf("set %6zu MB  random 512-byte rows               : %8.2f TB/s\n", bytes >> 20, moved / (ms * 1e-3) / 1e12);
         }
+    }
+    // write side: 256 MB (the projection's output at configs[1]), 512 MB (the gate's), 2 GB
+    f32x4* src;
+    hipMalloc(&src, 1ull << 30);
+    hipMemset(src, 0, 1ull << 30);
+    for (size_t bytes : {256ull << 20, 512ull << 20, 2ull << 30}) {
+        for (int read_every : {0, 5, 1}) {
+            const size_t n_vec = bytes / 16;
+            float ms = 0, best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                hipEventRecord(a);
+                hipLaunchKernelGGL(k_write_split, dim3(grid), dim3(256), 0, 0, buf, src, n_vec, read_every);
+                hipEventRecord(b);
+                hipEventSynchronize(b);
+                hipEventElapsedTime(&ms, a, b);
+                if (rep > 0 && ms < best) best = ms;
+            }
+            const double moved = (double)bytes * (read_every ? 1.0 + 1.0 / read_every : 1.0);
+            printf("write %5zu MB once, 16 B per lane, %s: %8.2f TB/s (%.4f ms)\n", bytes >> 20,
+                   read_every == 0 ? "stores only           " : read_every == 5 ? "1 read per 5 stores   " : "1 read per store (copy)", moved / (best * 1e-3) / 1e12, best);
+        }
+        float ms = 0, best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(a);
+            hipMemsetAsync(buf, 0, bytes, 0);
+            hipEventRecord(b);
+            hipEventSynchronize(b);
+            hipEventElapsedTime(&ms, a, b);
+            if (rep > 0 && ms < best) best = ms;
+        }
+        printf("write %5zu MB once, hipMemsetAsync                        : %8.2f TB/s (%.4f ms)\n", bytes >> 20, (double)bytes / (best * 1e-3) / 1e12, best);
     }
     return 0;
 }
