@@ -920,6 +920,7 @@ __global__ __launch_bounds__(640) void k_edge_gate_enc16(GateBfArgs a) {
         }
         auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
         const int lane_x = 4 * half * LDK + col;
+        const float bxc = consts[2 * H + col], bec = consts[3 * H + col];
         for (int i = 0; i < n; ++i) {
             const int slot = i % RING;
             const unsigned use = (unsigned)(i / RING) + 1u;
@@ -946,8 +947,8 @@ __global__ __launch_bounds__(640) void k_edge_gate_enc16(GateBfArgs a) {
             float* X = reinterpret_cast<float*>(ring + slot * SLOTB + 3 * TPLANE) + lane_x;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                X[crow(r) * LDK] = ax[r];
-                X[TILEF + crow(r) * LDK] = ae[r];
+                X[crow(r) * LDK] = ax[r] + bxc;          // (+ b23 / + b2 here, one column per lane, rather than as two more float4
+                X[TILEF + crow(r) * LDK] = ae[r] + bec;  //  constants in the store waves: the same two additions, the same bits)
             }
             flag_bump_bf(done0 + 4 * slot, lane);
         }
@@ -981,9 +982,15 @@ __global__ __launch_bounds__(640) void k_edge_gate_enc16(GateBfArgs a) {
                 g2[p] = *reinterpret_cast<const f32x4*>(a.B2h + (int64_t)di[p] * a.ldn + 4 * c4);
             }
         };
+        // Order of a group's requests (round 4): the gathers of its NEXT tile go out before the epilogue of the current one, from indices that were
+        // fetched a tile earlier still - g1 / g2 are free once G is summed, the loads precede the epilogue's stores in the in-order memory counter,
+        // and they have the wait for the compute waves + the epilogue to arrive.  Before, indices -> gathers -> use were strung out behind each
+        // epilogue and a group spent most of its cycle waiting for them: with three groups and half the gate's memory traffic this launch was bound
+        // by that chain (0.19 ms against 0.09 ms of store time), not by memory.
         if (group < n) {
             issue_early(group);
             issue_late();
+            if (group + RING < n) issue_early(group + RING);
         }
         unsigned char* S = ring + group * SLOTB;
         const float* Xs = reinterpret_cast<const float*>(S + 3 * TPLANE);
@@ -1009,31 +1016,31 @@ __global__ __launch_bounds__(640) void k_edge_gate_enc16(GateBfArgs a) {
                 asm volatile("" : "+v"(gk[p]));   // summed here, not in the epilogue (see k_edge_gate_pl)
             }
             flag_bump_bf(full0 + 4 * group, lane);
-            if (r + RING < n) issue_early(r + RING);
+            if (r + RING < n) issue_late();                       // tile r + RING: its indices arrived during the previous iteration
+            if (r + 2 * RING < n) issue_early(r + 2 * RING);
             flag_wait_bf(done0 + 4 * group, 4u * use, a.xp & 3);
             const int valid = tile_valid(r);
             const f32x4 sc4 = *reinterpret_cast<const f32x4*>(consts + 4 * c4), sh4 = *reinterpret_cast<const f32x4*>(consts + H + 4 * c4);
-            const f32x4 bx4 = *reinterpret_cast<const f32x4*>(consts + 2 * H + 4 * c4), be4 = *reinterpret_cast<const f32x4*>(consts + 3 * H + 4 * c4);
             float* out = a.e_out + (int64_t)tile_of(r) * TM * H;
+            // (two pieces per LDS round trip, not four: the next tile's 64 gather registers are live across this epilogue now)
 #pragma unroll
-            for (int pb = 0; pb < NP; pb += 4) {
-                f32x4 x[4], e0[4];
+            for (int pb = 0; pb < NP; pb += 2) {
+                f32x4 x[2], e0[2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     x[u] = *reinterpret_cast<const f32x4*>(Xs + (r0 + (pb + u) * RSTEP) * LDK + 4 * c4);
                     e0[u] = *reinterpret_cast<const f32x4*>(Xs + TILEF + (r0 + (pb + u) * RSTEP) * LDK + 4 * c4);
                 }
-                asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+                asm volatile("" : "+v"(x[0]), "+v"(x[1]));
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 2; ++u) {
                     const int p = pb + u, row = r0 + p * RSTEP;
                     f32x4 y;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) y[j] = fmaxf(((x[u][j] + bx4[j]) + gk[p][j]) * sc4[j] + sh4[j], 0.f) + (e0[u][j] + be4[j]);
+                    for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + gk[p][j]) * sc4[j] + sh4[j], 0.f) + e0[u][j];
                     if (row < valid) *reinterpret_cast<f32x4*>(out + (off_row + (unsigned)(p * RSTEP * H))) = y;
                 }
             }
-            if (r + RING < n) issue_late();
         }
     }
 }
