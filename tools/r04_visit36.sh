@@ -1,5 +1,5 @@
 #!/bin/bash
-# H = 256 edge-tile kernel: plane fragments three k steps ahead of their MFMAs (new) against hipcc's placement (prev)
+# H = 256 edge-tile kernel: A/B of two builds (build/ab/prev.so, new.so)
 mkdir -p gpurun_out/v36
 timeout 900 python -m pytest tests/test_hip_parity.py tests/test_edge_tile_f16.py -x -q -m gpu -k "256 or f16 or linear or goldens or folded" > gpurun_out/v36/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/v36/pytest.log
 tail -3 gpurun_out/v36/pytest.log
