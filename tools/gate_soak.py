@@ -105,6 +105,13 @@ for it in range(launches):
         Bm = torch.randn(rows, 256, generator=gen).to(dev)
         got = ops.wgrad(A, Bm).double() / rows ** 0.5
         want = (A.double().t() @ Bm.double()) / rows ** 0.5
+    elif mode == 0 and H == 128 and kind % 2 == 1:   # layer 0 with the edge encoder folded (k_edge_gate_enc16: its own ring and request order) against the unfused pair
+        e_raw = torch.randn(E, 2, generator=gen).to(dev)
+        enc = tuple(t.to(dev) for t in (torch.randn(16, 2, generator=gen), torch.randn(16, generator=gen), torch.randn(H, 16, generator=gen) / 4,
+                                        torch.randn(H, generator=gen)))
+        got = ops.edge_gate_encode(e_raw, enc, B1, B2, views, W3, sc, sh)
+        e0 = ops.encode(e_raw, *enc, gather=views.srt_eid)
+        want = ops.edge_gate(e0, B1, B2, views, W3, 0, sc, sh, out=torch.empty_like(e0))
     elif mode == 0:    # the gate, in place and out of place
         got = ops.edge_gate(e.clone(), B1, B2, views, W3, 0, sc, sh)
         ops.set_tuning(0, 6)
