@@ -40,7 +40,7 @@ ARITHMETIC_MODES = ("auto", "reference", "fast")
 # an eval-mode BatchNorm model of another width runs on the next built width with ZERO-PADDED parameters, which is exact: a padded
 # channel has zero weights, zero bias and a zero affine norm, so it stays 0.0 through relu + residual, enters every product as a
 # zero addend at the END of the k-ascending sums, and the aggregation's padded columns are sums of 0.5 * 0.0.  (LayerNorm's statistics run
-# over the row, and train-mode parameters are read from the module itself: both stay with the built widths.)
+# over the row: it stays with the built widths.  Train mode pads the same way on a twin model, train._padded_step.)
 BUILT_HIDDEN = (64, 128, 256)
 BUILT_SCORE_HIDDEN = (32, 64, 128)
 

@@ -26,7 +26,7 @@ class SymGatedGCN(nn.Module):
         if not residual:
             raise ValueError("residual=False is never used by the reference drivers and is not supported")
         # built widths: 64 (the reference's default, configs/hyperparameters.py:22), 128, 256; other widths up to 256 run zero-padded
-        # on the next built one in eval mode with BatchNorm (engine.BUILT_HIDDEN) - refused here where that does not apply
+        # on the next built one with BatchNorm (engine.BUILT_HIDDEN; train mode: train._padded_step) - refused here where that does not apply
         if engine.padded_width(in_channels) != in_channels and normalization == "layer":
             raise ValueError(f"hidden_features={in_channels} with normalization='layer': the HIP kernels are built for "
                              f"{engine.BUILT_HIDDEN}; other widths run zero-padded, which LayerNorm's row statistics do not allow")

@@ -456,14 +456,78 @@ def train_forward_on(model, shard, x_local, e_local):
     e_local are the input features of the shard's nodes / edges (local edge-id order).  Returns logits[E_global, 1],
     complete on every rank, differentiable w.r.t. the model's parameters; the parameter gradients that
     `backward()` leaves in `.grad` are already summed over ranks."""
-    from .engine import BUILT_HIDDEN, BUILT_SCORE_HIDDEN
+    from .engine import BUILT_HIDDEN
     H, hs = model.linear2_node.out_features, model.predictor.W1.out_features
-    if H not in BUILT_HIDDEN or hs not in BUILT_SCORE_HIDDEN:
-        # (inference pads other widths with zeros, engine.BUILT_HIDDEN; the step reads the module's own parameters)
-        raise NotImplementedError(f"train mode at hidden_features={H}, hidden_edge_scores={hs}: the training step is built for "
-                                  f"hidden_features in {BUILT_HIDDEN} and hidden_edge_scores in {BUILT_SCORE_HIDDEN}")
     names = [n for n, _ in model.named_parameters()]
     params = [p for _, p in model.named_parameters()]
     if any(p.device != x_local.device for p in params):
         raise RuntimeError("training needs the model on the compute device: call model.to(device) first")
+    if H not in BUILT_HIDDEN or (hs not in TRAIN_SCORE_HIDDEN and hs <= TRAIN_SCORE_HIDDEN[-1]):
+        return _padded_step(model, shard, x_local, e_local, names, params)
     return _TrainStep.apply(model, shard, x_local, e_local, names, *params)
+
+
+TRAIN_SCORE_HIDDEN = (32, 64)   # hidden_edge_scores the scorer's backward is built for (gnnome_score_tail_bwd_f32; inference also takes 128)
+
+
+def _pad_like(p, shape):
+    """p in the leading corner of zeros of `shape` - a differentiable op, so gradients of the padded tensor flow back to p sliced."""
+    pads = []
+    for have, want in zip(reversed(p.shape), reversed(tuple(shape))):
+        pads += [0, want - have]
+    return torch.nn.functional.pad(p, pads) if any(pads) else p
+
+
+def _padded_step(model, shard, x_local, e_local, names, params):
+    """The training step of a model whose widths lie BETWEEN the built ones (the reference takes any hidden_features / hidden_edge_scores,
+    configs/hyperparameters.py:22-24; engine.BUILT_HIDDEN): run on a twin of the next built widths whose parameters are zero-padded,
+    DIFFERENTIABLE functions of the model's own - exact, like the padded inference path: a padded channel carries zero weights, gamma = beta = 0
+    and constant-zero activations (batch mean 0, variance 0, x_hat = 0), so its relu mask is off, every gradient that reaches it is zero, and
+    the gradients of the padded tensors arrive at the model's parameters sliced by autograd.  BatchNorm models only (LayerNorm's statistics
+    run over the row - refused at construction, layers.py)."""
+    from .engine import padded_width
+    from .models import SymGatedGCNModel
+    conv0 = model.gnn.convs[0]
+    if not isinstance(conv0.bn_e, torch.nn.BatchNorm1d):
+        raise ValueError("train mode at a width between the built ones needs normalization='batch' (zero-padding does not commute with LayerNorm)")
+    H, hs = model.linear2_node.out_features, model.predictor.W1.out_features
+    if hs > TRAIN_SCORE_HIDDEN[-1]:
+        raise ValueError(f"train mode at hidden_edge_scores={hs}: the scorer's backward is built for widths up to {TRAIN_SCORE_HIDDEN[-1]}")
+    Hp, hsp = padded_width(H), padded_width(hs, TRAIN_SCORE_HIDDEN, "hidden_edge_scores")
+    dev = params[0].device
+    twin = model.__dict__.get("_gnnome_padded_twin")
+    if twin is None or next(twin.parameters()).device != dev:
+        twin = SymGatedGCNModel(model.linear1_node.in_features, model.linear1_edge.in_features, Hp, model.linear1_node.out_features,
+                                len(model.gnn.convs), hsp, "batch", dropout=conv0.dropout).to(dev)
+        model.__dict__["_gnnome_padded_twin"] = twin
+    twin.train()
+    for attr in ("activation_storage", "recompute_gate", "node_order"):
+        if hasattr(model, attr):
+            setattr(twin, attr, getattr(model, attr))
+    for conv, tconv in zip(model.gnn.convs, twin.gnn.convs):
+        tconv.dropout = conv.dropout
+    tparams = dict(twin.named_parameters())
+    padded = []
+    for name, p in zip(names, params):
+        t = tparams[name]
+        if name == "predictor.W1.weight":   # [hs, 3 H]: the x[src] | x[dst] | e blocks are padded one by one
+            q = torch.cat([_pad_like(p[:, i * H:(i + 1) * H], (hsp, Hp)) for i in range(3)], 1)
+        else:
+            q = _pad_like(p, t.shape)
+        with torch.no_grad():
+            t.copy_(q)          # what the kernels read; autograd sees `q`
+        padded.append(q)
+    mbufs, tbufs = dict(model.named_buffers()), dict(twin.named_buffers())
+    with torch.no_grad():
+        for k, b in mbufs.items():
+            tb = tbufs[k]
+            if b.dim() == 0:
+                tb.copy_(b)
+            else:
+                tb.fill_(1.0 if k.endswith("running_var") else 0.0)
+                tb[:b.shape[0]].copy_(b)
+    out = _TrainStep.apply(twin, shard, x_local, e_local, names, *padded)
+    with torch.no_grad():       # the running statistics the step has just updated, back into the model's own buffers
+        for k, b in mbufs.items():
+            b.copy_(tbufs[k] if b.dim() == 0 else tbufs[k][:b.shape[0]])
+    return out

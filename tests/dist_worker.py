@@ -43,7 +43,7 @@ def worker(rank, world, port, case, out_dir):
             torch.save({"sent": rows.cpu(), "got": got.cpu(), "summed": summed.cpu(), "every": every.cpu(), "ints": ints.cpu(),
                         "backend": dist.get_backend()}, os.path.join(out_dir, f"rank{rank}.pt"))
             return
-        m = gnnome_amd.models.SymGatedGCNModel(2, 2, g["hidden"], 16, g["layers"], 64, g.get("normalization", "batch"), dropout=0.0).eval()
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, g["hidden"], 16, g["layers"], g.get("hs", 64), g.get("normalization", "batch"), dropout=0.0).eval()
         m.load_state_dict(g["state_dict"])
         if g.get("device") == "cuda":
             # both ranks on the one GPU of the test box: HIP kernels as compute, gloo (host-staged) as transport

@@ -303,3 +303,39 @@ def test_partition_over_renumbered_nodes_gives_the_same_logits_and_a_banded_cut(
     for o in outs:
         assert o["sliced_equal"] and (torch.sigmoid(o["logits"]) - torch.sigmoid(want)).abs().max().item() < 1e-4
         assert o["n_local"] - o["n_own"] < 0.1 * n and o["e_local"] < 0.55 * e       # banded halo, banded replication
+
+
+def test_partitioned_forward_and_training_step_at_a_width_between_the_built_ones(tmp_path):
+    """hidden_features = 96 / hidden_edge_scores = 48 (the reference takes any width; engine.BUILT_HIDDEN, train._padded_step) over a two-rank
+    destination-range partition on the checker backend: eval logits against the oracle, and the train-mode step - loss, gradients in the
+    model's own shapes, identical on both ranks - against the oracle's autograd."""
+    from oracle.symgated_oracle import OracleModel, bce_loss
+    n, e, layers, hidden, hs = 300, 3000, 2, 96, 48
+    gr = make_graph(n, e, seed=8, kind="banded")
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(hidden, num_layers=layers, hidden_edge_scores=hs, seed=9)
+    om = OracleModel(2, 2, hidden, 16, layers, hs, "batch", dropout=0.0)
+    om.load_state_dict(sd)
+    om.eval()
+    with torch.no_grad():
+        want_eval = om((gr["src"], gr["dst"], n), x, gr["e"]).squeeze(-1)
+    om.train()
+    want = om((gr["src"], gr["dst"], n), x, gr["e"])
+    want_loss = bce_loss(want, gr["y"], gr["pos_weight"])
+    want_loss.backward()
+    g_want = {k: p.grad for k, p in om.named_parameters()}
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], y=gr["y"], pos_weight=gr["pos_weight"], hidden=hidden, hs=hs, layers=layers,
+                state_dict=sd)
+    (tmp_path / "eval").mkdir()
+    (tmp_path / "train").mkdir()
+    for o in _run(2, case, tmp_path / "eval"):
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(want_eval)).abs().max().item() < 1e-4
+    outs = _run(2, dict(case, train=True), tmp_path / "train")
+    for o in outs:
+        assert abs(o["loss"].item() - want_loss.item()) <= 2e-5 * abs(want_loss.item())
+        assert set(o["grads"]) == set(g_want)
+        for k, w in g_want.items():
+            assert o["grads"][k].shape == w.shape
+            assert (o["grads"][k] - w).abs().max().item() <= 2e-3 * w.abs().max().item() + 2e-6, k
+    for k in g_want:
+        assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k

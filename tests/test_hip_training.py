@@ -315,6 +315,49 @@ def test_training_step_matches_oracle_autograd(hidden, reverse):
     assert torch.isfinite(m(views, x.to(dev()), gr["e"].to(dev()))).all()
 
 
+@pytest.mark.parametrize("hidden,hs", [(96, 48), (200, 50), (40, 64)])
+def test_training_step_at_widths_between_the_built_ones(hidden, hs):
+    """The reference takes any hidden_features / hidden_edge_scores (configs/hyperparameters.py:22-24): in train mode a width between the built
+    ones runs on a zero-padded twin of the next built width (train._padded_step) - loss, every gradient in the model's own shapes and the
+    BatchNorm buffers against the oracle's autograd at N = 3000 / E = 30 000, then an Adam step and the eval forward of the updated model
+    against the oracle updated the same way."""
+    n, e, layers = 3000, 30000, 4
+    gr = make_graph(n, e, seed=9)
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(hidden, num_layers=layers, hidden_edge_scores=hs, seed=3)
+    om = OracleModel(2, 2, hidden, 16, layers, hs, "batch", dropout=0.0)
+    om.load_state_dict(sd)
+    om.train()
+    want_logits = om((gr["src"], gr["dst"], n), x, gr["e"])
+    want_loss = bce_loss(want_logits, gr["y"], gr["pos_weight"])
+    want_loss.backward()
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, layers, hs, "batch", dropout=0.0)
+    m.load_state_dict(sd)
+    m.to(dev()).train()
+    views = gnnome_amd.graph.views_for((gr["src"], gr["dst"], n), dev())
+    got = m(views, x.to(dev()), gr["e"].to(dev()))
+    loss = F.binary_cross_entropy_with_logits(got.squeeze(-1), gr["y"].to(dev()), pos_weight=gr["pos_weight"].to(dev()))
+    loss.backward()
+    assert got.shape == want_logits.shape and abs(loss.item() - want_loss.item()) <= 1e-5 * abs(want_loss.item())
+    assert (torch.sigmoid(got.detach().cpu()) - torch.sigmoid(want_logits.detach())).abs().max().item() < 1e-4
+    got_g = {k: p.grad for k, p in m.named_parameters()}
+    want_g = {k: p.grad for k, p in om.named_parameters()}
+    assert all(got_g[k].shape == want_g[k].shape for k in want_g)
+    _check_grads(got_g, want_g, rtol=3e-2)
+    num = sum(((got_g[k].cpu() - want_g[k]).double() ** 2).sum().item() for k in want_g) ** 0.5
+    den = sum((want_g[k].double() ** 2).sum().item() for k in want_g) ** 0.5
+    assert num / den < 3e-3, f"relative L2 error of the full gradient {num / den:.2e}"
+    ob, mb = dict(om.named_buffers()), dict(m.named_buffers())
+    assert all(mb[k].shape == ob[k].shape and torch.allclose(mb[k].float().cpu(), ob[k].float(), atol=1e-4, rtol=1e-3) for k in ob)
+    torch.optim.Adam(m.parameters(), lr=1e-4).step()
+    torch.optim.Adam(om.parameters(), lr=1e-4).step()
+    m.eval()
+    om.eval()
+    with torch.no_grad():
+        want_eval = om((gr["src"], gr["dst"], n), x, gr["e"])
+    assert (torch.sigmoid(m(views, x.to(dev()), gr["e"].to(dev())).cpu()) - torch.sigmoid(want_eval)).abs().max().item() < 1e-4
+
+
 def test_training_step_matches_oracle_autograd_at_200k_edges():
     """above 40k edges the gradient used to be checked against the builder's OTHER kernels only.  Here the
     oracle's autograd (torch CPU, the reference's op sequence) at N = 20k / E = 200k, H = 128 - five times the size of the test above,

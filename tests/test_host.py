@@ -118,7 +118,7 @@ def test_host_sequence_layernorm_and_reversed_graph():
 def test_widths_between_the_built_ones_run_zero_padded():
     """hidden_features / hidden_edge_scores outside {64,128,256} / {32,64,128} (the reference takes any): eval-mode BatchNorm models
     run on the next built width with zero-padded parameters - against the reference's own logits (golden G11) - and the cases
-    padding cannot serve are refused: LayerNorm (row statistics), train mode, widths above the largest built one."""
+    padding cannot serve are refused: LayerNorm (row statistics), widths above the largest built one.  (Train mode: tests/test_train_host.py.)"""
     g = load_golden("g11_widths.pt")
     for case in g["cases"]:
         sd = random_state_dict(case["hidden"], num_layers=case["layers"], hidden_edge_scores=case["hs"], seed=case["seed"])
@@ -137,10 +137,6 @@ def test_widths_between_the_built_ones_run_zero_padded():
         gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 1, 129, "batch")
     with pytest.raises(ValueError, match="LayerNorm"):
         gnnome_amd.models.SymGatedGCNModel(2, 2, 96, 16, 1, 64, "layer")
-    from gnnome_amd.train import train_forward_on
-    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 96, 16, 1, 64, "batch").train()
-    with pytest.raises(NotImplementedError, match="train mode at hidden_features=96"):
-        train_forward_on(m, None, torch.zeros(2, 2), torch.zeros(1, 2))
 
 
 def test_views_definition():

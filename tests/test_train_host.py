@@ -163,3 +163,47 @@ def test_recompute_gate_gives_the_same_bits_as_the_stored_activations():
     m.recompute_gate, m.activation_storage = True, "bf16"
     with pytest.raises(ValueError, match="alternatives"):
         train_forward_on(m, WholeGraph(cpu_ops.CpuViews(g["src"], g["dst"], g["num_nodes"]), cpu_ops), g["x"], g["e"])
+
+
+def test_training_step_at_widths_between_the_built_ones_matches_oracle_autograd():
+    """hidden_features / hidden_edge_scores outside {64,128,256} / {32,64,128} in TRAIN mode (the reference takes any width): the step runs on a
+    zero-padded twin of the next built widths whose parameters are differentiable functions of the model's own (train._padded_step) - loss,
+    every gradient (in the model's own shapes), the BatchNorm buffers and a second step after an optimizer update against the oracle's autograd."""
+    from gnnome_amd.synth import make_graph
+    from oracle.symgated_oracle import OracleModel, bce_loss, degree_features
+    n, ec = 300, 3000
+    gr = make_graph(n, ec, seed=7, kind="banded")
+    x = degree_features(gr["src"], gr["dst"], n)
+    views = cpu_ops.CpuViews(gr["src"], gr["dst"], n)
+    for hidden, hs in ((96, 48), (40, 20), (128, 40)):
+        sd = random_state_dict(hidden, num_layers=3, hidden_edge_scores=hs, seed=5)
+        om = OracleModel(2, 2, hidden, 16, 3, hs, "batch", dropout=0.0)
+        om.load_state_dict(sd)
+        om.train()
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, 3, hs, "batch", dropout=0.0)
+        m.load_state_dict(sd)
+        m.train()
+        opt_o, opt_m = torch.optim.SGD(om.parameters(), lr=0.05), torch.optim.SGD(m.parameters(), lr=0.05)
+        for step in range(2):
+            opt_o.zero_grad()
+            opt_m.zero_grad()
+            want = om((gr["src"], gr["dst"], n), x, gr["e"])
+            loss_o = bce_loss(want, gr["y"], gr["pos_weight"])
+            loss_o.backward()
+            got = train_forward_on(m, WholeGraph(views, cpu_ops), x, gr["e"])
+            loss_m = F.binary_cross_entropy_with_logits(got.squeeze(-1), gr["y"], pos_weight=gr["pos_weight"])
+            loss_m.backward()
+            assert got.shape == want.shape and abs(loss_m.item() - loss_o.item()) < 2e-5 * (1 + step)
+            assert (torch.sigmoid(got.detach()) - torch.sigmoid(want.detach())).abs().max().item() < 1e-4
+            check_grads({k: p.grad for k, p in m.named_parameters()}, {k: p.grad for k, p in om.named_parameters()}, rtol=2e-3 * (1 + step))
+            ob, mb = dict(om.named_buffers()), dict(m.named_buffers())
+            assert all(mb[k].shape == ob[k].shape and torch.allclose(mb[k].float(), ob[k].float(), atol=1e-5, rtol=1e-4) for k in ob)
+            opt_o.step()
+            opt_m.step()
+        assert list(m.state_dict().keys()) == list(sd.keys()) and all(m.state_dict()[k].shape == v.shape for k, v in sd.items())
+    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 1, 64, "batch").train()
+    m.gnn.convs[0].bn_e = torch.nn.LayerNorm(64)      # (a model patched after construction: the padded step only serves BatchNorm)
+    m.linear2_node = torch.nn.Linear(16, 72)
+    import pytest
+    with pytest.raises(ValueError, match="normalization='batch'"):
+        train_forward_on(m, WholeGraph(views, cpu_ops), x, gr["e"])
