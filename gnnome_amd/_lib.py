@@ -31,6 +31,10 @@ SIGNATURES = {
     "gnnome_edge_gate_ref_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_node_aggregate_f32": [_p, _i, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
     "gnnome_node_aggregate_range_f32": [_p, _i, _l, _l, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
+    "gnnome_stream_schedule_sizes": [_l, _l, _i, ctypes.POINTER(_l), ctypes.POINTER(_sz)],
+    "gnnome_build_stream_schedule": [_l, _l, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gnnome_node_aggregate_stream_f32": [_p, _i, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p,
+                                         _p, _l, _p, _p],
     "gnnome_edge_score_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_edge_gate_raw_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p],
     "gnnome_edge_gate_raw_stats_rows": [_i, ctypes.POINTER(_i)],
@@ -86,7 +90,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

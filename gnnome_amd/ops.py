@@ -81,7 +81,7 @@ class GraphViews:
     """In-edge / out-edge orderings of one edge list (see include/gnnome_hip.h, "graph views")."""
 
     __slots__ = ("num_nodes", "num_edges", "in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst", "device",
-                 "transposed", "_range", "_bad", "node_perm", "node_gather", "__weakref__")
+                 "transposed", "_range", "_bad", "node_perm", "node_gather", "_stream", "__weakref__")
 
     def __init__(self, src, dst, num_nodes, validate="now", node_perm=None):
         """node_perm (int64[N], optional): the views are built over RENUMBERED nodes, node_perm[caller's id] = internal id
@@ -108,6 +108,7 @@ class GraphViews:
                 self.check_range()
         self.num_nodes, self.num_edges, self.device, self.transposed = n, e, dev, False
         self.node_perm = self.node_gather = None
+        self._stream = None
         if node_perm is not None:
             node_perm = node_perm.to(device=dev, dtype=torch.int64)
             if node_perm.numel() != n:
@@ -144,6 +145,13 @@ class GraphViews:
                 raise IndexError(self._bad)
             self._range = None
 
+    def stream_schedule(self):
+        """The streaming aggregation's schedule of this graph (StreamSchedule), built on first use - one host sync, once per graph;
+        shared with the reversed views (the schedule is a function of the arrays, not of the roles the host gives them)."""
+        if self._stream is None:
+            self._stream = StreamSchedule(self)
+        return self._stream
+
     def reversed(self):
         """Views of dgl.reverse(g, copy_ndata=True, copy_edata=True) - endpoints swapped, edge ids and edge
         storage order kept (gated_gcn_full.py:99, train.py:165).  Free: the same arrays, with the roles of
@@ -154,6 +162,70 @@ class GraphViews:
                 setattr(r, k, getattr(self, k))
         r.transposed = not self.transposed
         return r
+
+
+# The streaming aggregation (gnnome_node_aggregate_stream_f32): "auto" = whenever the graph's schedule says its numbering has the
+# locality the LDS slot window needs; False = always the one-wave-per-node kernel (gnnome_node_aggregate_f32).
+import os as _os
+STREAM_AGGREGATE = False if _os.environ.get("GNNOME_STREAM_AGGREGATE", "auto").lower() in ("0", "off", "false") else "auto"   # (A/B switch)
+STREAM_MIN_EDGES = 400_000      # below this the chunks get so short that their boundaries make a quarter of the rows far
+STREAM_MAX_FAR = 0.20           # far rows / E above which the graph is left to the gathering kernel (a uniform random graph: ~1.0)
+STREAM_ROWS_PER_CHUNK = 2048
+STREAM_ROWS_PER_STEP = 16
+STREAM_SLOTS = 62
+
+
+class StreamSchedule:
+    """include/gnnome_hip.h, "streaming aggregation": the per-graph schedule + the facts the host decides with."""
+
+    __slots__ = ("chunks", "chunk_node", "chunk_steps", "steps", "edge_meta", "node_pend", "pend_nodes", "counters", "num_pending",
+                 "num_far", "num_overflow", "max_live", "max_steps", "total_steps", "far_fraction", "usable", "why")
+
+    def __init__(self, views, chunks=None, slots=None):
+        lib = _lib.load()
+        dev, n, e = views.device, views.num_nodes, views.num_edges
+        self.usable, self.why = False, ""
+        if e == 0 or n == 0:
+            self.why = "empty graph"
+            return
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        self.chunks = int(chunks) if chunks else max(2 * cus, -(-e // STREAM_ROWS_PER_CHUNK))
+        slots = STREAM_SLOTS if slots is None else int(slots)
+        cap, scratch = ctypes.c_int64(0), ctypes.c_size_t(0)
+        _lib.check(lib.gnnome_stream_schedule_sizes(n, e, STREAM_ROWS_PER_STEP, ctypes.byref(cap), ctypes.byref(scratch)), "stream_schedule_sizes")
+        mk = lambda k: torch.empty(k, dtype=torch.int32, device=dev)  # noqa: E731
+        self.chunk_node, self.chunk_steps = mk(self.chunks + 1), mk(self.chunks)
+        self.steps = torch.empty((int(cap.value), 4), dtype=torch.int32, device=dev)
+        self.edge_meta = torch.empty(e, dtype=torch.uint8, device=dev)
+        self.node_pend, self.pend_nodes, self.counters = mk(n), mk(n), mk(8)
+        ws = torch.empty(int(scratch.value), dtype=torch.uint8, device=dev)
+        with _on(dev):
+            _lib.check(lib.gnnome_build_stream_schedule(n, e, _ptr(views.in_ptr), _ptr(views.srt_src), _ptr(views.out_ptr), _ptr(views.out_pos),
+                                                        _ptr(views.out_dst), self.chunks, STREAM_ROWS_PER_STEP, slots, _ptr(self.chunk_node),
+                                                        _ptr(self.chunk_steps), _ptr(self.steps), _ptr(self.edge_meta), _ptr(self.node_pend),
+                                                        _ptr(self.pend_nodes), _ptr(self.counters), _ptr(ws), ws.numel(), _stream(dev)),
+                       "build_stream_schedule")
+            ws.record_stream(torch.cuda.current_stream(dev))
+        c = self.counters.tolist()   # the one host sync
+        self.num_pending, self.num_far, self.num_overflow, self.max_live, self.max_steps = c[0], c[1], c[2], c[3], c[4]
+        self.total_steps = int(self.chunk_steps.sum())
+        self.far_fraction = self.num_far / e
+        if self.far_fraction > STREAM_MAX_FAR:
+            self.why = f"{self.far_fraction:.0%} of the rows are far: the numbering has no locality (or the graph is too small for its chunks)"
+        elif self.max_steps > 4 * (self.total_steps // self.chunks + 16):
+            self.why = f"a chunk of {self.max_steps} steps against {self.total_steps // self.chunks} on average: a hub"
+        else:
+            self.usable = True
+
+
+def stream_schedule_for(views, e_rows, num_nodes_out, node_range, norm_kind):
+    """The schedule the streaming aggregation would run this call with, or None: whole-graph inference updates with the affine norm
+    on graphs whose schedule is usable (STREAM_AGGREGATE)."""
+    if (not STREAM_AGGREGATE or norm_kind != NORM_AFFINE or node_range is not None or views.num_edges < STREAM_MIN_EDGES
+            or e_rows != views.num_edges or (num_nodes_out is not None and num_nodes_out != views.num_nodes) or not hasattr(views, "stream_schedule")):
+        return None
+    sched = views.stream_schedule()
+    return sched if sched.usable else None
 
 
 edge_gate_out_of_place_at_256 = True   # engine.gate_update: the H = 256 streaming gate needs out != e
@@ -301,8 +373,18 @@ def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_n
     n_out = int(h_in.shape[0] if num_nodes_out is None else num_nodes_out)
     h_out = torch.empty((h_in.shape[0], hidden), dtype=torch.float32, device=h_in.device) if out is None else out
     assert h_out.is_contiguous() and h_out.shape == (h_in.shape[0], hidden) and h_out.dtype == torch.float32
+    sched = stream_schedule_for(views, e.shape[0], num_nodes_out, node_range, norm_kind) if h_in.shape[0] == views.num_nodes else None
     with _on(h_in.device):
-        if node_range is None:
+        if sched is not None:
+            pend = torch.empty((max(sched.num_pending, 1), 3, hidden), dtype=torch.float32, device=h_in.device)
+            _lib.check(lib.gnnome_node_aggregate_stream_f32(_ptr(e), hidden, n_out, _ptr(A1h), _ptr(A2h), _ptr(A3h), ldn, _ptr(views.in_ptr),
+                                                            _ptr(views.srt_src), _ptr(views.out_ptr), _ptr(views.out_pos), _ptr(views.out_dst),
+                                                            _ptr(h_in), ldh, _ptr(h_out), _ptr(scale), _ptr(shift), sched.chunks,
+                                                            STREAM_ROWS_PER_STEP, STREAM_SLOTS, _ptr(sched.chunk_node), _ptr(sched.chunk_steps),
+                                                            _ptr(sched.steps), _ptr(sched.edge_meta), _ptr(sched.node_pend), _ptr(sched.pend_nodes),
+                                                            _ptr(sched.counters), sched.num_pending, _ptr(pend), _stream(h_in.device)),
+                       "node_aggregate_stream_f32")
+        elif node_range is None:
             _lib.check(lib.gnnome_node_aggregate_f32(_ptr(e), hidden, n_out, _ptr(A1h), _ptr(A2h), _ptr(A3h), ldn,
                                                      _ptr(views.in_ptr), _ptr(views.srt_src), _ptr(views.out_ptr),
                                                      _ptr(views.out_pos), _ptr(views.out_dst), _ptr(h_in), ldh, _ptr(h_out),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 10
+#define GNNOME_ABI_VERSION 11
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -206,6 +206,43 @@ int gnnome_node_aggregate_range_f32(const float* e, int hidden, int64_t num_node
                                     const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
                                     const int32_t* out_dst, const float* h_in, int ld_h, float* h_out, int norm_kind,
                                     const float* norm_scale, const float* norm_shift, void* stream);
+
+/* ---- streaming aggregation (round 5) -----------------------------------------------------------------
+ * The same node update as gnnome_node_aggregate_f32 with norm_kind = GNNOME_NORM_AFFINE (gated_gcn_full.py:111-114, :124-127,
+ * :129-137), with every e row read ONCE: the rows are streamed in destination order, the in-edge sums are reduced per run, and a
+ * row's contribution to its SOURCE node (the out-edge sums of dgl.reverse(g), :125-126) is accumulated in a window of slots in LDS.
+ * What a row does to which slot is a SCHEDULE, a function of the graph alone, built once per graph:
+ *   - the nodes are cut into num_chunks ranges of consecutive destination nodes with about equal numbers of in-edge rows
+ *     (chunk_node[num_chunks + 1]); one workgroup walks one chunk, a wave of it one 32-channel slice of the rows;
+ *   - a chunk's rows are walked in STEPS of <= rows_per_step (16) rows of ONE destination node: steps[][4] =
+ *     {first row, node, count | flags | slot << 16, pending index}; chunk c's steps start at in_ptr[chunk_node[c]] / 16 +
+ *     chunk_node[c], chunk_steps[c] of them (capacity from gnnome_stream_schedule_sizes);
+ *   - edge_meta[p]: 0xFF = FAR (source in another chunk, a repeated (src, dst) pair, or no free slot: the stream skips the row's
+ *     out-edge half), else state << 6 | slot, state 0 / 1 = accumulate, 2 / 3 = the LAST event of the row's source - that row
+ *     also runs the source's node update (3: the source is pending);
+ *   - a node with far rows is PENDING (node_pend[node] = its index, pend_nodes[index] = node, counters[0] = their number): its
+ *     last event parks (A1h + fwd, num_b, den_b) in pend_rows[index][3][H], and a second launch adds the far rows in out-list
+ *     order and finishes the update.
+ * counters[8] (device): [0] pending nodes, [1] far rows, [2] nodes that found no free slot, [3] most slots in use, [4] most
+ * steps in a chunk.  A caller reads [0] back once to size pend_rows and decides from [1] / E whether the graph's numbering has
+ * the locality this form needs (a uniform random graph is all far rows: use gnnome_node_aggregate_f32).  num_slots <= 62.
+ * Results are bit-reproducible and equal gnnome_node_aggregate_f32's up to fp32 reassociation (and 1-ulp reciprocals).
+ * h_out must not alias h_in; hidden in {64,128,256}. */
+int gnnome_stream_schedule_sizes(int64_t num_nodes, int64_t num_edges, int rows_per_step, int64_t* steps_capacity_host,
+                                 size_t* scratch_bytes_host);
+int gnnome_build_stream_schedule(int64_t num_nodes, int64_t num_edges, const int32_t* in_ptr, const int32_t* srt_src,
+                                 const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst, int num_chunks,
+                                 int rows_per_step, int num_slots, int32_t* chunk_node, int32_t* chunk_steps, int32_t* steps,
+                                 uint8_t* edge_meta, int32_t* node_pend, int32_t* pend_nodes, int32_t* counters, void* scratch,
+                                 size_t scratch_bytes, void* stream);
+int gnnome_node_aggregate_stream_f32(const float* e, int hidden, int64_t num_nodes, const float* A1h, const float* A2h,
+                                     const float* A3h, int ld_node, const int32_t* in_ptr, const int32_t* srt_src,
+                                     const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst, const float* h_in,
+                                     int ld_h, float* h_out, const float* norm_scale, const float* norm_shift, int num_chunks,
+                                     int rows_per_step, int num_slots, const int32_t* chunk_node, const int32_t* chunk_steps,
+                                     const int32_t* steps, const uint8_t* edge_meta, const int32_t* node_pend,
+                                     const int32_t* pend_nodes, const int32_t* counters, int64_t num_pending, float* pend_rows,
+                                     void* stream);
 
 /* ---- fused edge scorer --------------------------------------------------------------------------
  * For every sorted position p < num_edges:

@@ -384,3 +384,100 @@ def segment_sum2(X, views, num_nodes, out_in=None, out_out=None):
     a = segment_sum(X, views.in_ptr, None, num_nodes, out=out_in)
     b = segment_sum(X, views.out_ptr, views.out_pos, num_nodes, out=out_out)
     return a, b
+
+
+def stream_schedule(views, chunks, rps=16, slots=62):
+    """The streaming aggregation's schedule (include/gnnome_hip.h, gnnome_build_stream_schedule) restated in plain Python: chunk bounds,
+    near / far rows, interval colouring of the nodes' live ranges with `slots` colours (lowest free first), step descriptors.
+    -> dict(chunk_node, chunk_steps, steps {chunk: [(row, node, word2, pending?)]}, edge_meta, pending (set of nodes), far, overflow)."""
+    import numpy as np
+    FAR, UNALLOC, OVERFLOW = 0xFF, 0xFF, 0xFE
+    MIDDLE, FIRST, LAST_FINAL, LAST_PENDING = 0, 1, 2, 3
+    D_LASTSTEP, D_FIRST, D_LAST, D_HASSLOT = 1 << 5, 1 << 6, 1 << 7, 1 << 8
+    n, e = views.num_nodes, views.num_edges
+    in_ptr, srt_src = views.in_ptr.cpu().numpy().astype(np.int64), views.srt_src.cpu().numpy().astype(np.int64)
+    out_ptr, out_pos, out_dst = (t.cpu().numpy().astype(np.int64) for t in (views.out_ptr, views.out_pos, views.out_dst))
+    chunk_node = np.zeros(chunks + 1, dtype=np.int64)
+    for c in range(1, chunks):
+        chunk_node[c] = np.searchsorted(in_ptr[:n], e * c // chunks, side="left")
+    chunk_node[chunks] = n
+    meta = np.zeros(e, dtype=np.int64)
+    last_near = np.arange(n)
+    pending, far = set(), 0
+    chunk_of = np.zeros(n, dtype=np.int64)
+    for c in range(chunks):
+        chunk_of[chunk_node[c]:chunk_node[c + 1]] = c   # (empty chunks write nothing: a node belongs to the last chunk that starts at or before it)
+    for s in range(n):
+        n0, n1 = chunk_node[chunk_of[s]], chunk_node[chunk_of[s] + 1]
+        k0, k1 = out_ptr[s], out_ptr[s + 1]
+        for k in range(k0, k1):
+            d = out_dst[k]
+            if n0 <= d < n1 and not (k > k0 and out_dst[k - 1] == d):
+                last_near[s] = max(last_near[s], d)
+            else:
+                meta[out_pos[k]] = FAR
+                far += 1
+                pending.add(s)
+    slot_of = np.full(n, UNALLOC, dtype=np.int64)
+    steps, chunk_steps, overflow = {}, np.zeros(chunks, dtype=np.int64), 0
+    for c in range(chunks):
+        free = list(range(slots))   # kept sorted: lowest free slot first
+        out = []
+        for t in range(chunk_node[c], chunk_node[c + 1]):
+            ib, ie = in_ptr[t], in_ptr[t + 1]
+            free_after = []
+            for p in range(ib, ie):
+                if meta[p] == FAR:
+                    continue
+                s = srt_src[p]
+                so = slot_of[s]
+                if so == OVERFLOW:
+                    meta[p] = FAR
+                    far += 1
+                    continue
+                state = MIDDLE
+                if so == UNALLOC:
+                    if not free:
+                        slot_of[s] = OVERFLOW
+                        meta[p] = FAR
+                        far += 1
+                        pending.add(s)
+                        overflow += 1
+                        continue
+                    so = free.pop(0)
+                    slot_of[s] = so
+                    state = FIRST
+                if last_near[s] == t and s != t:
+                    state = LAST_PENDING if s in pending else LAST_FINAL
+                    free_after.append(so)
+                meta[p] = (state << 6) | so
+            so, info, last_ev = slot_of[t], 0, last_near[t] == t
+            if so == OVERFLOW:
+                info = D_FIRST | D_LAST
+            elif so == UNALLOC:
+                if last_ev:
+                    info = D_FIRST | D_LAST
+                elif not free:
+                    slot_of[t] = OVERFLOW
+                    pending.add(t)
+                    overflow += 1
+                    info = D_FIRST | D_LAST
+                else:
+                    so = free.pop(0)
+                    slot_of[t] = so
+                    info = D_FIRST | D_HASSLOT | (so << 16)
+            else:
+                info = D_HASSLOT | (so << 16)
+                if last_ev:
+                    info |= D_LAST
+                    free_after.append(so)
+            din = ie - ib
+            nst = (din + rps - 1) // rps if din > 0 else 1
+            for j in range(nst):
+                cnt = max(min(rps, din - j * rps), 0)
+                out.append((int(ib + j * rps), int(t), int(cnt | ((D_LASTSTEP | info) if j == nst - 1 else 0)), t in pending))
+            free = sorted(free + free_after)
+        steps[c] = out
+        chunk_steps[c] = len(out)
+    return {"chunk_node": chunk_node, "chunk_steps": chunk_steps, "steps": steps, "edge_meta": meta, "pending": pending, "far": far,
+            "overflow": overflow}

@@ -1,0 +1,15 @@
+#!/bin/bash
+# one GPU-box visit of round 5: `tools/r05_visit.sh <leg> [<leg> ...]`, every leg bounded, logs under gpurun_out/r05/.
+cd "$GRAFT_REPO_ROOT" || exit 1
+out=gpurun_out/r05; mkdir -p $out
+for leg in "$@"; do
+  case $leg in
+    stream_tests) timeout 900 python -m pytest tests/test_stream_aggregate.py -x -q > $out/stream_tests.log 2>&1; echo "stream_tests rc=$?"; tail -15 $out/stream_tests.log ;;
+    stream_time)  for a in "128 100000 1000000 banded 0,256,512,1024" "128 1000000 10000000 banded 0" "256 250000 2500000 banded 0" "64 100000 1000000 banded 0" "128 100000 1000000 uniform 512"; do
+                    timeout 300 python tools/stream_agg_time.py $a >> $out/stream_time.jsonl 2>> $out/stream_time.err; done; echo "stream_time rc=$?"; cat $out/stream_time.jsonl; tail -5 $out/stream_time.err ;;
+    tests)        timeout 2400 python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 $out/pytest.log ;;
+    bench)        timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$?"; tail -c 1500 $out/bench_default.json; tail -3 $out/bench_default.err ;;
+    bench_ab)     for v in auto off; do GNNOME_STREAM_AGGREGATE=$v timeout 300 python bench.py --no-cpu-baseline --steps 30 --warmup 5 > $out/bench_stream_$v.json 2> $out/bench_stream_$v.err; echo "bench $v rc=$?"; tail -c 700 $out/bench_stream_$v.json; done ;;
+    *) echo "unknown leg $leg" ;;
+  esac
+done
