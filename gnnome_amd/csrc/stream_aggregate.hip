@@ -39,6 +39,7 @@ namespace gnnome {
 constexpr int kFar = 0xFF;             // edge_meta: the row's out-edge half is not done by the stream
 constexpr int kStMiddle = 0, kStFirst = 1, kStLastFinal = 2, kStLastPending = 3;   // edge_meta >> 6
 constexpr int kSlotUnalloc = 0xFF, kSlotOverflow = 0xFE;
+constexpr int kLateDistance = 3;   // > the number of steps the stream requests a closing row's operands ahead of the row (2)
 // step descriptor word 2
 constexpr int kDLastStep = 1 << 5, kDFirst = 1 << 6, kDLast = 1 << 7, kDHasSlot = 1 << 8;
 
@@ -87,10 +88,12 @@ __global__ void k_stream_sched_nodes(int64_t n, int chunks, const int32_t* __res
     last_near[s] = last;
     slot_of[s] = kSlotUnalloc;
     int idx = -1;
-    if (far > 0) {
+    // also pending: a node whose closing row follows its in-run end by fewer than kLateDistance steps - the stream requests a closing row's
+    // operands that many steps ahead, and the parked A1h + fwd of a node that is NOT pending is read back from h_out
+    if (far > 0 || (last > s && last - s < kLateDistance)) {
         idx = atomicAdd(&counters[0], 1);
         pend_nodes[idx] = (int32_t)s;
-        atomicAdd(&counters[1], far);
+        if (far > 0) atomicAdd(&counters[1], far);
     }
     node_pend[s] = idx;
 }
@@ -229,14 +232,18 @@ __device__ __forceinline__ f32x4 load16(const float* base, unsigned byte_off) { 
 
 // One workgroup = one chunk, wave w = channels [32 w, 32 w + 32).  Lane (g = lane / 4, l = lane % 4) of a step holds row g's channels
 // 4 l .. 4 l + 3 and 16 + 4 l .. 16 + 4 l + 3 of the slice (two 16-byte pieces; a load instruction covers 64 contiguous bytes of each row).
-// Software pipeline over the chunk's steps, everything a step carries lives in ONE of four register sets (step j in set j % 4) and the
-// loop is unrolled four times by hand, so that no value is copied while its load is in flight (a register copy waits for the load):
-//   iteration q:  A0  source ids + schedule bytes of step q + 3 requested
-//                 A   row pieces x, A2h[src] and A3h[node] of step q + 2 requested (its source ids have arrived)
-//                 C   step q: sigmoid, in-edge partial sums, slot updates in LDS, closing rows, the node's in-run end
-//                 L   operands of step q + 1 that must be requested AFTER stage C's stores in program order: the parked A1h + fwd of a
-//                     closing row's source (it lives in h_out until the node is finished and may have been written by this very wave a
-//                     step earlier), h[src], the pending index; and the node-level operands A1h[node], h[node] (4 bytes per lane)
+// Software pipeline over the chunk's steps, everything a step carries lives in ONE of five register sets (step j in set j % 5) and the
+// loop is unrolled five times by hand, so that no value is copied while its load is in flight (a register copy waits for the load):
+//   iteration q:  C   step q: sigmoid, in-edge partial sums, slot updates in LDS, closing rows, the node's in-run end
+//                 X   descriptor and row pieces x of step q + 4 requested (the HBM stream: four steps = 8 KB per wave in flight)
+//                 A0  source ids + schedule bytes of step q + 3 requested
+//                 A   the gathers of step q + 2 requested (its source ids have arrived): A2h[src], A3h[node], the node-level operands
+//                     A1h[node], h[node] (4 bytes per lane) and, for a closing row, h[src], the pending index or the parked A1h + fwd of
+//                     its source (in h_out since that node's in-run end - at least kLateDistance steps ago, the schedule makes every
+//                     node with a closer closing row pending, and a pending node parks in pend_rows)
+// The vector-memory queue returns in order: stage C waits for step q's operands only, and the requests of steps q + 1 .. q + 3 stay in
+// flight across it (the first version requested the closing rows' operands one step ahead, AFTER the stage-C stores they might depend on:
+// every iteration then waited for the newest request and drained the queue - 1.9 us per step).
 // Slots are zero whenever they are free (zeroed at the start, and again by the event that closes them), so a row never has to know
 // whether it is the first to touch its slot.
 // BIG: the node tables exceed 4 GB (64-bit gather addresses); otherwise a gather is a uniform base + a 32-bit lane offset.
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
     const int4* __restrict__ sd = steps + ((int64_t)in_ptr[n0] / RPS + n0);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int i = lane * 4; i < K * SLOT; i += 256) *reinterpret_cast<f32x4*>(W + i) = zero;
-    // lane constants: byte offsets of this lane's first piece inside a step's rows / a node row / a parked row
+    // lane constants: byte offsets of this lane's first piece inside a step's rows / a node row
     const unsigned xoff = (unsigned)(g * H + cl) * 4u, noff = (unsigned)cl * 4u;
     // node-level lane roles (the in-run end): lane j < 32 owns channel c0 + j
     const int cj = c0 + (lane & 31);
@@ -277,17 +284,17 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
         int4 d;                          // descriptor (wave-uniform)
         int src, meta;                   // A0
         f32x4 xl, xh, a2l, a2h, a3l, a3h;   // A
-        f32x4 tsl, tsh, hil, hih;        // L (closing rows)
+        f32x4 tsl, tsh, hil, hih;        //   (closing rows)
         int pi;
-        float a1j, hnj;                  // L (node level)
+        float a1j, hnj;                  //   (node level)
     };
-    StepRegs R0, R1, R2, R3;
+    StepRegs R0, R1, R2, R3, R4;
     const int4 empty = make_int4(0, n0, 0, -1);
-    R0.d = R1.d = R2.d = R3.d = empty;
+    R0.d = R1.d = R2.d = R3.d = R4.d = empty;
     f32x4 nfl = zero, nfh = zero, dfl = zero, dfh = zero;
 
     // a gathered row piece of a node table: row * ld + this lane's channels
-    auto gather = [&](const float* __restrict__ table, int row, int ld, f32x4& lo, f32x4& hi) {
+    auto gather = [&](const float* table, int row, int ld, f32x4& lo, f32x4& hi) {
         if (BIG) {
             const float* r = table + (int64_t)row * ld + cl;
             lo = *reinterpret_cast<const f32x4*>(r), hi = *reinterpret_cast<const f32x4*>(r + 16);
@@ -296,9 +303,16 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
             lo = load16(table, off), hi = load16(table, off + 64u);
         }
     };
-    auto stage_a0 = [&](StepRegs& R, const int j) {   // source ids and schedule bytes of step j
+    auto stage_x = [&](StepRegs& R, const int j) {   // the descriptor and the row pieces of step j (their addresses need nothing else)
         const int4 dj = sd[min(j, ns - 1)];   // (always a scalar load; steps past the end are empty steps)
         R.d = j < ns ? dj : empty;
+        forget(R.xl), forget(R.xh);
+        if (g < (R.d.z & 31)) {
+            const float* xr = e + (int64_t)R.d.x * H;   // (wave-uniform)
+            R.xl = load16(xr, xoff), R.xh = load16(xr, xoff + 64u);
+        }
+    };
+    auto stage_a0 = [&](StepRegs& R) {   // source ids and schedule bytes
         forget(R.src), forget(R.meta);
         if (g < (R.d.z & 31)) {
             const int32_t* sp = srt_src + R.d.x;
@@ -307,23 +321,21 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
             R.meta = mp[g];
         }
     };
-    auto stage_a = [&](StepRegs& R) {   // the row pieces and the table rows of the in-edge / out-edge sums
-        forget(R.xl), forget(R.xh), forget(R.a2l), forget(R.a2h), forget(R.a3l), forget(R.a3h);
+    auto stage_a = [&](StepRegs& R) {
+        forget(R.a2l), forget(R.a2h), forget(R.a3l), forget(R.a3h);
+        forget(R.tsl), forget(R.tsh), forget(R.hil), forget(R.hih), forget(R.pi);
         if (g < (R.d.z & 31)) {
-            const float* xr = e + (int64_t)R.d.x * H;   // (wave-uniform)
-            R.xl = load16(xr, xoff), R.xh = load16(xr, xoff + 64u);
             gather(A2h, R.src, ldn, R.a2l, R.a2h);
             const float* br = A3h + (int64_t)R.d.y * ldn;
             R.a3l = load16(br, noff), R.a3h = load16(br, noff + 64u);
-        }
-    };
-    auto stage_l = [&](StepRegs& R) {
-        forget(R.tsl), forget(R.tsh), forget(R.hil), forget(R.hih), forget(R.pi);
-        if (g < (R.d.z & 31) && R.meta != kFar && (R.meta >> 6) >= kStLastFinal) {
-            gather(h_out, R.src, H, R.tsl, R.tsh);
-            gather(h_in, R.src, ldh, R.hil, R.hih);
-            R.pi = -1;
-            if ((R.meta >> 6) == kStLastPending) R.pi = node_pend[R.src];
+            if (R.meta != kFar && (R.meta >> 6) >= kStLastFinal) {
+                if ((R.meta >> 6) == kStLastPending) {
+                    R.pi = node_pend[R.src];
+                } else {
+                    gather(h_out, R.src, H, R.tsl, R.tsh);
+                    gather(h_in, R.src, ldh, R.hil, R.hih);
+                }
+            }
         }
         R.a1j = A1h[(int64_t)R.d.y * ldn + cj];
         R.hnj = h_in[(int64_t)R.d.y * ldh + cj];
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
                 nbl += sl * R.a3l, nbh += sh_ * R.a3h;
                 dbl += sl, dbh += sh_;
                 if ((R.meta >> 6) >= kStLastFinal) {   // the last event of the row's source: its node update, and the slot is free (= zero) again
-                    if (R.pi < 0) {
+                    if ((R.meta >> 6) == kStLastFinal) {
                         f32x4 yl, yh;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -352,11 +364,10 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
                         float* o = h_out + (int64_t)R.src * H + cl;
                         *reinterpret_cast<f32x4*>(o) = yl;
                         *reinterpret_cast<f32x4*>(o + 16) = yh;
-                    } else {
-                        float* pr = pend_rows + (int64_t)R.pi * 3 * H + cl;
-                        *reinterpret_cast<f32x4*>(pr) = R.tsl, *reinterpret_cast<f32x4*>(pr + 16) = R.tsh;
-                        *reinterpret_cast<f32x4*>(pr + H) = nbl, *reinterpret_cast<f32x4*>(pr + H + 16) = nbh;
-                        *reinterpret_cast<f32x4*>(pr + 2 * H) = dbl, *reinterpret_cast<f32x4*>(pr + 2 * H + 16) = dbh;
+                    } else {   // a pending source: its in-run end has parked A1h + fwd in row 0 already
+                        float* pr = pend_rows + ((int64_t)R.pi * 3 + 1) * H + cl;
+                        *reinterpret_cast<f32x4*>(pr) = nbl, *reinterpret_cast<f32x4*>(pr + 16) = nbh;
+                        *reinterpret_cast<f32x4*>(pr + H) = dbl, *reinterpret_cast<f32x4*>(pr + H + 16) = dbh;
                     }
                     nbl = nbh = dbl = dbh = zero;
                 }
@@ -385,41 +396,47 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
             const int node = R.d.y;
             if (lane < 32) {
                 float* slot = W + ((R.d.z >> 16) & 63) * SLOT + lane;
-                if (R.d.z & kDLast) {
+                if (R.d.w >= 0) {   // a pending node: A1h + fwd goes to its side rows now; num_b / den_b follow with its last event
+                    float* pr = pend_rows + (int64_t)R.d.w * 3 * H + cj;
+                    pr[0] = t;
+                    if (R.d.z & kDLast) {
+                        float nb = 0.f, db = 0.f;
+                        if (R.d.z & kDHasSlot) {
+                            nb = slot[0], db = slot[CH];
+                            slot[0] = 0.f, slot[CH] = 0.f;
+                        }
+                        pr[H] = nb, pr[2 * H] = db;
+                    }
+                } else if (R.d.z & kDLast) {
                     float nb = 0.f, db = 0.f;
                     if (R.d.z & kDHasSlot) {
                         nb = slot[0], db = slot[CH];
                         slot[0] = 0.f, slot[CH] = 0.f;
                     }
-                    if (R.d.w < 0) {
-                        h_out[(int64_t)node * H + cj] = fmaxf((t + nb * __builtin_amdgcn_rcpf(db + kAggEps)) * scj + shj, 0.f) + R.hnj;
-                    } else {
-                        float* pr = pend_rows + (int64_t)R.d.w * 3 * H + cj;
-                        pr[0] = t, pr[H] = nb, pr[2 * H] = db;
-                    }
+                    h_out[(int64_t)node * H + cj] = fmaxf((t + nb * __builtin_amdgcn_rcpf(db + kAggEps)) * scj + shj, 0.f) + R.hnj;
                 } else {
-                    h_out[(int64_t)node * H + cj] = t;   // parked until the node's closing row
+                    h_out[(int64_t)node * H + cj] = t;   // parked until the node's closing row, at least kLateDistance steps from here
                 }
             }
         }
     };
 
-    stage_a0(R0, 0), stage_a0(R1, 1), stage_a0(R2, 2);
+    stage_x(R0, 0), stage_x(R1, 1), stage_x(R2, 2), stage_x(R3, 3);
+    stage_a0(R0), stage_a0(R1), stage_a0(R2);
     stage_a(R0), stage_a(R1);
-    stage_l(R0);
-    // iteration q: A0 of step q + 3, A of q + 2, C of q, L of q + 1
-    auto iteration = [&](const int q, StepRegs& Rq, StepRegs& Rq1, StepRegs& Rq2, StepRegs& Rq3) {
-        stage_a0(Rq3, q + 3);
-        stage_a(Rq2);
+    // iteration q: C of step q; then X of q + 4, A0 of q + 3, A of q + 2
+    auto iteration = [&](const int q, StepRegs& Rq, StepRegs& Rq2, StepRegs& Rq3, StepRegs& Rq4) {
         stage_c(Rq);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler ordering only: the requests below stay behind the stores above)
-        stage_l(Rq1);
+        stage_x(Rq4, q + 4);
+        stage_a0(Rq3);
+        stage_a(Rq2);
     };
-    for (int q = 0; q < ns; q += 4) {
-        iteration(q, R0, R1, R2, R3);
-        iteration(q + 1, R1, R2, R3, R0);
-        iteration(q + 2, R2, R3, R0, R1);
+    for (int q = 0; q < ns; q += 5) {
+        iteration(q, R0, R2, R3, R4);
+        iteration(q + 1, R1, R3, R4, R0);
+        iteration(q + 2, R2, R4, R0, R1);
         iteration(q + 3, R3, R0, R1, R2);
+        iteration(q + 4, R4, R1, R2, R3);
     }
 }
 

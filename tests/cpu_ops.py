@@ -391,7 +391,7 @@ def stream_schedule(views, chunks, rps=16, slots=62):
     near / far rows, interval colouring of the nodes' live ranges with `slots` colours (lowest free first), step descriptors.
     -> dict(chunk_node, chunk_steps, steps {chunk: [(row, node, word2, pending?)]}, edge_meta, pending (set of nodes), far, overflow)."""
     import numpy as np
-    FAR, UNALLOC, OVERFLOW = 0xFF, 0xFF, 0xFE
+    FAR, UNALLOC, OVERFLOW, LATE_DISTANCE = 0xFF, 0xFF, 0xFE, 3
     MIDDLE, FIRST, LAST_FINAL, LAST_PENDING = 0, 1, 2, 3
     D_LASTSTEP, D_FIRST, D_LAST, D_HASSLOT = 1 << 5, 1 << 6, 1 << 7, 1 << 8
     n, e = views.num_nodes, views.num_edges
@@ -418,6 +418,8 @@ def stream_schedule(views, chunks, rps=16, slots=62):
                 meta[out_pos[k]] = FAR
                 far += 1
                 pending.add(s)
+        if 0 < last_near[s] - s < LATE_DISTANCE:   # its closing row would follow its in-run end too closely for the stream's prefetch distance
+            pending.add(s)
     slot_of = np.full(n, UNALLOC, dtype=np.int64)
     steps, chunk_steps, overflow = {}, np.zeros(chunks, dtype=np.int64), 0
     for c in range(chunks):
