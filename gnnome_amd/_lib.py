@@ -33,7 +33,7 @@ SIGNATURES = {
     "gnnome_node_aggregate_range_f32": [_p, _i, _l, _l, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
     "gnnome_stream_schedule_sizes": [_l, _l, _i, ctypes.POINTER(_l), ctypes.POINTER(_sz)],
     "gnnome_build_stream_schedule": [_l, _l, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
-    "gnnome_node_aggregate_stream_f32": [_p, _i, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p,
+    "gnnome_node_aggregate_stream_f32": [_p, _i, _l, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p,
                                          _p, _l, _p, _p],
     "gnnome_edge_score_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_edge_gate_raw_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p],

@@ -208,7 +208,7 @@ struct StreamArgs {
     const int32_t* node_pend;
     float* pend_rows;   // [num_pending][3][H]: A1h + fwd | num_b | den_b
     int chunks;
-    int64_t num_nodes;
+    int64_t num_nodes, num_edges;
 };
 
 constexpr int kStreamCH = 32;    // channels per wave
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
     const float* __restrict__ h_in, const int ldh, float* h_out, const float* __restrict__ scale, const float* __restrict__ shift,
     const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src, const uint8_t* __restrict__ edge_meta, const int4* __restrict__ steps,
     const int32_t* __restrict__ chunk_node, const int32_t* __restrict__ chunk_steps, const int32_t* __restrict__ node_pend, float* __restrict__ pend_rows,
-    const int chunks) {
+    const int chunks, const int last_row) {
     constexpr int CH = kStreamCH, RPS = kStreamRPS;
     constexpr int SLOT = 2 * CH;               // floats per slot: num_b[CH] | den_b[CH]
     constexpr int WAVE_LDS = K * SLOT + 4 * 64;   // + the in-run end's transposition buffer [4 rows of lanes][64 values]
@@ -303,45 +303,44 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
             lo = load16(table, off), hi = load16(table, off + 64u);
         }
     };
-    auto stage_x = [&](StepRegs& R, const int j) {   // the descriptor and the row pieces of step j (their addresses need nothing else)
-        const int4 dj = sd[min(j, ns - 1)];   // (always a scalar load; steps past the end are empty steps)
+    // Every request of the pipeline is UNCONDITIONAL: hipcc's wait insertion counts only the requests it can prove were issued, so a
+    // wait for an older load behind loads inside an `if (live)` is computed as if those did not exist and drains them (measured: the
+    // same 1.9 us per step as with no pipeline at all).  A dead lane (g >= count) repeats the request of lane l of the step's first row,
+    // which coalesces with that lane's; what it receives is never used.
+    auto stage_x = [&](StepRegs& R, const int j, const int4 dj) {   // the descriptor and the row pieces of step j
         R.d = j < ns ? dj : empty;
-        forget(R.xl), forget(R.xh);
-        if (g < (R.d.z & 31)) {
-            const float* xr = e + (int64_t)R.d.x * H;   // (wave-uniform)
-            R.xl = load16(xr, xoff), R.xh = load16(xr, xoff + 64u);
-        }
+        const int p0 = min(R.d.x, last_row);   // (an empty step of a trailing node without in-edges points one past the end)
+        const float* xr = e + (int64_t)p0 * H;   // (wave-uniform)
+        const unsigned off = g < (R.d.z & 31) ? xoff : noff;
+        R.xl = load16(xr, off), R.xh = load16(xr, off + 64u);
     };
     auto stage_a0 = [&](StepRegs& R) {   // source ids and schedule bytes
-        forget(R.src), forget(R.meta);
-        if (g < (R.d.z & 31)) {
-            const int32_t* sp = srt_src + R.d.x;
-            const uint8_t* mp = edge_meta + R.d.x;
-            R.src = sp[g];
-            R.meta = mp[g];
-        }
+        const int p0 = min(R.d.x, last_row);
+        const int gg = g < (R.d.z & 31) ? g : 0;
+        const int32_t* sp = srt_src + p0;
+        const uint8_t* mp = edge_meta + p0;
+        R.src = sp[gg];
+        R.meta = mp[gg];
     };
     auto stage_a = [&](StepRegs& R) {
-        forget(R.a2l), forget(R.a2h), forget(R.a3l), forget(R.a3h);
-        forget(R.tsl), forget(R.tsh), forget(R.hil), forget(R.hih), forget(R.pi);
-        if (g < (R.d.z & 31)) {
-            gather(A2h, R.src, ldn, R.a2l, R.a2h);
-            const float* br = A3h + (int64_t)R.d.y * ldn;
-            R.a3l = load16(br, noff), R.a3h = load16(br, noff + 64u);
-            if (R.meta != kFar && (R.meta >> 6) >= kStLastFinal) {
-                if ((R.meta >> 6) == kStLastPending) {
-                    R.pi = node_pend[R.src];
-                } else {
-                    gather(h_out, R.src, H, R.tsl, R.tsh);
-                    gather(h_in, R.src, ldh, R.hil, R.hih);
-                }
-            }
-        }
+        gather(A2h, R.src, ldn, R.a2l, R.a2h);
+        const float* br = A3h + (int64_t)R.d.y * ldn;
+        R.a3l = load16(br, noff), R.a3h = load16(br, noff + 64u);
         R.a1j = A1h[(int64_t)R.d.y * ldn + cj];
         R.hnj = h_in[(int64_t)R.d.y * ldh + cj];
+        // (the closing rows' operands stay conditional: a handful of requests in ~40 % of the steps)
+        forget(R.tsl), forget(R.tsh), forget(R.hil), forget(R.hih), forget(R.pi);
+        if (g < (R.d.z & 31) && R.meta != kFar && (R.meta >> 6) >= kStLastFinal) {
+            if ((R.meta >> 6) == kStLastPending) {
+                R.pi = node_pend[R.src];
+            } else {
+                gather(h_out, R.src, H, R.tsl, R.tsh);
+                gather(h_in, R.src, ldh, R.hil, R.hih);
+            }
+        }
     };
     auto stage_c = [&](StepRegs& R) {
-        if (g < (R.d.z & 31)) {
+        if (g < (R.d.z & 31)) {   // (no vector-memory loads inside: see above)
             f32x4 sl, sh_;
 #pragma unroll
             for (int k = 0; k < 4; ++k) sl[k] = sigmoidf_(R.xl[k]), sh_[k] = sigmoidf_(R.xh[k]);
@@ -421,13 +420,15 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
         }
     };
 
-    stage_x(R0, 0), stage_x(R1, 1), stage_x(R2, 2), stage_x(R3, 3);
+    stage_x(R0, 0, sd[0]), stage_x(R1, 1, sd[min(1, ns - 1)]), stage_x(R2, 2, sd[min(2, ns - 1)]), stage_x(R3, 3, sd[min(3, ns - 1)]);
     stage_a0(R0), stage_a0(R1), stage_a0(R2);
     stage_a(R0), stage_a(R1);
+    int4 dnext = sd[min(4, ns - 1)];   // the descriptor of the step stage X takes next: a scalar load, one iteration ahead of its use
     // iteration q: C of step q; then X of q + 4, A0 of q + 3, A of q + 2
     auto iteration = [&](const int q, StepRegs& Rq, StepRegs& Rq2, StepRegs& Rq3, StepRegs& Rq4) {
         stage_c(Rq);
-        stage_x(Rq4, q + 4);
+        stage_x(Rq4, q + 4, dnext);
+        dnext = sd[min(q + 5, ns - 1)];
         stage_a0(Rq3);
         stage_a(Rq2);
     };
@@ -568,7 +569,7 @@ static int launch_stream(const StreamArgs& a, hipStream_t s) {
 #define GN_STREAM(BIG_)                                                                                                                                  \
     hipLaunchKernelGGL((k_aggregate_stream<K, BIG_>), dim3((unsigned)a.chunks), dim3(64 * waves), lds_bytes, s, a.e, a.H, a.A1h, a.A2h, a.A3h, a.ldn, a.h_in, \
                        a.ldh, a.h_out, a.scale, a.shift, a.in_ptr, a.srt_src, a.edge_meta, a.steps, a.chunk_node, a.chunk_steps, a.node_pend, a.pend_rows,     \
-                       a.chunks)
+                       a.chunks, (int)(a.num_edges - 1))
     if (big) GN_STREAM(true); else GN_STREAM(false);
 #undef GN_STREAM
     GN_LAUNCH_CHECK();
@@ -576,7 +577,7 @@ static int launch_stream(const StreamArgs& a, hipStream_t s) {
 }
 }  // namespace gnnome
 
-extern "C" int gnnome_node_aggregate_stream_f32(const float* e, int hidden, int64_t num_nodes, const float* A1h, const float* A2h, const float* A3h,
+extern "C" int gnnome_node_aggregate_stream_f32(const float* e, int hidden, int64_t num_nodes, int64_t num_edges, const float* A1h, const float* A2h, const float* A3h,
                                                 int ld_node, const int32_t* in_ptr, const int32_t* srt_src, const int32_t* out_ptr,
                                                 const int32_t* out_pos, const int32_t* out_dst, const float* h_in, int ld_h, float* h_out,
                                                 const float* norm_scale, const float* norm_shift, int num_chunks, int rows_per_step, int num_slots,
@@ -584,7 +585,7 @@ extern "C" int gnnome_node_aggregate_stream_f32(const float* e, int hidden, int6
                                                 const int32_t* node_pend, const int32_t* pend_nodes, const int32_t* counters, int64_t num_pending,
                                                 float* pend_rows, void* stream) {
     using namespace gnnome;
-    GN_REQUIRE(num_nodes > 0, "node_aggregate_stream: empty graph");
+    GN_REQUIRE(num_nodes > 0 && num_edges > 0 && num_edges < (1ll << 31), "node_aggregate_stream: empty graph");
     GN_REQUIRE(e && A1h && A2h && A3h && in_ptr && srt_src && out_ptr && out_pos && out_dst && h_in && h_out && norm_scale && norm_shift && chunk_node &&
                    chunk_steps && steps && edge_meta && node_pend && pend_nodes && counters, "node_aggregate_stream: null pointer");
     GN_REQUIRE(hidden == 64 || hidden == 128 || hidden == 256, "node_aggregate_stream: hidden=%d not in {64,128,256}", hidden);
@@ -602,7 +603,7 @@ extern "C" int gnnome_node_aggregate_stream_f32(const float* e, int hidden, int6
     a.e = e, a.H = hidden, a.A1h = A1h, a.A2h = A2h, a.A3h = A3h, a.ldn = ld_node, a.h_in = h_in, a.ldh = ld_h, a.h_out = h_out;
     a.scale = norm_scale, a.shift = norm_shift, a.in_ptr = in_ptr, a.srt_src = srt_src, a.edge_meta = edge_meta;
     a.steps = reinterpret_cast<const int4*>(steps), a.chunk_node = chunk_node, a.chunk_steps = chunk_steps, a.node_pend = node_pend;
-    a.pend_rows = pend_rows, a.chunks = num_chunks, a.num_nodes = num_nodes;
+    a.pend_rows = pend_rows, a.chunks = num_chunks, a.num_nodes = num_nodes, a.num_edges = num_edges;
     // the kernel is built for 62 slots (the LDS a wave owns is a compile-time size); a schedule built for fewer slots runs on it unchanged
     const int rc = launch_stream(a, s);
     if (rc != GNNOME_OK) return rc;

@@ -377,7 +377,7 @@ def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_n
     with _on(h_in.device):
         if sched is not None:
             pend = torch.empty((max(sched.num_pending, 1), 3, hidden), dtype=torch.float32, device=h_in.device)
-            _lib.check(lib.gnnome_node_aggregate_stream_f32(_ptr(e), hidden, n_out, _ptr(A1h), _ptr(A2h), _ptr(A3h), ldn, _ptr(views.in_ptr),
+            _lib.check(lib.gnnome_node_aggregate_stream_f32(_ptr(e), hidden, n_out, views.num_edges, _ptr(A1h), _ptr(A2h), _ptr(A3h), ldn, _ptr(views.in_ptr),
                                                             _ptr(views.srt_src), _ptr(views.out_ptr), _ptr(views.out_pos), _ptr(views.out_dst),
                                                             _ptr(h_in), ldh, _ptr(h_out), _ptr(scale), _ptr(shift), sched.chunks,
                                                             STREAM_ROWS_PER_STEP, STREAM_SLOTS, _ptr(sched.chunk_node), _ptr(sched.chunk_steps),

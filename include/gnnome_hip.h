@@ -235,7 +235,7 @@ int gnnome_build_stream_schedule(int64_t num_nodes, int64_t num_edges, const int
                                  int rows_per_step, int num_slots, int32_t* chunk_node, int32_t* chunk_steps, int32_t* steps,
                                  uint8_t* edge_meta, int32_t* node_pend, int32_t* pend_nodes, int32_t* counters, void* scratch,
                                  size_t scratch_bytes, void* stream);
-int gnnome_node_aggregate_stream_f32(const float* e, int hidden, int64_t num_nodes, const float* A1h, const float* A2h,
+int gnnome_node_aggregate_stream_f32(const float* e, int hidden, int64_t num_nodes, int64_t num_edges, const float* A1h, const float* A2h,
                                      const float* A3h, int ld_node, const int32_t* in_ptr, const int32_t* srt_src,
                                      const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst, const float* h_in,
                                      int ld_h, float* h_out, const float* norm_scale, const float* norm_shift, int num_chunks,

@@ -77,7 +77,7 @@ def _run(views, t, H, sched):
     out = torch.full((views.num_nodes, H), float("nan"), device=DEV)
     pend = torch.empty((max(sched.num_pending, 1), 3, H), device=DEV)
     p = ops._ptr
-    _lib.check(lib.gnnome_node_aggregate_stream_f32(p(t["e"]), H, views.num_nodes, p(A1), p(A2), p(A3), t["P"].stride(0), p(views.in_ptr), p(views.srt_src),
+    _lib.check(lib.gnnome_node_aggregate_stream_f32(p(t["e"]), H, views.num_nodes, views.num_edges, p(A1), p(A2), p(A3), t["P"].stride(0), p(views.in_ptr), p(views.srt_src),
                                                     p(views.out_ptr), p(views.out_pos), p(views.out_dst), p(t["h"]), H, p(out), p(t["scale"]),
                                                     p(t["shift"]), sched.chunks, 16, 62, p(sched.chunk_node), p(sched.chunk_steps), p(sched.steps),
                                                     p(sched.edge_meta), p(sched.node_pend), p(sched.pend_nodes), p(sched.counters), sched.num_pending,
