@@ -115,18 +115,22 @@ class KernelTimer:
         return sum(s.elapsed_time(t) for s, t in ev) / max(len(ev), 1), len(ev)
 
 
-def _pmc_traffic(args, hidden, e):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
-    from inside this process; tools/final_profiles.sh collects them per the guide - separate --pmc passes, FETCH_SIZE
-    doubled on gfx950 - and stamps the file with the .so it profiled).  Only quoted for that exact build and shape."""
-    if args.mode != "infer" or args.workload != "c2" or hidden != 128 or e != 1_000_000:
-        return None
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-        if name.endswith("_gate_pmc.json"):
-            with open(os.path.join(ROOT, "profiles", name)) as f:
+def _pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` (a substring of its name) from the committed PMC passes over one forward of `workload`
+    (FETCH_SIZE / WRITE_SIZE cannot be read from inside this process; tools/pmc_forward.sh collects them per the guide - separate
+    --pmc passes, FETCH_SIZE doubled on gfx950 - and tools/pmc_forward_json.py stamps the file with the .so it profiled).  Only quoted
+    for that exact build and workload: a stale file is never used."""
+    prof = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(prof), reverse=True):
+        if name.endswith(f"_forward_pmc_{workload}.json"):
+            with open(os.path.join(prof, name)) as f:
                 d = json.load(f)
-            if d.get("so_sha16") == so_sha16():
-                return d["hbm_bytes_per_launch"]
+            if d.get("so_sha16") != so_sha16():
+                continue
+            hits = [v for k, v in d["kernels"].items() if kernel in k]
+            if hits:
+                v = max(hits, key=lambda r: r["launches"])
+                return v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
     return None
 
 
@@ -714,7 +718,9 @@ def main():
     # the same shape): a pair around every launch of every kernel cost ~1.6 ms per step here (56 events, ~28 us
     # of pipeline bubble each) and inflated what it measured; a pair per gate launch still cost ~0.4 ms.
     # (N>1: rank 0 times its own launches; its gate kernel covers the edges incident to its node range)
-    dominant = [] if args.no_kernel_timers else ["edge_gate"]
+    # Round 5: the gate AND the aggregation carry a pair each (one launch in eight = one per step each), and the line's `roofline` is
+    # whichever of the two holds the larger share of the measured step (the aggregation had overtaken the gate).
+    dominant = [] if args.no_kernel_timers else ["edge_gate", "node_aggregate"]
     e_gate = e if world == 1 else plan.views.num_edges
     with KernelTimer(ops, dominant, every=8) as kt:
         for _ in range(args.warmup):
@@ -793,7 +799,7 @@ def main():
                     "kernel": ("k_edge_gate_pl" if hidden == 128 else "k_edge_gate_bf") + f" (fused B_3 GEMM as {arith} + u_add_v + bn_e + relu + residual)",
                     "bound": "hbm", "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK,
-                    "traffic": _pmc_traffic(args, hidden, e) if world == 1 else None,
+                    "traffic": _pmc_traffic(args.workload, "k_edge_gate_pl" if hidden == 128 else "k_edge_gate_bf") if (world == 1 and args.kind == "banded") else None,
                     "avg_launch_ms": gate_ms, "launches": gate_n, "algorithmic_bytes_per_launch": gate_bytes,
                     "fp32_equivalent_flops_per_launch": gate_flops, "fp32_equivalent_tflops": gate_flops / (gate_ms * 1e-3) / 1e12,
                     "mfma_16bit_frac": terms * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK, "arithmetic": arith,
@@ -804,7 +810,8 @@ def main():
                 res["roofline"] = {
                     "kernel": "k_edge_tile_f16 (H=256: fp16x3, e tiles by LDS-DMA, planes in place, W3 in registers, two workgroups per row)",
                     "bound": "hbm", "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                    "frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK,
+                    "traffic": _pmc_traffic(args.workload, "k_edge_tile_f16<0") if (world == 1 and args.kind == "banded") else None,
                     "avg_launch_ms": gate_ms, "launches": gate_n, "algorithmic_bytes_per_launch": gate_bytes,
                     "fp32_equivalent_tflops": gate_flops / (gate_ms * 1e-3) / 1e12,
                     "mfma_16bit_frac": terms * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK, "arithmetic": arith,
@@ -823,6 +830,30 @@ def main():
                 }
             if world > 1:
                 res["roofline"]["note"] = f"rank 0's launches: {e_gate} local edges (its node range's in- and out-edges)"
+            # the aggregation, timed in the same region on the same stream (one launch per step): if it holds the larger share of the
+            # step, IT is the line's roofline and the gate becomes the second record
+            n_agg = n if world == 1 else plan.n_own
+            if kt.events.get("node_aggregate"):
+                agg_ms_t, agg_n_t = kt.mean_ms("node_aggregate")
+                # algorithmic bytes (SURVEY.md 8d counts e' once per layer): e' read once + 3 index arrays + three node tables' worth of
+                # rows; the kernel's own operands touched once (4 node-table reads + h' written) are `operand_bytes_per_launch`
+                agg_bytes_t = 1.0 * e_gate * hidden * 4 + 3 * e_gate * 4 + 3 * n_agg * hidden * 4
+                agg_rec = {
+                    "kernel": "k_node_aggregate (sigmoid + both gated sums over in- / out-edges + node update, one wave per node; e' rows read by both passes)",
+                    "bound": "hbm", "achieved": agg_bytes_t / (agg_ms_t * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": agg_bytes_t / (agg_ms_t * 1e-3) / HBM_PEAK,
+                    "traffic": _pmc_traffic(args.workload, "k_node_aggregate") if (world == 1 and args.kind == "banded") else None,
+                    "avg_launch_ms": agg_ms_t, "launches": agg_n_t, "algorithmic_bytes_per_launch": agg_bytes_t,
+                    "operand_bytes_per_launch": 1.0 * e_gate * hidden * 4 + 3 * e_gate * 4 + 5 * n_agg * hidden * 4,
+                }
+                gate_share = kt.calls["edge_gate"] / args.steps * gate_ms / ms   # (launches per step x average launch; layer 0 runs the folded-encoder gate)
+                agg_share = kt.calls["node_aggregate"] / args.steps * agg_ms_t / ms
+                res["roofline"]["share_of_step"], agg_rec["share_of_step"] = gate_share, agg_share
+                if agg_share > gate_share:
+                    res["roofline"], res["roofline_second"] = agg_rec, res["roofline"]
+                else:
+                    res["roofline_second"] = agg_rec
+                res["roofline"]["chosen_by"] = "the larger measured share of the step among the two big kernels (HIP events on one launch of each per step, inside the timed region)"
         if timed and others:
             agg_ms, agg_n = kd.mean_ms("node_aggregate")
             # e' is read ONCE algorithmically (SURVEY.md 8d's B_layer has no second read of it); the kernel's in- and out-edge
@@ -838,7 +869,7 @@ def main():
                  "frac": agg_bytes / (agg_ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": agg_bytes},
                 {"kernel": "linear (all calls: node projections [N,H]x[H,5H] and predictor node halves)", "bound": "hbm",
                  "avg_launch_ms": lin_ms, "launches": lin_n},
-                {"kernel": "k_edge_score (bf16x6 tile GEMM + fp32 tail)", "bound": "hbm", "avg_launch_ms": sc_ms, "launches": sc_n,
+                {"kernel": "k_edge_score_ws<H, fp16x3> (weight-stationary streaming scorer: e W1e^T and the 64 -> 32 layer as fp16x3 on the f16 matrix cores, fp32 tail)", "bound": "hbm", "avg_launch_ms": sc_ms, "launches": sc_n,
                  "achieved": (e * hidden * 4.0 + 3 * e * 4.0) / (sc_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                  "frac": (e * hidden * 4.0 + 3 * e * 4.0) / (sc_ms * 1e-3) / HBM_PEAK},
                 {"kernel": "k_encode (node + edge)", "bound": "hbm", "avg_launch_ms": en_ms, "launches": en_n},
@@ -864,6 +895,8 @@ def main():
             torch.cuda.empty_cache()
             if not args.no_extras and args.workload == "c2":
                 res["target_10m"] = _single_gpu_forward(gnnome_amd, ops, make_graph, random_state_dict, "10m", args.kind, dev, 20, 3)
+                # the width of configs[3] / configs[4], driver-timed: one GPU's eighth of configs[3] (2.5M edges, H = 256)
+                res["h256_shard"] = _single_gpu_forward(gnnome_amd, ops, make_graph, random_state_dict, "c4shard", args.kind, dev, 20, 3)
                 res["train"] = _train_record(gnnome_amd, ops, g, n, e, hidden, dev, 20, 3, False, None)
                 t16 = _train_record(gnnome_amd, ops, g, n, e, hidden, dev, 20, 3, False, None, storage="bf16")
                 res["train"]["bf16_storage"] = {k: t16[k] for k in ("value", "ms_per_step", "loss", "activation_storage")}

@@ -312,7 +312,10 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
         const int p0 = min(R.d.x, last_row);   // (an empty step of a trailing node without in-edges points one past the end)
         const float* xr = e + (int64_t)p0 * H;   // (wave-uniform)
         const unsigned off = g < (R.d.z & 31) ? xoff : noff;
-        R.xl = load16(xr, off), R.xh = load16(xr, off + 64u);
+        // the e rows are read once: nontemporal, so that they do not push the chunk's window of table rows (A2h[src]: every row gathered
+        // ~10 times over ~25 steps) out of its share of the L2 - 64 chunks per XCD share 4 MB
+        R.xl = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xr) + off));
+        R.xh = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xr) + off + 64u));
     };
     auto stage_a0 = [&](StepRegs& R) {   // source ids and schedule bytes
         const int p0 = min(R.d.x, last_row);

@@ -164,10 +164,12 @@ class GraphViews:
         return r
 
 
-# The streaming aggregation (gnnome_node_aggregate_stream_f32): "auto" = whenever the graph's schedule says its numbering has the
-# locality the LDS slot window needs; False = always the one-wave-per-node kernel (gnnome_node_aggregate_f32).
+# The streaming aggregation (gnnome_node_aggregate_stream_f32): False = the one-wave-per-node kernel gnnome_node_aggregate_f32 everywhere (the
+# default: the streaming form is a MEASURED NEGATIVE on the MI355X - 0.29 against 0.20 ms per launch at configs[1], profiles/r05_stream_aggregate_*,
+# NOTES.md round 5); "auto" (or GNNOME_STREAM_AGGREGATE=auto) = the streaming kernel whenever the graph's schedule says its numbering has the
+# locality the LDS slot window needs.
 import os as _os
-STREAM_AGGREGATE = False if _os.environ.get("GNNOME_STREAM_AGGREGATE", "auto").lower() in ("0", "off", "false") else "auto"   # (A/B switch)
+STREAM_AGGREGATE = "auto" if _os.environ.get("GNNOME_STREAM_AGGREGATE", "off").lower() in ("1", "on", "auto", "true") else False
 STREAM_MIN_EDGES = 400_000      # below this the chunks get so short that their boundaries make a quarter of the rows far
 STREAM_MAX_FAR = 0.20           # far rows / E above which the graph is left to the gathering kernel (a uniform random graph: ~1.0)
 STREAM_ROWS_PER_CHUNK = 2048

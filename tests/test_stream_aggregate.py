@@ -120,9 +120,11 @@ def test_stream_and_gather_kernels_agree_through_ops_and_the_policy_picks():
     A1, A2, A3 = (t["P"][:, i * H:(i + 1) * H] for i in range(3))
     sched = views.stream_schedule()
     assert sched.usable and sched.far_fraction < 0.2, (sched.why, sched.far_fraction)
-    got = ops.node_aggregate(t["e"], A1, A2, A3, views, t["h"], 0, t["scale"], t["shift"])
-    saved, ops.STREAM_AGGREGATE = ops.STREAM_AGGREGATE, False
+    saved = ops.STREAM_AGGREGATE
     try:
+        ops.STREAM_AGGREGATE = "auto"
+        got = ops.node_aggregate(t["e"], A1, A2, A3, views, t["h"], 0, t["scale"], t["shift"])
+        ops.STREAM_AGGREGATE = False
         old = ops.node_aggregate(t["e"], A1, A2, A3, views, t["h"], 0, t["scale"], t["shift"])
     finally:
         ops.STREAM_AGGREGATE = saved

@@ -9,7 +9,11 @@ for leg in "$@"; do
                     timeout 300 python tools/stream_agg_time.py $a >> $out/stream_time.jsonl 2>> $out/stream_time.err; done; echo "stream_time rc=$?"; cat $out/stream_time.jsonl; tail -5 $out/stream_time.err ;;
     tests)        timeout 2400 python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 $out/pytest.log ;;
     bench)        timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc=$?"; tail -c 1500 $out/bench_default.json; tail -3 $out/bench_default.err ;;
-    bench_ab)     for v in auto off; do GNNOME_STREAM_AGGREGATE=$v timeout 300 python bench.py --no-cpu-baseline --steps 30 --warmup 5 > $out/bench_stream_$v.json 2> $out/bench_stream_$v.err; echo "bench $v rc=$?"; tail -c 700 $out/bench_stream_$v.json; done ;;
+    bench_ab)     for v in off auto; do GNNOME_STREAM_AGGREGATE=$v timeout 300 python bench.py --no-cpu-baseline --steps 30 --warmup 5 > $out/bench_stream_$v.json 2> $out/bench_stream_$v.err; echo "bench $v rc=$?"; tail -c 700 $out/bench_stream_$v.json; done ;;
+    agg_scaling)  timeout 400 python tools/agg_scaling.py 128 > $out/agg_scaling.jsonl 2> $out/agg_scaling.err; echo "agg_scaling rc=$?"; cat $out/agg_scaling.jsonl; tail -3 $out/agg_scaling.err ;;
+    pmc_stream)   timeout 1500 bash tools/pmc_stream.sh $out/pmc_stream > $out/pmc_stream.log 2>&1; echo "pmc_stream rc=$?"; tail -120 $out/pmc_stream.log ;;
+    pmc_forward)  for w in c2 c4shard; do rm -rf $out/pmc_fwd_$w; timeout 600 bash tools/pmc_forward.sh $out/pmc_fwd_$w $w > $out/r05_forward_hbm_traffic_$w.md 2>&1
+                    python tools/pmc_forward_json.py $out/pmc_fwd_$w profiles/r05_forward_pmc_$w.json $w; cp profiles/r05_forward_pmc_$w.json $out/; done ;;
     *) echo "unknown leg $leg" ;;
   esac
 done
