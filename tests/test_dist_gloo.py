@@ -339,3 +339,94 @@ def test_partitioned_forward_and_training_step_at_a_width_between_the_built_ones
             assert (o["grads"][k] - w).abs().max().item() <= 2e-3 * w.abs().max().item() + 2e-6, k
     for k in g_want:
         assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k
+
+
+# ---- eight ranks (round 5): the process-group size of BASELINE configs[3] / [4], end to end on the CPU -------------
+
+@pytest.mark.parametrize("kind", ["banded", "uniform"])
+def test_eight_ranks_inference_matches_the_oracle(kind, tmp_path):
+    """World 8 on a ~2k-node graph.  banded: a rank's halo comes from its two neighbours plus a few long-range rows, some send lists are
+    EMPTY (all_to_all with zero-row blocks, all-gather padding of ranks with different row counts); uniform: 7/8 of the edges are cut
+    and every rank talks to every other.  Logits of every rank against the unpartitioned oracle; every edge scored exactly once."""
+    n, e = 2048, 20480
+    gr = make_graph(n, e, seed=11, kind=kind)
+    sd = random_state_dict(64, num_layers=3, seed=5)
+    x = degree_features(gr["src"], gr["dst"], n)
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], hidden=64, layers=3, state_dict=sd)
+    outs = _run(8, case, tmp_path)
+    with torch.no_grad():
+        want = model_from_state_dict(sd).eval()((gr["src"], gr["dst"], n), x, gr["e"]).squeeze(1)
+    for o in outs:
+        assert o["logits"].shape == want.shape and (torch.sigmoid(o["logits"]) - torch.sigmoid(want)).abs().max().item() < 1e-4
+        assert torch.equal(o["logits"], outs[0]["logits"])
+    assert sum(o["n_own"] for o in outs) == n and sum(o["n_score"] for o in outs) == e
+    assert all(sum(o["recv"]) == o["n_local"] - o["n_own"] for o in outs)
+    empty_links = sum(1 for o in outs for c in o["send"] if c == 0)
+    if kind == "banded":
+        # the 1 % long-range edges give most rank pairs a row or two; some links stay empty
+        assert empty_links > 8
+        assert sum(o["e_local"] for o in outs) < 1.25 * e
+    else:
+        assert empty_links == 8              # only the diagonal
+        assert sum(o["e_local"] for o in outs) > 1.8 * e
+
+
+@pytest.mark.parametrize("kind", ["banded", "uniform"])
+def test_eight_ranks_training_step_matches_oracle_autograd(kind, tmp_path):
+    """One train-mode step at world 8 (configs[4]'s group size): BatchNorm statistics all-reduced with every edge counted once, halo
+    gradients returned through mostly-empty (banded) or all-to-all (uniform) links, parameter gradients summed over eight ranks -
+    loss, all gradients and the BatchNorm buffers against the oracle's autograd on the unpartitioned graph; identical on every rank."""
+    from oracle.symgated_oracle import OracleModel, bce_loss
+    from test_train_host import check_grads
+    n, e, layers = 1024, 10240, 2
+    gr = make_graph(n, e, seed=12, kind=kind)
+    x = degree_features(gr["src"], gr["dst"], n)
+    sd = random_state_dict(64, num_layers=layers, seed=3)
+    om = OracleModel(2, 2, 64, 16, layers, 64, "batch", dropout=0.0)
+    om.load_state_dict(sd)
+    om.train()
+    want = om((gr["src"], gr["dst"], n), x, gr["e"])
+    want_loss = bce_loss(want, gr["y"], gr["pos_weight"])
+    want_loss.backward()
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], y=gr["y"], pos_weight=gr["pos_weight"], hidden=64, layers=layers,
+                state_dict=sd, train=True)
+    outs = _run(8, case, tmp_path)
+    assert sum(o["n_score"] for o in outs) == e
+    for o in outs:
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(want.detach().squeeze(-1))).abs().max().item() < 1e-4
+        assert abs(o["loss"].item() - want_loss.item()) < 1e-5
+        check_grads(o["grads"], {k: p.grad for k, p in om.named_parameters()}, rtol=2e-3)
+        for k, b in om.named_buffers():
+            assert torch.allclose(o["buffers"][k].float(), b.float(), atol=1e-5, rtol=1e-4), k
+    for k in outs[0]["grads"]:
+        assert all(torch.equal(outs[0]["grads"][k], o["grads"][k]) for o in outs[1:]), k
+
+
+def test_eight_ranks_plan_from_slices_and_ranks_that_own_almost_nothing(tmp_path):
+    """from_slices at world 8 (uneven slices, rank order) equals from_global array by array and gives the same logits; and a graph whose
+    edges all sit on a few nodes, so that the balanced split leaves several ranks with node ranges that carry (almost) no edges:
+    empty local edge lists, empty halos, zero-row score blocks must still assemble the full result."""
+    n, e = 2048, 20480
+    gr = make_graph(n, e, seed=13, kind="banded")
+    sd = random_state_dict(64, num_layers=2, seed=1)
+    x = degree_features(gr["src"], gr["dst"], n)
+    case = dict(src=gr["src"], dst=gr["dst"], num_nodes=n, x=x, e=gr["e"], hidden=64, layers=2, state_dict=sd)
+    (tmp_path / "whole").mkdir()
+    (tmp_path / "sliced").mkdir()
+    whole = _run(8, case, tmp_path / "whole")
+    sliced = _run(8, dict(case, sliced=True), tmp_path / "sliced")
+    assert all(o["sliced_equal"] for o in sliced)
+    assert all(torch.equal(a["logits"], b["logits"]) for a, b in zip(whole, sliced))
+    # 64 nodes, all 600 edges among the first 3 of them: at most three ranks can own a node with edges, the others get edgeless ranges
+    g = torch.Generator().manual_seed(3)
+    src, dst = torch.randint(0, 3, (600,), generator=g).int(), torch.randint(0, 3, (600,), generator=g).int()
+    feat = torch.randn(600, 2, generator=g)
+    xs = degree_features(src, dst, 64)
+    case = dict(src=src, dst=dst, num_nodes=64, x=xs, e=feat, hidden=64, layers=2, state_dict=sd)
+    (tmp_path / "skew").mkdir()
+    outs = _run(8, case, tmp_path / "skew")
+    with torch.no_grad():
+        want = model_from_state_dict(sd).eval()((src, dst, 64), xs, feat).squeeze(1)
+    assert sum(1 for o in outs if o["e_local"] == 0) >= 4 and sum(o["n_own"] for o in outs) == 64 and sum(o["n_score"] for o in outs) == 600
+    for o in outs:
+        assert (torch.sigmoid(o["logits"]) - torch.sigmoid(want)).abs().max().item() < 1e-4 and torch.equal(o["logits"], outs[0]["logits"])
