@@ -291,8 +291,10 @@ __global__ __launch_bounds__(512) void k_edge_score_ws(
         for (int i = 0; i < 8; ++i) {
             float* zr = Zs + (4 * i + grow) * LDZ + 4 * gc4;
             f32x4 z = *reinterpret_cast<const f32x4*>(zr) + g[i];
+            // F16: an operand beyond fp16's range (an e element, or a z1 value below) leaves the matrix cores as inf / NaN and must not come out of
+            // the relu as 0 - fmaxf(NaN, 0) = 0 would hand back a finite, wrong logit; t - t is 0 iff t is finite
 #pragma unroll
-            for (int j = 0; j < 4; ++j) z[j] = fmaxf(z[j], 0.f);
+            for (int j = 0; j < 4; ++j) z[j] = (!F16 || z[j] - z[j] == 0.f) ? fmaxf(z[j], 0.f) : __builtin_nanf("");
             *reinterpret_cast<f32x4*>(zr) = z;
         }
         // z2 = relu(W2 z1 + b2) on the exact-fp32 matrix cores (K = 64), logit = W3 . z2 + b3
@@ -328,7 +330,8 @@ __global__ __launch_bounds__(512) void k_edge_score_ws(
         float mine = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float sum = half_wave_sum(fmaxf(acc2[r], 0.f) * w3);
+            const float t2 = acc2[r];
+            const float sum = half_wave_sum(((!F16 || t2 - t2 == 0.f) ? fmaxf(t2, 0.f) : __builtin_nanf("")) * w3);
             if (cl == r) mine = sum;
         }
         if (cl < 16) {

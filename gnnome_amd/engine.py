@@ -85,6 +85,53 @@ class Prepared:
                                                _pad(model.linear2_edge.weight.detach(), H, ne), _pad(model.linear2_edge.bias.detach(), H)))
         self.layers = [prepare_layer(conv, device, arithmetic) for conv in model.gnn.convs]
         self.predictor = prepare_predictor(model.predictor, device)
+        # fp16x3's operand range (|x| < 65504), checked ONCE for the weights: a model with a weight outside it (or a non-finite one) runs
+        # its forward as bf16x6 from the start; the activations are checked per call (forward_in_range)
+        weights = [t for lw in self.layers for t in (lw.Wcat, lw.W3)] + [self.predictor["_W1"], self.predictor["W2"]]
+        amax = max((float(t.abs().max()) if t.numel() else 0.0) for t in weights) if weights else 0.0
+        self.force_bf16x6 = not (amax < hip_ops_fp16_max())
+        self.range_verified = self.range_failed = None
+
+
+def hip_ops_fp16_max():
+    return getattr(hip_ops, "FP16_MAX", 65504.0)
+
+
+def _inputs_key(views, x, e):
+    """Identity of one set of inputs: the caller's tensor OBJECTS and their versions (an in-place change bumps the version, another
+    tensor is another object) and the views."""
+    import weakref
+    return (weakref.ref(x), x._version, weakref.ref(e), e._version, weakref.ref(views))
+
+
+def _same_inputs(key, views, x, e):
+    return key is not None and key[0]() is x and key[1] == x._version and key[2]() is e and key[3] == e._version and key[4]() is views
+
+
+def forward_in_range(ops, prep, views, x, e, xd, ed, check=True):
+    """run_stack with the reference's DOMAIN (gated_gcn_full.py:97 is a plain fp32 nn.Linear): the forward's dense
+    products run as fp16x3, whose operands must stay below 65504; an element beyond that leaves those kernels as a NaN row (never as a
+    wrong finite value), so a forward whose logits are not all finite is run AGAIN as bf16x6 (fp32's range) and that is what the caller
+    gets - without touching gnnome_set_tuning itself.  The check is one device reduction + one host sync after everything has been
+    enqueued (the pattern of GraphViews(validate="lazy")), made once per set of inputs: a caller that scores the same tensors again
+    (a benchmark loop, CapturedForward's warm-up and recording) is not synchronised again.  Inputs that are themselves non-finite cost
+    one extra forward and come back non-finite, as from the reference.  check=False (`model.range_check = False`): no check, NaN rows
+    stay NaN rows."""
+    bf = getattr(ops, "bf16x6_arithmetic", None)
+    if bf is None or getattr(ops, "_TUNING", {}).get(10, 0) == 1:   # the checker backend / bf16x6 already selected
+        return run_stack(ops, prep, views, xd, ed)
+    if prep.force_bf16x6 or _same_inputs(prep.range_failed, views, x, e):
+        with bf():
+            return run_stack(ops, prep, views, xd, ed)
+    logits = run_stack(ops, prep, views, xd, ed)
+    if not check or _same_inputs(prep.range_verified, views, x, e):
+        return logits
+    if bool(torch.isfinite(logits).all()):
+        prep.range_verified = _inputs_key(views, x, e)
+        return logits
+    prep.range_failed = _inputs_key(views, x, e)
+    with bf():
+        return run_stack(ops, prep, views, xd, ed)
 
 
 def _norm_affine(norm_module, device):
@@ -381,7 +428,7 @@ def model_forward(model, graph, x, e):
     with torch.no_grad():
         xd = x.detach().to(device=device, dtype=torch.float32).contiguous()
         ed = e.detach().to(device=device, dtype=torch.float32).contiguous()
-        logits = run_stack(hip_ops, prep, views, xd, ed)
+        logits = forward_in_range(hip_ops, prep, views, x, e, xd, ed, check=getattr(model, "range_check", True))
     views.check_range()   # a fresh graph's deferred endpoint check, after the whole forward has been enqueued
     return logits.unsqueeze(1).to(out_device)
 

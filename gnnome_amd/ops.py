@@ -242,6 +242,25 @@ def set_tuning(key, value):
     _TUNING[int(key)] = int(value)
 
 
+FP16_MAX = 65504.0   # fp16x3's operand range (include/gnnome_hip.h, gnnome_linear_f32): beyond it an output row is NaN
+
+
+class bf16x6_arithmetic:
+    """`with ops.bf16x6_arithmetic():` - the forward's dense products as bf16x6 (fp32's range; round 3's arithmetic) instead of fp16x3 for
+    the duration: gnnome_set_tuning(10, 1), restored on exit.  engine.model_forward re-runs a forward under it when fp16x3's range did
+    not hold (an operand >= 65504 leaves the fp16x3 kernels as NaN rows, never as wrong finite values)."""
+
+    def __enter__(self):
+        self.prev = _TUNING.get(10, 0)
+        if self.prev != 1:
+            set_tuning(10, 1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != 1:
+            set_tuning(10, self.prev)
+
+
 def encode(x, W1, b1, W2, b2, gather=None, rows=None):
     lib = _lib.load()
     x, _ = _rows(x.contiguous(), "encode.in")
