@@ -394,7 +394,9 @@ def node_aggregate(e, A1h, A2h, A3h, views, h_in, norm_kind, scale, shift, num_n
     n_out = int(h_in.shape[0] if num_nodes_out is None else num_nodes_out)
     h_out = torch.empty((h_in.shape[0], hidden), dtype=torch.float32, device=h_in.device) if out is None else out
     assert h_out.is_contiguous() and h_out.shape == (h_in.shape[0], hidden) and h_out.dtype == torch.float32
-    sched = stream_schedule_for(views, e.shape[0], num_nodes_out, node_range, norm_kind) if h_in.shape[0] == views.num_nodes else None
+    sched = None
+    if STREAM_AGGREGATE and getattr(views, "num_nodes", None) == h_in.shape[0]:   # (opt-in; duck-typed views without the counts take the gathering kernel)
+        sched = stream_schedule_for(views, e.shape[0], num_nodes_out, node_range, norm_kind)
     with _on(h_in.device):
         if sched is not None:
             pend = torch.empty((max(sched.num_pending, 1), 3, hidden), dtype=torch.float32, device=h_in.device)
