@@ -483,8 +483,9 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: c2 at --gpus 1, 10m at --gpus > 1")
     ap.add_argument("--kind", default="banded", choices=["banded", "uniform", "permuted"],
                     help="permuted: the banded graph with shuffled read ids (locality exists, the numbering hides it)")
-    ap.add_argument("--node-order", default="input", choices=["input", "locality"],
-                    help="locality: renumber the reads by gnnome_amd.node_order.locality_order once, outside the timed region")
+    ap.add_argument("--node-order", default="auto", choices=["auto", "input", "locality"],
+                    help="auto (the model's default): one device statistic decides whether the node ids follow the layout; if not the reads are renumbered "
+                         "once by gnnome_amd.node_order.locality_order, outside the timed region (its cost is in `cold`); locality: always; input: never")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: one forward (BASELINE configs[1]); train: the training step as the headline value (configs[2], fp32)")
     ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"], help="train: model.activation_storage (bf16 = xe / dxe stored as bfloat16)")
@@ -586,6 +587,13 @@ def main():
             order_ms = (time.perf_counter() - t_o) * 1e3
             extras["node_order"] = dict(order_stats, ms=order_ms, kind="locality (gnnome_amd/node_order.py), computed once per graph, not timed")
             t0 = time.perf_counter()
+        elif args.node_order == "auto":   # what model.node_order = "auto" does for a cached graph object (gnnome_amd.graph.views_for)
+            from gnnome_amd import node_order as _order
+            node_perm, info = _order.auto_order(src, dst, n)
+            torch.cuda.synchronize()
+            order_ms = (time.perf_counter() - t0) * 1e3
+            extras["node_order"] = dict(info, decision_and_order_ms=order_ms, kind="auto: mean edge span against N / 16, then locality_order if the ids are shuffled; once per graph, not timed")
+            t0 = time.perf_counter()
         views = ops.GraphViews(src, dst, n, node_perm=node_perm)
         x = ops.degree_features(views)   # inference.py:416-420 on the device, off the views' CSR pointers
         torch.cuda.synchronize()
@@ -606,7 +614,7 @@ def main():
             torch.cuda.synchronize()
             t4 = time.perf_counter()
             del views2
-        cold = {"graph_views_and_features_ms": (t1 - t0) * 1e3, "first_call_ms": (t2 - t1) * 1e3, "weight_preparation_ms": (t1b - t1) * 1e3,
+        cold = {"node_order_ms": order_ms, "graph_views_and_features_ms": (t1 - t0) * 1e3, "first_call_ms": (t2 - t1) * 1e3, "weight_preparation_ms": (t1b - t1) * 1e3,
                 "first_forward_after_preparation_ms": (t2 - t1b) * 1e3,
                 "fresh_graph_warm_process_ms": (t4 - t3) * 1e3,
                 "note": "first call = weight preparation (weight_preparation_ms) + allocator growth + kernel code load + one forward "
@@ -658,6 +666,9 @@ def main():
         if args.node_order == "locality":   # the order needs the whole graph once; every rank computes the same permutation on its GPU
             from gnnome_amd import node_order as _order
             node_perm = _order.locality_order(g["src"].to(dev), g["dst"].to(dev), n)
+        elif args.node_order == "auto":   # the same statistic on every rank: the same decision and the same permutation
+            from gnnome_amd import node_order as _order
+            node_perm, _ = _order.auto_order(g["src"].to(dev), g["dst"].to(dev), n)
         if args.plan == "slices":
             # every rank starts from ITS 1/world of the edge list (as a reader splitting the input would): degrees all-reduced, edges
             # and their features shuffled to the owners of their endpoints (PartitionedGraph.from_slices) - no rank plans over E rows
@@ -778,8 +789,7 @@ def main():
         res["arithmetic"] = ("fp32 in / fp32 out; dense products as an exact-split fp32 emulation on the 16-bit matrix cores with fp32 accumulation: fp16x3 "
                              "(two fp16 planes per operand, three MFMAs; measured no further from an fp64 product than an fp32 GEMM - tests/test_f16x3_model.py) "
                              "for the forward at H >= 128, bf16x6 elsewhere; --tuning 10=1 = bf16x6 everywhere (round 3)")
-        if args.node_order != "input":
-            res["config"]["node_order"] = args.node_order
+        res["config"]["node_order"] = args.node_order + (f" -> {extras['node_order'].get('decision')}" if args.node_order == "auto" and "node_order" in extras else "")
         if args.tuning:
             res["tuning"] = args.tuning   # not the shipped defaults
         if "scaling_reference" in extras:
@@ -799,7 +809,7 @@ def main():
                     "kernel": ("k_edge_gate_pl" if hidden == 128 else "k_edge_gate_bf") + f" (fused B_3 GEMM as {arith} + u_add_v + bn_e + relu + residual)",
                     "bound": "hbm", "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK,
-                    "traffic": _pmc_traffic(args.workload, "k_edge_gate_pl" if hidden == 128 else "k_edge_gate_bf") if (world == 1 and args.kind == "banded") else None,
+                    "traffic": _pmc_traffic(args.workload, "k_edge_gate_pl<false, 0," if hidden == 128 else "k_edge_gate_bf") if (world == 1 and args.kind == "banded") else None,
                     "avg_launch_ms": gate_ms, "launches": gate_n, "algorithmic_bytes_per_launch": gate_bytes,
                     "fp32_equivalent_flops_per_launch": gate_flops, "fp32_equivalent_tflops": gate_flops / (gate_ms * 1e-3) / 1e12,
                     "mfma_16bit_frac": terms * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK, "arithmetic": arith,

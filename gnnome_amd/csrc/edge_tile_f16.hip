@@ -146,7 +146,11 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
     // ordinals past the end repeat the last tile (their loads are issued so that every wait counts the same instructions; nothing reads them)
     auto tile_of = [&](int r) {
         r = min(r, n - 1);
-        const int rr = (MODE != 4 && hh == 1 && (r ^ 1) < n) ? (r ^ 1) : r;   // the two workgroups of a pair swap every two tiles (see k_edge_gate_pl256)
+        // Round 5: both workgroups of a pair walk the tiles in the SAME order (their requests for a row meet in the L2's miss queue), and the
+        // gate's e' rows leave through nontemporal stores so that they do not push the e rows the pair shares out of the L2: HBM read per
+        // launch 5489 -> 3588 MB at the 2.5M-edge shard (e rows: 2560 MB), 1.515 -> 1.46 ms (profiles/r05_gate256_pair_sharing.txt).
+        // PROBE 64: round 4's order (the second workgroup swaps every two tiles, as k_edge_gate_pl256 does); PROBE 128: plain stores.
+        const int rr = (MODE != 4 && (PROBE & 64) && hh == 1 && (r ^ 1) < n) ? (r ^ 1) : r;
         return first + rr * stride;
     };
     auto tile_valid = [&](int r) { return (int)min((int64_t)TM, a.E - (int64_t)tile_of(r) * TM); };
@@ -465,6 +469,8 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
                             asm volatile("" ::"v"(y));
                         else if (X16)
                             *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.e_out) + ((int64_t)tile_of(i) * TM + rl + p) * ldo + colh + 4 * c4) = pk;
+                        else if (GATE && !(PROBE & 128))   // nontemporal: the e' rows are not read again by this launch - the L2 is for the e rows the pair shares
+                            __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(out + (int64_t)p * ldo));
                         else
                             *reinterpret_cast<f32x4*>(out + (int64_t)p * ldo) = y;
                     }
@@ -543,6 +549,9 @@ int gate_f16_launch(int mode, const GateBfArgs& a, int grid, hipStream_t s, bool
             case 24: return launch_f16<0, 24>(a, grid, s);
             case 31: return launch_f16<0, 31>(a, grid, s);
             case 32: return launch_f16<0, 32>(a, grid, s);   // B2h[dst] fetched for every piece (the form before the destination-run skip)
+            case 64: return launch_f16<0, 64>(a, grid, s);     // (correct results) round 4's tile order: the second workgroup of a pair swaps every two tiles
+            case 128: return launch_f16<0, 128>(a, grid, s);   // (correct results) plain e' stores
+            case 192: return launch_f16<0, 192>(a, grid, s);   // both = round 4's form
             default: break;
         }
     }

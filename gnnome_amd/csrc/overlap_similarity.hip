@@ -100,12 +100,14 @@ __global__ void k_overlap_finish(int64_t E, int32_t* __restrict__ dist_out) {
 
 template <int NP>
 __global__ __launch_bounds__(64) void k_overlap_banded(const uint8_t* __restrict__ reads, const int64_t* __restrict__ read_off,
-                                                       const uint8_t* __restrict__ symtab, const int32_t* __restrict__ src,
+                                                       const uint8_t* __restrict__ symtab, const int nsym, const int32_t* __restrict__ src,
                                                        const int32_t* __restrict__ dst, const int32_t* __restrict__ ol, int64_t E,
                                                        int* __restrict__ ticket, int32_t* __restrict__ dist_out) {
     __shared__ uint8_t st[512];
     const int lane = threadIdx.x;
-    for (int i = lane; i < 128; i += 64) reinterpret_cast<uint32_t*>(st)[i] = reinterpret_cast<const uint32_t*>(symtab)[i];
+    // entries >= num_symbols are read as num_symbols - 1, as the header says and the full-matrix kernel does: a raw entry > 15 would spill
+    // into the neighbouring 4-bit nibbles of the packed target symbols
+    for (int i = lane; i < 512; i += 64) st[i] = (uint8_t)min((int)symtab[i], nsym - 1);
     __syncthreads();
     for (;;) {
         int first = 0;
@@ -396,11 +398,11 @@ extern "C" int gnnome_overlap_edit_distance(const uint8_t* reads, const int64_t*
     if (tuning(kTuneOverlapBand) != 1 && num_symbols <= 16) {   // (key 9 = 1: full-matrix kernels only, for A/B runs and cross-checks)
         const int bgrid = (int)std::min<int64_t>((num_edges + 63) / 64, (int64_t)persistent_grid() * 32);
         if (num_symbols <= 4)
-            hipLaunchKernelGGL((k_overlap_banded<2>), dim3((unsigned)bgrid), dim3(64), 0, s, reads, read_off, symtab, src, dst, overlap_length, num_edges, tickets + 10, dist_out);
+            hipLaunchKernelGGL((k_overlap_banded<2>), dim3((unsigned)bgrid), dim3(64), 0, s, reads, read_off, symtab, num_symbols, src, dst, overlap_length, num_edges, tickets + 10, dist_out);
         else if (num_symbols <= 8)
-            hipLaunchKernelGGL((k_overlap_banded<3>), dim3((unsigned)bgrid), dim3(64), 0, s, reads, read_off, symtab, src, dst, overlap_length, num_edges, tickets + 10, dist_out);
+            hipLaunchKernelGGL((k_overlap_banded<3>), dim3((unsigned)bgrid), dim3(64), 0, s, reads, read_off, symtab, num_symbols, src, dst, overlap_length, num_edges, tickets + 10, dist_out);
         else
-            hipLaunchKernelGGL((k_overlap_banded<4>), dim3((unsigned)bgrid), dim3(64), 0, s, reads, read_off, symtab, src, dst, overlap_length, num_edges, tickets + 10, dist_out);
+            hipLaunchKernelGGL((k_overlap_banded<4>), dim3((unsigned)bgrid), dim3(64), 0, s, reads, read_off, symtab, num_symbols, src, dst, overlap_length, num_edges, tickets + 10, dist_out);
         GN_LAUNCH_CHECK();
     }
     // persistent waves: enough to fill every SIMD several times over (the kernel is VALU-bound, 8 waves per SIMD hide the

@@ -29,13 +29,33 @@ AUTO_MIN_NODES = 20_000      # "auto": smaller graphs live in cache whatever the
 AUTO_SPAN_FRACTION = 1 / 16  # "auto": renumber when the mean |src - dst| exceeds this fraction of the node count
 
 
+class _Entry:
+    """What is cached per graph object: the views over the caller's numbering, the views over renumbered nodes, and what "auto"
+    decided for this graph (None: not looked at yet).  Callers that ask for "input" (CapturedForward, the layer-level API, features.*)
+    and a model that renumbers no longer evict each other."""
+    __slots__ = ("input", "renumbered", "auto", "order_ms")
+
+    def __init__(self):
+        self.input = self.renumbered = self.auto = self.order_ms = None
+
+
+def _usable(hit, graph, device):
+    if hit is None or hit.device != device or hit.num_nodes != int(graph.num_nodes()):
+        return False
+    # (a graph mutated in place is a new graph to DGL as well - node_subgraph / reverse return fresh objects; the edge count is
+    # re-checked where the object can tell it without building the edge list)
+    count = getattr(graph, "num_edges", None)
+    return count is None or hit.num_edges == int(count())
+
+
 def views_for(graph, device, node_order="input"):
     """Build (or fetch the cached) views of `graph` on `device`.  Cached per graph OBJECT: callers such as
     train.py:96 / :336 create fresh sub-graphs every step, which simply miss the cache.
-    node_order ("input" | "locality" | "auto"; `model.node_order`): "locality" builds the views over nodes renumbered by
-    gnnome_amd.node_order.locality_order - for graphs whose ids do not follow the layout (graph_parser.py:174-181 numbers reads
-    in S-line order) and that are scored or trained on more than once: the order costs tens of forwards to compute; "auto" does
-    so only for cacheable graph objects of at least AUTO_MIN_NODES nodes whose mean edge span says the ids are shuffled.
+    node_order ("input" | "locality" | "auto"; `model.node_order`, default "auto" since round 5): "locality" builds the views over
+    nodes renumbered by gnnome_amd.node_order.locality_order - for graphs whose ids do not follow the layout (graph_parser.py:174-181
+    numbers reads in S-line order) and that are scored or trained on more than once: the order costs tens of forwards to compute;
+    "auto" does so only for cacheable graph objects of at least AUTO_MIN_NODES nodes whose mean edge span says the ids are shuffled
+    (one device reduction + one host sync per graph object, remembered), and keeps the renumbering only if it shortened the edges.
     Callers never see the renumbering (GraphViews.node_perm)."""
     if node_order not in NODE_ORDERS:
         raise ValueError(f"node_order={node_order!r} not in {NODE_ORDERS}")
@@ -43,39 +63,52 @@ def views_for(graph, device, node_order="input"):
         if graph.device != device:
             raise ValueError(f"GraphViews live on {graph.device}, inputs on {device}")
         return graph
-    key = None
+    entry = None
     if not isinstance(graph, (tuple, list)):
         try:
-            hit = _cache.get(graph)
-            key = graph
+            entry = _cache.get(graph)
+            if entry is None:
+                entry = _Entry()
+                _cache[graph] = entry
         except TypeError:  # not weak-referenceable
-            hit = None
-        if hit is not None and ((node_order == "locality" and hit.node_perm is None) or (node_order == "input" and hit.node_perm is not None)):
-            hit = None   # cached under the other numbering: build again
-        if hit is not None and hit.device == device and hit.num_nodes == int(graph.num_nodes()):
-            # (a graph mutated in place is a new graph to DGL as well - node_subgraph / reverse return fresh objects;
-            # the edge count is re-checked where the object can tell it without building the edge list)
-            count = getattr(graph, "num_edges", None)
-            if count is None or hit.num_edges == int(count()):
-                if hit._bad is not None:   # a graph whose deferred range check failed stays refused on every later call
-                    raise IndexError(hit._bad)
-                return hit
+            entry = None
+    if entry is not None:
+        want = node_order if node_order != "auto" else entry.auto
+        hit = entry.input if want == "input" else entry.renumbered if want == "locality" else None
+        if _usable(hit, graph, device):
+            if hit._bad is not None:   # a graph whose deferred range check failed stays refused on every later call
+                raise IndexError(hit._bad)
+            return hit
     src, dst, n = edge_list(graph)
     src = src.to(device=device, dtype=torch.int32).contiguous()
     dst = dst.to(device=device, dtype=torch.int32).contiguous()
-    perm = None
-    if node_order == "locality" or (node_order == "auto" and key is not None and n >= AUTO_MIN_NODES):
+    perm, order_ms = None, None
+    if node_order == "locality" or (node_order == "auto" and entry is not None and entry.auto != "input" and n >= AUTO_MIN_NODES):
         from . import node_order as order
         cs, cd = src.clamp(0, max(n - 1, 0)), dst.clamp(0, max(n - 1, 0))
-        if node_order == "locality" or order.mean_edge_span(cs, cd) > AUTO_SPAN_FRACTION * n:   # ("auto": one host sync, cached graphs only)
+        if node_order == "locality":
             perm = order.locality_order(cs, cd, n)
+        else:
+            perm, info = order.auto_order(cs, cd, n, AUTO_SPAN_FRACTION)
+            order_ms = info.get("order_ms")
     views = GraphViews(src, dst, n, validate="lazy", node_perm=perm)   # range check deferred: engine.model_forward / train_forward
-    if key is not None:
-        try:
-            _cache[key] = views
-        except TypeError:
-            pass
+    if entry is not None:
+        if perm is None:
+            entry.input = views
+        else:
+            entry.renumbered = views
+        if node_order == "auto":
+            entry.auto, entry.order_ms = ("input" if perm is None else "locality"), order_ms
     return views
+
+
+def auto_decision(graph):
+    """("input" | "locality" | None, ms spent on the order) - what node_order="auto" decided for this graph object, if it has been asked."""
+    try:
+        entry = _cache.get(graph)
+    except TypeError:
+        entry = None
+    return (None, None) if entry is None else (entry.auto, entry.order_ms)
 
 
 def reverse(graph, device=None):

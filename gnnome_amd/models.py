@@ -16,6 +16,9 @@ weights/weights.pt, same call.  Differences, all deliberate:
     matrix-core kernels and kernels that evaluate the layer's dense products in the reference's own ORDER (bit for bit
     what torch's CPU nn.Linear computes); "auto" uses the latter for layers whose eval-BatchNorm gain magnifies fp32
     reorder noise (engine.REFERENCE_ORDER_GAIN; the shipped checkpoint's layer 0).  Eval mode only.
+  * `model.node_order` ("auto" | "input" | "locality", default "auto"): graph_parser.py:174-181 numbers reads in S-line order, which need not be
+    the layout's; a cached graph object whose mean edge span says so gets its nodes renumbered once (gnnome_amd/node_order.py) - callers
+    never see it (x goes in and logits come out in their numbering).
   * `model.activation_storage` ("fp32" | "bf16", default "fp32"; train mode only): "bf16" keeps the pre-normalisation gate output
     and its gradient in HBM as bfloat16 between the kernels of the training step (gnnome_amd/train.py; arithmetic stays fp32).
 """
@@ -28,6 +31,8 @@ from .layers import ScorePredictor, SymGatedGCN_processor
 class SymGatedGCNModel(nn.Module):
     arithmetic = "auto"
     activation_storage = "fp32"
+    node_order = "auto"      # gnnome_amd.graph.views_for: renumber the nodes of a cached graph object whose ids do not follow the layout
+    range_check = True       # engine.forward_in_range: a forward that left fp16x3's operand range is run again as bf16x6
 
     def __init__(self, node_features, edge_features, hidden_features, hidden_ne_features, num_layers,
                  hidden_edge_scores, normalization, dropout=None):

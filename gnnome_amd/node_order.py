@@ -80,7 +80,7 @@ def locality_order(src, dst, num_nodes, pair=None, return_stats=False):
     key = key.long()
     # reads outside the kept graph: next to their best-placed neighbour (over all edges), else at the end
     lone = key < 0
-    big = torch.iinfo(torch.int64).max // 4
+    big = R + 1   # above every level key; (big * R + id stays far inside int64 - int64.max // 4 here wrapped around for any R > 4)
     if bool(lone.any()):
         nb_key = torch.where(key[adj.long()] < 0, torch.full_like(adj, big, dtype=torch.int64), key[adj.long()])
         best = torch.full((R,), big, dtype=torch.int64, device=dev).scatter_reduce(0, row.long(), nb_key, reduce="amin", include_self=True)
@@ -97,6 +97,27 @@ def locality_order(src, dst, num_nodes, pair=None, return_stats=False):
         return perm, {"reads": R, "adjacency_entries": int(adj.numel()), "supported_entries": int(sup.sum()), "components": int(ncomp),
                       "levels": int(key[~lone].max()) + 1 if bool((~lone).any()) else 0, "lone_reads": int(lone.sum())}
     return perm
+
+
+def auto_order(src, dst, num_nodes, span_fraction=1 / 16):
+    """node_order="auto": (perm or None, info).  One device statistic decides - the mean |src - dst| of the edge list; beyond
+    span_fraction * N the ids do not follow the layout (a layout-ordered assembly graph: ~2 x its degree; a shuffled one or a uniform
+    random one: ~N / 3) and locality_order runs; its result is kept only if it at least halved that span (a graph without locality,
+    e.g. a uniform random one, is left alone).  info: span_before, span_after, order_ms, decision."""
+    import time
+    before = mean_edge_span(src, dst)
+    info = {"span_before": before, "threshold": span_fraction * num_nodes, "decision": "input"}
+    if before <= span_fraction * num_nodes:
+        return None, info
+    torch.cuda.synchronize(src.device) if src.is_cuda else None
+    t0 = time.perf_counter()
+    perm = locality_order(src, dst, num_nodes)
+    after = mean_edge_span(perm[src.long()], perm[dst.long()])
+    info["order_ms"], info["span_after"] = (time.perf_counter() - t0) * 1e3, after
+    if after > 0.5 * before:
+        return None, info
+    info["decision"] = "locality"
+    return perm, info
 
 
 def mean_edge_span(src, dst):

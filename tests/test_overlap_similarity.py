@@ -259,3 +259,41 @@ def test_endpoints_out_of_range_are_reported_by_the_kernel_itself():
     want, _ = overlap_oracle.calculate_similarities(reads, [src[i] for i in good], [dst[i] for i in good], [ol[i] for i in good])
     got = dist.cpu().tolist()
     assert [got[i] for i in good] == want and [got[i] for i in (2, 3, 4)] == [-1, -1, -1]
+
+
+@pytest.mark.gpu
+def test_symbol_table_entries_beyond_the_alphabet_read_as_its_last_symbol_in_every_kernel():
+    """include/gnnome_hip.h: entries >= num_symbols are read as num_symbols - 1.  The banded pass packs symbols into 4-bit nibbles and used to
+    copy the table raw: an entry > 15 corrupted the neighbouring columns.  Here T (the last of A, C, G, T) is entered as 77."""
+    import ctypes
+
+    from gnnome_amd import _lib, overlap
+    from gnnome_amd.ops import _ptr, _stream, set_tuning
+    rng = random.Random(8)
+    reads = _overlapping_reads(rng, [600, 700, 650, 800], 0.01)
+    src, dst, ol = [0, 2, 4, 1, 3], [2, 4, 6, 3, 5], [300, 350, 320, 280, 310]
+    data, off = overlap.pack_reads(reads)
+    symtab, nsym = overlap.symbol_table(data)
+    assert nsym == 4 and int(symtab[ord("T")]) == 3
+    odd = symtab.clone()
+    odd[ord("T")] = 77
+    odd[256 + ord("A")] = 77       # (the complement of A)
+    d = dev()
+    t = lambda x, dt: torch.as_tensor(x, dtype=dt).to(d)  # noqa: E731
+    data, off = data.to(d), off.to(d)
+    s_, d_, o_ = t(src, torch.int32), t(dst, torch.int32), t(ol, torch.int32)
+    lib = _lib.load()
+    need = ctypes.c_size_t(0)
+    _lib.check(lib.gnnome_overlap_workspace_bytes(ctypes.byref(need)), "ws")
+    ws = torch.empty(int(need.value), dtype=torch.uint8, device=d)
+    got = {}
+    for band in (0, 1):       # 0: banded pass first, 1: full-matrix kernels only
+        set_tuning(9, band)
+        for name, tab in (("plain", symtab), ("odd", odd)):
+            dist = torch.full((len(src),), -7, dtype=torch.int32, device=d)
+            _lib.check(lib.gnnome_overlap_edit_distance(_ptr(data), _ptr(off), len(reads), _ptr(tab.to(d)), nsym, _ptr(s_), _ptr(d_), _ptr(o_), len(src),
+                                                        _ptr(dist), None, _ptr(ws), ws.numel(), _stream(d)), "overlap_edit_distance")
+            got[(band, name)] = dist.cpu().tolist()
+    set_tuning(9, 0)
+    want, _ = overlap_oracle.calculate_similarities(reads, src, dst, ol)
+    assert all(v == want for v in got.values()), got

@@ -28,6 +28,7 @@ W3 = torch.randn(H, H, device=dev, generator=gen) / H ** 0.5
 sc, sh = torch.rand(H, device=dev, generator=gen) * 0.1, torch.randn(H, device=dev, generator=gen)
 ops.set_tuning(0, a.variant)
 ops.set_tuning(1, a.ablation)
+out = torch.empty_like(ee) if H == 256 else None   # (the H = 256 edge-tile kernel wants separate buffers: in place runs another kernel)
 for _ in range(a.reps):
-    ops.edge_gate(ee, P[:, 3 * H:4 * H], P[:, 4 * H:], views, W3, 0, sc, sh)
+    ops.edge_gate(ee, P[:, 3 * H:4 * H], P[:, 4 * H:], views, W3, 0, sc, sh, out=out)
 torch.cuda.synchronize()

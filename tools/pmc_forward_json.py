@@ -18,7 +18,7 @@ def main():
     for k, c in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
         with open(os.path.join(src, c, "p_counter_collection.csv")) as f:
             for row in csv.DictReader(f):
-                name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("gnnome::", "")
+                name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("gnnome::", "")
                 tot[name][k] += float(row["Counter_Value"])
                 if k == 0:
                     tot[name][2] += 1
