@@ -312,6 +312,53 @@ def test_high_gain_layer_at_hidden_256():
 
 
 @pytest.mark.gpu
+def test_reference_order_is_needed_and_sufficient_at_hidden_256():
+    """the test above cannot tell the modes apart (2e-6 in all three).  Here layer 0's gate input is built the way
+    the shipped checkpoint's is, only more so: a large common offset (B_3's bias ~ 300) with little variation (weights x 0.01), and a
+    BatchNorm whose running statistics MATCH that input (a trained-like state: mean ~ 300, var ~ 5e-6, gain ~ 500) - its output is
+    of order one and carries every bit of fp32 rounding of the pre-activation, magnified.  The fp32 oracle itself is 9e-4 from the fp64
+    truth on it.  "fast" (fp16x3 / bf16x6: another fp32 number) must MISS the 1e-4 bar against the oracle, "auto" must send exactly that
+    layer through the K = 256 reference-order kernels and hold it with a wide margin - the mechanism is needed, and it is sufficient."""
+    from gnnome_amd.synth import random_state_dict
+    from gnnome_amd import engine
+    hidden, n, e = 256, 6000, 60_000
+    gr = make_graph(n, e, seed=2, kind="banded")
+    x = degree_features(gr["src"], gr["dst"], n)
+    graph = (gr["src"], gr["dst"], n)
+    sd = random_state_dict(hidden, seed=4)
+    for k in ("B_1", "B_2", "B_3"):
+        sd[f"gnn.convs.0.{k}.weight"] = sd[f"gnn.convs.0.{k}.weight"] * 0.01
+    sd["gnn.convs.0.B_3.bias"] = 300.0 * (1 + 0.3 * torch.randn(hidden, generator=torch.Generator().manual_seed(1)))
+    om = model_from_state_dict(sd, dtype=torch.float64).eval()
+    with torch.no_grad():   # the statistics of layer 0's gate input on this graph, in fp64
+        h = om.linear2_node(torch.relu(om.linear1_node(x.double())))
+        ee = om.linear2_edge(torch.relu(om.linear1_edge(gr["e"].double())))
+        c = om.gnn.convs[0]
+        pre = c.B_1(h)[gr["src"].long()] + c.B_2(h)[gr["dst"].long()] + c.B_3(ee)
+    sd["gnn.convs.0.bn_e.running_mean"] = pre.mean(0).float()
+    sd["gnn.convs.0.bn_e.running_var"] = pre.var(0, unbiased=False).float()
+    sd["gnn.convs.0.bn_e.weight"] = sd["gnn.convs.0.bn_e.weight"].abs() + 0.5
+    with torch.no_grad():
+        ref32 = model_from_state_dict(sd).eval()(graph, x, gr["e"])
+        ref64 = model_from_state_dict(sd, dtype=torch.float64).eval()(graph, x.double(), gr["e"].double()).float()
+    m = gnnome_amd.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch").eval()
+    m.load_state_dict(sd)
+    m.to(dev())
+    res = {"oracle32_vs_fp64": _dprob(ref32, ref64), "gain": float(engine.Prepared(m, dev()).layers[0].gain_e)}
+    for mode in ("auto", "reference", "fast"):
+        m.arithmetic = mode
+        out = m(graph, x.to(dev()), gr["e"].to(dev()))
+        res[mode + "_vs_oracle32"] = _dprob(out, ref32)
+        res[mode + "_vs_fp64"] = _dprob(out, ref64)
+        if mode == "auto":
+            assert [lw.ref for lw in engine.Prepared(m, dev()).layers] == [True] + [False] * 7
+    _record("sensitive_layer_h256", nodes=n, edges=e, **res)
+    assert res["oracle32_vs_fp64"] > 3e-4 and res["gain"] > 300, res            # the construction is as sensitive as intended
+    assert res["fast_vs_oracle32"] > PROB_TOL, res                                # without the reference-order kernels the bar is missed
+    assert res["auto_vs_oracle32"] < AUTO_TOL and res["reference_vs_oracle32"] < AUTO_TOL, res
+
+
+@pytest.mark.gpu
 def test_goldens_in_every_arithmetic_mode(shipped_weights):
     m = gnnome_amd.SymGatedGCNModel(2, 2, 64, 16, 8, 64, "batch").eval()
     m.load_state_dict(shipped_weights)

@@ -14,6 +14,14 @@ for leg in "$@"; do
     pmc_stream)   timeout 1500 bash tools/pmc_stream.sh $out/pmc_stream > $out/pmc_stream.log 2>&1; echo "pmc_stream rc=$?"; tail -120 $out/pmc_stream.log ;;
     pmc_forward)  for w in c2 c4shard; do rm -rf $out/pmc_fwd_$w; timeout 600 bash tools/pmc_forward.sh $out/pmc_fwd_$w $w > $out/r05_forward_hbm_traffic_$w.md 2>&1
                     python tools/pmc_forward_json.py $out/pmc_fwd_$w profiles/r05_forward_pmc_$w.json $w; cp profiles/r05_forward_pmc_$w.json $out/; done ;;
+    clocks)       timeout 300 python tools/clock_sample.py > $out/clock_samples.jsonl 2> $out/clock_samples.err; echo "clocks rc=$?"; cut -c1-700 $out/clock_samples.jsonl; tail -2 $out/clock_samples.err ;;
+    node_order)   timeout 900 python -m pytest tests/test_node_order.py tests/test_overlap_similarity.py tests/test_edge_tile_f16.py -m gpu -x -q > $out/node_order_tests.log 2>&1; echo "node_order rc=$?"; tail -6 $out/node_order_tests.log
+                  for k in banded permuted uniform; do timeout 300 python bench.py --kind $k --no-cpu-baseline --no-extras --steps 50 --warmup 5 > $out/bench_c2_$k.json 2> $out/bench_c2_$k.err; python - $out/bench_c2_$k.json <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+print(sys.argv[1], round(d["ms_per_step"], 4), "ms", d["config"].get("node_order"), d["cold"].get("node_order_ms"))
+PY
+                  done ;;
     *) echo "unknown leg $leg" ;;
   esac
 done
