@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_gate(const float* e_in, f
                                                             const int32_t* __restrict__ srt_dst,
                                                             const float* __restrict__ W3, int ldw,
                                                             const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, int total_tiles) {
+                                                            const float* __restrict__ shift, int total_tiles, int norm_width) {
     constexpr int H = 32 * NB;
     __shared__ __attribute__((aligned(16))) float lds[tile_lds_floats<NB>() + 2 * kTileM];
     float* As = lds;
@@ -77,14 +77,17 @@ __global__ __launch_bounds__(kGemmThreads) void k_edge_gate(const float* e_in, f
         for (int nb = 0; nb < NB; ++nb) v[nb] = acc[nb][r];
         if (NORM == GNNOME_NORM_LAYER) {
             // a row lives in the NB registers of the 32 lanes sharing (lane >> 5)
+            // norm_width < H: a model narrower than the built width runs zero-padded - the statistics are those of its own channels
+            // (the padded ones hold exact zeros: they add nothing to the sum and are left out of the centred second moment)
             float s1 = 0.f;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) s1 += v[nb];
-            const float mean = half_wave_sum(s1) * (1.0f / H);
+            const float inv_w = 1.0f / (float)norm_width;
+            const float mean = half_wave_sum(s1) * inv_w;
             float s2 = 0.f;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) s2 += (v[nb] - mean) * (v[nb] - mean);
-            const float rstd = rsqrtf(half_wave_sum(s2) * (1.0f / H) + kNormEps);
+            for (int nb = 0; nb < NB; ++nb) s2 += (32 * nb + cl < norm_width) ? (v[nb] - mean) * (v[nb] - mean) : 0.f;
+            const float rstd = rsqrtf(half_wave_sum(s2) * inv_w + kNormEps);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) v[nb] = (v[nb] - mean) * rstd;
         }
@@ -569,18 +572,18 @@ int ws_linear_acc(const float* A, int64_t M, int K, const float* W, int ldw, flo
 template <int NB>
 static int launch_gate(const float* e_in, float* e_out, int64_t E, const float* B1h, const float* B2h, int ldn,
                        const int32_t* ss, const int32_t* sd, const float* W3, int ldw, int norm, const float* scale,
-                       const float* shift, hipStream_t s) {
+                       const float* shift, hipStream_t s, int norm_width = 32 * NB) {
     const int64_t tiles = (E + kTileM - 1) / kTileM;
     GN_REQUIRE(tiles < (1ll << 31), "edge_gate: too many tiles");
     if (norm == 2) {
         hipLaunchKernelGGL((k_edge_gate<NB, 2>), dim3((unsigned)tiles), dim3(kGemmThreads), 0, s, e_in, e_out, E, B1h, B2h, ldn,
-                           ss, sd, W3, ldw, scale, shift, (int)tiles);
+                           ss, sd, W3, ldw, scale, shift, (int)tiles, norm_width);
     } else if (norm == GNNOME_NORM_AFFINE) {
         hipLaunchKernelGGL((k_edge_gate<NB, GNNOME_NORM_AFFINE>), dim3((unsigned)tiles), dim3(kGemmThreads), 0, s, e_in,
-                           e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, scale, shift, (int)tiles);
+                           e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, scale, shift, (int)tiles, norm_width);
     } else {
         hipLaunchKernelGGL((k_edge_gate<NB, GNNOME_NORM_LAYER>), dim3((unsigned)tiles), dim3(kGemmThreads), 0, s, e_in,
-                           e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, scale, shift, (int)tiles);
+                           e_out, E, B1h, B2h, ldn, ss, sd, W3, ldw, scale, shift, (int)tiles, norm_width);
     }
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
@@ -597,7 +600,11 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
     if (num_edges == 0) return GNNOME_OK;
     GN_REQUIRE(e_in && e_out && B1h && B2h && srt_src && srt_dst && W3 && norm_scale && norm_shift,
                "edge_gate: null pointer");
+    // norm_kind = GNNOME_NORM_LAYER_OVER(w): LayerNorm whose statistics run over the first w channels (a zero-padded narrower model)
+    const int norm_width = (norm_kind >> 8) ? (norm_kind >> 8) : hidden;
+    norm_kind &= 0xFF;
     GN_REQUIRE(norm_kind == GNNOME_NORM_AFFINE || norm_kind == GNNOME_NORM_LAYER, "edge_gate: bad norm_kind %d", norm_kind);
+    GN_REQUIRE(norm_width >= 1 && norm_width <= hidden && (norm_width == hidden || norm_kind == GNNOME_NORM_LAYER), "edge_gate: bad norm width %d", norm_width);
     GN_REQUIRE(ld_node >= hidden && ldw >= hidden && ldw % 4 == 0, "edge_gate: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0), "edge_gate: e_in and W3 must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
@@ -632,9 +639,9 @@ extern "C" int gnnome_edge_gate_f32(const float* e_in, float* e_out, int64_t num
         return gate_stream_launch(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_scale, norm_shift, s);   // variant 9: round 2's streaming kernel
     }
     switch (hidden) {
-        case 64: return launch_gate<2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);
-        case 128: return launch_gate<4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);
-        case 256: return launch_gate<8>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s);
+        case 64: return launch_gate<2>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s, norm_width);
+        case 128: return launch_gate<4>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s, norm_width);
+        case 256: return launch_gate<8>(e_in, e_out, num_edges, B1h, B2h, ld_node, srt_src, srt_dst, W3, ldw, norm_kind, norm_scale, norm_shift, s, norm_width);
         default: set_error("edge_gate: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
 }

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
     const float* __restrict__ h_in, int ldh, float* __restrict__ h_out, const float* __restrict__ scale,
     const float* __restrict__ shift, int total_blocks, float* __restrict__ aux0, float* __restrict__ aux1,
     float* __restrict__ aux2, float* __restrict__ aux3, const int* __restrict__ hub_count, const int* __restrict__ hub_nodes,
-    const float* __restrict__ hub_partials, int64_t node0) {
+    const float* __restrict__ hub_partials, int64_t node0, int norm_width) {
     constexpr int LPR = H / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t node;
@@ -416,11 +416,13 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
         return;
     }
     if (NORM == GNNOME_NORM_LAYER) {
-        const float mean = row_sum<H>(v[0] + v[1] + v[2] + v[3]) * (1.0f / H);
+        // (norm_width < H: a zero-padded narrower model - statistics over its own channels, the padded ones hold exact zeros)
+        const float inv_w = 1.0f / (float)norm_width;
+        const float mean = row_sum<H>(v[0] + v[1] + v[2] + v[3]) * inv_w;
         float s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s2 += (v[k] - mean) * (v[k] - mean);
-        const float rstd = rsqrtf(row_sum<H>(s2) * (1.0f / H) + kNormEps);
+        for (int k = 0; k < 4; ++k) s2 += (c + k < norm_width) ? (v[k] - mean) * (v[k] - mean) : 0.f;
+        const float rstd = rsqrtf(row_sum<H>(s2) * inv_w + kNormEps);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (v[k] - mean) * rstd;
     }
@@ -570,7 +572,8 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
                       const int32_t* in_ptr, const int32_t* ss, const int32_t* out_ptr, const int32_t* out_pos,
                       const int32_t* od, const float* h_in, int ldh, float* h_out, int norm, const float* scale,
                       const float* shift, hipStream_t s, int mode = 0, float* aux0 = nullptr, float* aux1 = nullptr,
-                      float* aux2 = nullptr, float* aux3 = nullptr, int64_t node_begin = 0, int64_t node_end = -1) {
+                      float* aux2 = nullptr, float* aux3 = nullptr, int64_t node_begin = 0, int64_t node_end = -1, int norm_width = 0) {
+    if (norm_width <= 0) norm_width = H;
     // [node_begin, node_end): the rows the regular launch covers (gnnome_node_aggregate_range_f32); the hub path always works
     // on the whole graph [0, n_out) and runs with the range that starts at node 0
     if (node_end < 0) node_end = n_out;
@@ -628,7 +631,7 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
 #define GN_AGG_LAUNCH_S(NORM_, MODE_, FIN_, U_, WPS_, GRID_, SPLIT_)                                                                           \
     hipLaunchKernelGGL((k_node_aggregate<H, NORM_, MODE_, FIN_, U_, WPS_, SPLIT_>), dim3((unsigned)(GRID_)), dim3(kAggThreads), (FIN_) ? 0 : dyn, s, e, \
                        (FIN_) ? n_out : node_end, A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift,   \
-                       (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials, (FIN_) ? (int64_t)0 : node0)
+                       (int)blocks, aux0, aux1, aux2, aux3, hub_count, hub_nodes, hub_partials, (FIN_) ? (int64_t)0 : node0, norm_width)
 #define GN_AGG_LAUNCH(NORM_, MODE_, FIN_, U_, WPS_, GRID_) GN_AGG_LAUNCH_S(NORM_, MODE_, FIN_, U_, WPS_, GRID_, 1)
     // The regular launches run the split item loop (accumulate_items_split: 0.2207 -> 0.2103 ms per launch at configs[1], whole forward
     // 4.89 -> 4.78 ms, the same bits, the same 782 MB fetched); variant 6 keeps the single loop for A/B.  (A single loop with a
@@ -716,6 +719,9 @@ extern "C" int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num
     // e / srt_src / out_pos / out_dst may be NULL for a graph without edges (never dereferenced then)
     GN_REQUIRE(A1h && A2h && A3h && in_ptr && out_ptr && h_in && h_out && norm_scale && norm_shift,
                "node_aggregate: null pointer");
+    const int norm_width = (norm_kind >> 8) ? (norm_kind >> 8) : hidden;   // GNNOME_NORM_LAYER_OVER(w), see gnnome_edge_gate_f32
+    norm_kind &= 0xFF;
+    GN_REQUIRE(norm_width >= 1 && norm_width <= hidden && (norm_width == hidden || norm_kind == GNNOME_NORM_LAYER), "node_aggregate: bad norm width %d", norm_width);
     GN_REQUIRE(norm_kind == GNNOME_NORM_AFFINE || norm_kind == GNNOME_NORM_LAYER, "node_aggregate: bad norm_kind %d",
                norm_kind);
     GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ld_h >= hidden && ld_h % 4 == 0, "node_aggregate: bad strides");
@@ -724,9 +730,9 @@ extern "C" int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num
                "node_aggregate: tensors must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     switch (hidden) {
-        case 64: return launch_agg<64>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
-        case 128: return launch_agg<128>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
-        case 256: return launch_agg<256>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s);
+        case 64: return launch_agg<64>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, 0, -1, norm_width);
+        case 128: return launch_agg<128>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, 0, -1, norm_width);
+        case 256: return launch_agg<256>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, 0, -1, norm_width);
         default: set_error("node_aggregate: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
 }
@@ -739,6 +745,9 @@ extern "C" int gnnome_node_aggregate_range_f32(const float* e, int hidden, int64
     using namespace gnnome;
     GN_REQUIRE(num_nodes_out > 0, "node_aggregate_range: empty graph");
     GN_REQUIRE(A1h && A2h && A3h && in_ptr && out_ptr && h_in && h_out && norm_scale && norm_shift, "node_aggregate_range: null pointer");
+    const int norm_width = (norm_kind >> 8) ? (norm_kind >> 8) : hidden;   // GNNOME_NORM_LAYER_OVER(w), see gnnome_edge_gate_f32
+    norm_kind &= 0xFF;
+    GN_REQUIRE(norm_width >= 1 && norm_width <= hidden && (norm_width == hidden || norm_kind == GNNOME_NORM_LAYER), "node_aggregate_range: bad norm width %d", norm_width);
     GN_REQUIRE(norm_kind == GNNOME_NORM_AFFINE || norm_kind == GNNOME_NORM_LAYER, "node_aggregate_range: bad norm_kind %d", norm_kind);
     GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ld_h >= hidden && ld_h % 4 == 0, "node_aggregate_range: bad strides");
     GN_REQUIRE(((uintptr_t)A1h % 16 == 0) && ((uintptr_t)A2h % 16 == 0) && ((uintptr_t)A3h % 16 == 0) &&
@@ -746,9 +755,9 @@ extern "C" int gnnome_node_aggregate_range_f32(const float* e, int hidden, int64
                "node_aggregate_range: tensors must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     switch (hidden) {
-        case 64: return launch_agg<64>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, node_begin, node_end);
-        case 128: return launch_agg<128>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, node_begin, node_end);
-        case 256: return launch_agg<256>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, node_begin, node_end);
+        case 64: return launch_agg<64>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, node_begin, node_end, norm_width);
+        case 128: return launch_agg<128>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, node_begin, node_end, norm_width);
+        case 256: return launch_agg<256>(e, num_nodes_out, A1h, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, h_in, ld_h, h_out, norm_kind, norm_scale, norm_shift, s, 0, nullptr, nullptr, nullptr, nullptr, node_begin, node_end, norm_width);
         default: set_error("node_aggregate_range: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
 }

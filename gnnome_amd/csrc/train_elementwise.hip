@@ -150,8 +150,10 @@ __device__ __forceinline__ float lpr_sum(float v, int lpr) {
 // out = relu(LayerNorm(x) * gamma + beta) + res ; LayerNorm over the H entries of each row, biased variance, eps 1e-5
 __global__ __launch_bounds__(kEwThreads) void k_ln_relu_res(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ res,
-                                                            int64_t rows, int H, float* __restrict__ out) {
+                                                            int64_t rows, int H, int W, float* __restrict__ out) {
+    // W <= H: the statistics run over the first W channels (a zero-padded narrower model: the padded channels hold exact zeros)
     const int lpr = H / 4, c = (threadIdx.x % lpr) * 4, rpb = kEwThreads / lpr;
+    const float inv_w = 1.0f / (float)W;
     // whole rows only: a row never straddles two passes, idle lanes past the end still take part in the shuffles
     const int64_t passes = (rows + rpb - 1) / rpb;
     for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
@@ -159,11 +161,11 @@ __global__ __launch_bounds__(kEwThreads) void k_ln_relu_res(const float* __restr
         const bool live = r < rows;
         const int64_t off = (live ? r : 0) * H + c;
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
-        const float mean = lpr_sum(xv[0] + xv[1] + xv[2] + xv[3], lpr) * (1.0f / H);
+        const float mean = lpr_sum(xv[0] + xv[1] + xv[2] + xv[3], lpr) * inv_w;
         float s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s2 += (xv[j] - mean) * (xv[j] - mean);
-        const float rstd = rsqrtf(lpr_sum(s2, lpr) * (1.0f / H) + kNormEps);
+        for (int j = 0; j < 4; ++j) s2 += (c + j < W) ? (xv[j] - mean) * (xv[j] - mean) : 0.f;
+        const float rstd = rsqrtf(lpr_sum(s2, lpr) * inv_w + kNormEps);
         if (live) {
             const f32x4 rv = *reinterpret_cast<const f32x4*>(res + off);
             f32x4 o;
@@ -180,9 +182,10 @@ __global__ __launch_bounds__(kEwThreads) void k_ln_relu_res(const float* __restr
 // (column sums deterministic: per-workgroup partials + k_col_finish, as for BatchNorm)
 __global__ __launch_bounds__(kEwThreads) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int64_t rows,
-                                                       int H, float* __restrict__ dx, float* __restrict__ part) {
+                                                       int H, int W, float* __restrict__ dx, float* __restrict__ part) {
     __shared__ float red[2][kEwThreads * 4];
     const int lpr = H / 4, tid = threadIdx.x, c4 = tid % lpr, rsub = tid / lpr, rpb = kEwThreads / lpr, c = 4 * c4;
+    const float inv_w = 1.0f / (float)W;   // (W <= H: see k_ln_relu_res; a padded channel gets dx = 0)
     f32x4 acc_b = {0.f, 0.f, 0.f, 0.f}, acc_g = acc_b;
     const int64_t passes = (rows + rpb - 1) / rpb;
     for (int64_t pass = blockIdx.x; pass < passes; pass += gridDim.x) {
@@ -191,16 +194,16 @@ __global__ __launch_bounds__(kEwThreads) void k_ln_bwd(const float* __restrict__
         const int64_t off = (live ? r : 0) * H + c;
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
         const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + off);
-        const float mean = lpr_sum(xv[0] + xv[1] + xv[2] + xv[3], lpr) * (1.0f / H);
+        const float mean = lpr_sum(xv[0] + xv[1] + xv[2] + xv[3], lpr) * inv_w;
         float s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s2 += (xv[j] - mean) * (xv[j] - mean);
-        const float rstd = rsqrtf(lpr_sum(s2, lpr) * (1.0f / H) + kNormEps);
+        for (int j = 0; j < 4; ++j) s2 += (c + j < W) ? (xv[j] - mean) * (xv[j] - mean) : 0.f;
+        const float rstd = rsqrtf(lpr_sum(s2, lpr) * inv_w + kNormEps);
         f32x4 xh, g;
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            xh[j] = (xv[j] - mean) * rstd;
+            xh[j] = (c + j < W) ? (xv[j] - mean) * rstd : 0.f;
             const float dm = (xh[j] * gamma[c + j] + beta[c + j] > 0.f) ? dv[j] : 0.f;
             g[j] = dm * gamma[c + j];
             sg += g[j];
@@ -210,11 +213,11 @@ __global__ __launch_bounds__(kEwThreads) void k_ln_bwd(const float* __restrict__
                 acc_g[j] += dm * xh[j];
             }
         }
-        const float mg = lpr_sum(sg, lpr) * (1.0f / H), mgx = lpr_sum(sgx, lpr) * (1.0f / H);
+        const float mg = lpr_sum(sg, lpr) * inv_w, mgx = lpr_sum(sgx, lpr) * inv_w;
         if (live) {
             f32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = rstd * (g[j] - mg - xh[j] * mgx);
+            for (int j = 0; j < 4; ++j) o[j] = (c + j < W) ? rstd * (g[j] - mg - xh[j] * mgx) : 0.f;
             *reinterpret_cast<f32x4*>(dx + off) = o;
         }
     }
@@ -427,25 +430,29 @@ extern "C" int gnnome_bn_relu_res_x16(const uint16_t* x, const float* scale, con
 }
 
 extern "C" int gnnome_ln_relu_res_f32(const float* x, const float* gamma, const float* beta, const float* res, int64_t rows,
-                                      int hidden, float* out, void* stream) {
+                                      int hidden, int norm_width, float* out, void* stream) {
     GN_REQUIRE(rows >= 0 && ok_width(hidden), "ln_relu_res: hidden=%d not in {16,32,64,128,256}", hidden);
+    if (norm_width <= 0) norm_width = hidden;
+    GN_REQUIRE(norm_width <= hidden, "ln_relu_res: norm_width=%d exceeds hidden=%d", norm_width, hidden);
     if (rows == 0) return GNNOME_OK;
     GN_REQUIRE(x && gamma && beta && res && out, "ln_relu_res: null pointer");
     hipLaunchKernelGGL(k_ln_relu_res, dim3(ew_grid(rows * (hidden / 4))), dim3(kEwThreads), 0, (hipStream_t)stream, x, gamma, beta, res,
-                       rows, hidden, out);
+                       rows, hidden, norm_width, out);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
 
 extern "C" int gnnome_ln_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, int64_t rows, int hidden,
-                                 float* dx, float* dbeta, float* dgamma, void* workspace, size_t workspace_bytes, void* stream) {
+                                 int norm_width, float* dx, float* dbeta, float* dgamma, void* workspace, size_t workspace_bytes, void* stream) {
     GN_REQUIRE(rows >= 0 && ok_width(hidden), "ln_bwd: hidden=%d not in {16,32,64,128,256}", hidden);
+    if (norm_width <= 0) norm_width = hidden;
+    GN_REQUIRE(norm_width <= hidden, "ln_bwd: norm_width=%d exceeds hidden=%d", norm_width, hidden);
     if (rows == 0) return GNNOME_OK;
     GN_REQUIRE(dy && x && gamma && beta && dx && dbeta && dgamma, "ln_bwd: null pointer");
     GN_REQUIRE(workspace && workspace_bytes >= kColWorkspaceBytes && (uintptr_t)workspace % 16 == 0,
                "ln_bwd: workspace too small or misaligned (gnnome_colsum_workspace_bytes)");
     const unsigned grid = col_grid(rows, hidden);
-    hipLaunchKernelGGL(k_ln_bwd, dim3(grid), dim3(kEwThreads), 0, (hipStream_t)stream, dy, x, gamma, beta, rows, hidden, dx,
+    hipLaunchKernelGGL(k_ln_bwd, dim3(grid), dim3(kEwThreads), 0, (hipStream_t)stream, dy, x, gamma, beta, rows, hidden, norm_width, dx,
                        (float*)workspace);
     GN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)grid,

@@ -756,7 +756,9 @@ extern "C" int gnnome_score_tail_bwd_f32(const float* z1, const float* dscore, c
     switch (hidden_edge_scores) {
         case 32: hipLaunchKernelGGL(k_score_tail_bwd<32>, grid, block, 0, s, z1, dscore, srt_eid, num_edges, W2, b2, W3, dz1, dz2, u); break;
         case 64: hipLaunchKernelGGL(k_score_tail_bwd<64>, grid, block, 0, s, z1, dscore, srt_eid, num_edges, W2, b2, W3, dz1, dz2, u); break;
-        default: set_error("score_tail_bwd: hidden_edge_scores=%d not in {32,64}", hidden_edge_scores); return GNNOME_EINVAL;
+        // round 5: the widest built scorer (inference always took it) - the row-per-lane form, a rare configuration
+        case 128: hipLaunchKernelGGL(k_score_tail_bwd<128>, grid, block, 0, s, z1, dscore, srt_eid, num_edges, W2, b2, W3, dz1, dz2, u); break;
+        default: set_error("score_tail_bwd: hidden_edge_scores=%d not in {32,64,128}", hidden_edge_scores); return GNNOME_EINVAL;
     }
     GN_LAUNCH_CHECK();
     return GNNOME_OK;

@@ -39,8 +39,9 @@ ARITHMETIC_MODES = ("auto", "reference", "fast")
 # Widths the kernels are built for.  The reference takes any hidden_features / hidden_edge_scores (configs/hyperparameters.py:22-24);
 # an eval-mode BatchNorm model of another width runs on the next built width with ZERO-PADDED parameters, which is exact: a padded
 # channel has zero weights, zero bias and a zero affine norm, so it stays 0.0 through relu + residual, enters every product as a
-# zero addend at the END of the k-ascending sums, and the aggregation's padded columns are sums of 0.5 * 0.0.  (LayerNorm's statistics run
-# over the row: it stays with the built widths.  Train mode pads the same way on a twin model, train._padded_step.)
+# zero addend at the END of the k-ascending sums, and the aggregation's padded columns are sums of 0.5 * 0.0.  LayerNorm's statistics run
+# over the row: its kernels take the model's own width and leave the padded channels out (GNNOME_NORM_LAYER_OVER, round 5).  Train mode pads
+# the same way on a twin model, train._padded_step.
 BUILT_HIDDEN = (64, 128, 256)
 BUILT_SCORE_HIDDEN = (32, 64, 128)
 
@@ -59,12 +60,6 @@ def _pad(t, *shape):
     out = t.new_zeros(shape)
     out[tuple(slice(0, n) for n in t.shape)] = t
     return out
-
-
-def _refuse_padded_layer_norm(norm_module, width, padded):
-    if padded != width and not isinstance(norm_module, torch.nn.BatchNorm1d):
-        raise ValueError(f"normalization='layer' at hidden_features={width}: LayerNorm's statistics run over the row, so the zero-padding "
-                         f"that serves other widths does not apply - the kernels are built for {BUILT_HIDDEN}")
 
 
 class Prepared:
@@ -155,7 +150,12 @@ def _norm_affine(norm_module, device):
     if isinstance(norm_module, torch.nn.LayerNorm):
         if abs(norm_module.eps - 1e-5) > 1e-12:
             raise ValueError("LayerNorm eps other than 1e-5 is not supported by the HIP kernels")
-        return NORM_LAYER, dev(norm_module.weight), dev(norm_module.bias)
+        # a width between the built ones: zero-padded gamma / beta, and the row statistics over the model's OWN channels
+        # (GNNOME_NORM_LAYER_OVER(w) in include/gnnome_hip.h - the padded channels hold exact zeros; round 5)
+        own = int(norm_module.weight.numel())
+        width = padded_width(own)
+        kind = NORM_LAYER if width == own else (NORM_LAYER | (own << 8))
+        return kind, dev(_pad(norm_module.weight.detach(), width)), dev(_pad(norm_module.bias.detach(), width))
     raise TypeError(type(norm_module))
 
 
@@ -169,7 +169,6 @@ def prepare_layer(conv, device, arithmetic=None):
     lw = LayerWeights()
     width = conv.B_3.weight.shape[0]
     hidden = padded_width(width)
-    _refuse_padded_layer_norm(conv.bn_e, width, hidden)
     W = lambda lin: _pad(lin.weight.detach(), hidden, hidden)  # noqa: E731
     b = lambda lin: _pad(lin.bias.detach(), hidden)  # noqa: E731
     lw.Wcat = dev(torch.cat([W(conv.A_1), W(conv.A_2), W(conv.A_3), W(conv.B_1), W(conv.B_2)], 0))

@@ -25,11 +25,9 @@ class SymGatedGCN(nn.Module):
                              "(layers/processor.py:12-14); unequal widths are not supported")
         if not residual:
             raise ValueError("residual=False is never used by the reference drivers and is not supported")
-        # built widths: 64 (the reference's default, configs/hyperparameters.py:22), 128, 256; other widths up to 256 run zero-padded
-        # on the next built one with BatchNorm (engine.BUILT_HIDDEN; train mode: train._padded_step) - refused here where that does not apply
-        if engine.padded_width(in_channels) != in_channels and normalization == "layer":
-            raise ValueError(f"hidden_features={in_channels} with normalization='layer': the HIP kernels are built for "
-                             f"{engine.BUILT_HIDDEN}; other widths run zero-padded, which LayerNorm's row statistics do not allow")
+        # built widths: 64 (the reference's default, configs/hyperparameters.py:22), 128, 256; other widths up to 256 run zero-padded on the
+        # next built one (engine.BUILT_HIDDEN; train mode: train._padded_step) - with LayerNorm the statistics run over the model's own channels
+        engine.padded_width(in_channels)   # (raises above the largest built width)
         self.dropout = dropout if dropout else 0.0
         self.normalization = normalization
         self.residual = residual

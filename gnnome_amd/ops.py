@@ -734,22 +734,23 @@ def bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd, out=None):
     return dx
 
 
-def ln_relu_res(x, gamma, beta, res, out=None):
-    """relu(LayerNorm(x) * gamma + beta) + res (normalization='layer' in train mode)."""
+def ln_relu_res(x, gamma, beta, res, out=None, width=None):
+    """relu(LayerNorm(x) * gamma + beta) + res (normalization='layer' in train mode).  width: the statistics run over the first `width`
+    channels (a zero-padded narrower model; default: all)."""
     x, res = _dense(x, "ln_relu_res.x"), _dense(res, "ln_relu_res.res")
     out = torch.empty_like(x) if out is None else _dense(out, "ln_relu_res.out")
-    _call("gnnome_ln_relu_res_f32", x.device, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(res), x.shape[0], x.shape[1], _ptr(out))
+    _call("gnnome_ln_relu_res_f32", x.device, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(res), x.shape[0], x.shape[1], int(width or 0), _ptr(out))
     return out
 
 
-def ln_bwd(dy, x, gamma, beta, out=None):
+def ln_bwd(dy, x, gamma, beta, out=None, width=None):
     """-> (dx, dgamma, dbeta) of out = relu(LayerNorm(x) * gamma + beta) + res."""
     dy, x = _dense(dy, "ln_bwd.dy"), _dense(x, "ln_bwd.x")
     H = x.shape[1]
     dx = torch.empty_like(x) if out is None else _dense(out, "ln_bwd.out")
     s = (torch.empty if x.shape[0] > 0 else torch.zeros)((2, H), dtype=torch.float32, device=x.device)
     ws = _col_workspace(x.device)
-    _call("gnnome_ln_bwd_f32", x.device, _ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), x.shape[0], H, _ptr(dx), _ptr(s[0]), _ptr(s[1]),
+    _call("gnnome_ln_bwd_f32", x.device, _ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), x.shape[0], H, int(width or 0), _ptr(dx), _ptr(s[0]), _ptr(s[1]),
           _ptr(ws), ws.numel())
     return dx, s[1], s[0]
 

@@ -200,6 +200,7 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, sh, x, e_raw, names, *params):
         layer_norm = isinstance(model.gnn.convs[0].bn_e, torch.nn.LayerNorm)   # normalization='layer' (gated_gcn_full.py:40-42)
+        ln_width = model.__dict__.get("_gnnome_norm_width")    # a zero-padded twin (_padded_step): LayerNorm over the model's own channels
         ops, views = sh.ops, sh.views
         H = model.linear2_node.out_features
         n_own, n_local, e_own, e_local = sh.n_own, sh.n_local, sh.e_own, sh.e_local
@@ -245,7 +246,7 @@ class _TrainStep(torch.autograd.Function):
             if two_pass:
                 pass
             elif layer_norm:   # per-row statistics: nothing crosses rows (or ranks), and there are no running buffers
-                e_new = ops.ln_relu_res(xe, d(conv.bn_e.weight), d(conv.bn_e.bias), e)
+                e_new = ops.ln_relu_res(xe, d(conv.bn_e.weight), d(conv.bn_e.bias), e, width=ln_width)
             else:
                 if path == "moments":
                     mean_e, rstd_e, sc_e, sh_e = _bn_train_fused(sh, conv.bn_e, stats, updates=2)
@@ -258,7 +259,7 @@ class _TrainStep(torch.autograd.Function):
                                                          rows_alloc=n_local)
             h_next = new(n_local, H)
             if layer_norm:
-                ops.ln_relu_res(v[:n_own], d(conv.bn_h.weight), d(conv.bn_h.bias), h[:n_own], out=h_next[:n_own])
+                ops.ln_relu_res(v[:n_own], d(conv.bn_h.weight), d(conv.bn_h.bias), h[:n_own], out=h_next[:n_own], width=ln_width)
             else:
                 if _can_fuse_bn(sh, conv.bn_h):
                     mean_h, rstd_h, sc_h, sh_h = _bn_train_fused(sh, conv.bn_h, ops.batch_moments(v[:n_own]), updates=1)
@@ -305,6 +306,7 @@ class _TrainStep(torch.autograd.Function):
                                "retain_graph=True is not supported - run the forward again")
         ops, views = sh.ops, sh.views
         H = model.linear2_node.out_features
+        ln_width = model.__dict__.get("_gnnome_norm_width")
         n_own, n_local, e_own, e_local = sh.n_own, sh.n_local, sh.e_own, sh.e_local
         r = _roles(views.transposed)
         blk = lambda P, k: P[:, r[k] * H:(r[k] + 1) * H]  # noqa: E731
@@ -347,7 +349,7 @@ class _TrainStep(torch.autograd.Function):
             dv = (torch.zeros if n_local > n_own else torch.empty)((n_local, H), dtype=torch.float32, device=dev)
             if s["sc_h"] is None:   # LayerNorm: per-row backward, linear in dy, so partial gradients of replicas simply add
                 _, g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = ops.ln_bwd(dh[:n_own], s["v"][:n_own], d(conv.bn_h.weight),
-                                                                             d(conv.bn_h.bias), out=dv[:n_own])
+                                                                             d(conv.bn_h.bias), out=dv[:n_own], width=ln_width)
             else:
                 g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = _bn_bwd(sh, dh[:n_own], s["v"][:n_own], s["sc_h"], s["sh_h"], s["mean_h"],
                                                                        s["rstd_h"], sh.n_global, n_own, dv[:n_own])
@@ -370,7 +372,7 @@ class _TrainStep(torch.autograd.Function):
             # e' = relu(bn_e(xe)) + e_in ;  xe = B1h[src] + B2h[dst] + e_in W3^T
             if s["sc_e"] is None:
                 dxe = torch.empty_like(de)
-                _, g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = ops.ln_bwd(de, s["xe"], d(conv.bn_e.weight), d(conv.bn_e.bias), out=dxe)
+                _, g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = ops.ln_bwd(de, s["xe"], d(conv.bn_e.weight), d(conv.bn_e.bias), out=dxe, width=ln_width)
             else:
                 W3t = s["W3T"] if s["W3T"] is not None else d(conv.B_3.weight).t().contiguous()
                 if hasattr(ops, "bn_bwd_dgrad") and ops.can_fuse_bn_bwd_dgrad(de, W3t, s["xe"]):
@@ -467,7 +469,7 @@ def train_forward_on(model, shard, x_local, e_local):
     return _TrainStep.apply(model, shard, x_local, e_local, names, *params)
 
 
-TRAIN_SCORE_HIDDEN = (32, 64)   # hidden_edge_scores the scorer's backward is built for (gnnome_score_tail_bwd_f32; inference also takes 128)
+TRAIN_SCORE_HIDDEN = (32, 64, 128)   # hidden_edge_scores the scorer's backward is built for (gnnome_score_tail_bwd_f32; 128: round 5)
 
 
 def _pad_like(p, shape):
@@ -483,13 +485,12 @@ def _padded_step(model, shard, x_local, e_local, names, params):
     configs/hyperparameters.py:22-24; engine.BUILT_HIDDEN): run on a twin of the next built widths whose parameters are zero-padded,
     DIFFERENTIABLE functions of the model's own - exact, like the padded inference path: a padded channel carries zero weights, gamma = beta = 0
     and constant-zero activations (batch mean 0, variance 0, x_hat = 0), so its relu mask is off, every gradient that reaches it is zero, and
-    the gradients of the padded tensors arrive at the model's parameters sliced by autograd.  BatchNorm models only (LayerNorm's statistics
-    run over the row - refused at construction, layers.py)."""
+    the gradients of the padded tensors arrive at the model's parameters sliced by autograd.  LayerNorm (round 5): the twin's kernels take the
+    statistics over the model's own channels (`_gnnome_norm_width`; a padded channel gets xhat = 0, output 0 and dx = 0)."""
     from .engine import padded_width
     from .models import SymGatedGCNModel
     conv0 = model.gnn.convs[0]
-    if not isinstance(conv0.bn_e, torch.nn.BatchNorm1d):
-        raise ValueError("train mode at a width between the built ones needs normalization='batch' (zero-padding does not commute with LayerNorm)")
+    layer_norm = isinstance(conv0.bn_e, torch.nn.LayerNorm)
     H, hs = model.linear2_node.out_features, model.predictor.W1.out_features
     if hs > TRAIN_SCORE_HIDDEN[-1]:
         raise ValueError(f"train mode at hidden_edge_scores={hs}: the scorer's backward is built for widths up to {TRAIN_SCORE_HIDDEN[-1]}")
@@ -498,8 +499,10 @@ def _padded_step(model, shard, x_local, e_local, names, params):
     twin = model.__dict__.get("_gnnome_padded_twin")
     if twin is None or next(twin.parameters()).device != dev:
         twin = SymGatedGCNModel(model.linear1_node.in_features, model.linear1_edge.in_features, Hp, model.linear1_node.out_features,
-                                len(model.gnn.convs), hsp, "batch", dropout=conv0.dropout).to(dev)
+                                len(model.gnn.convs), hsp, "layer" if layer_norm else "batch", dropout=conv0.dropout).to(dev)
         model.__dict__["_gnnome_padded_twin"] = twin
+    if layer_norm and Hp != H:
+        twin.__dict__["_gnnome_norm_width"] = H
     twin.train()
     for attr in ("activation_storage", "recompute_gate", "node_order"):
         if hasattr(model, attr):

@@ -40,6 +40,10 @@ extern "C" {
 #define GNNOME_NORM_AFFINE 0  /* y = x*scale[c] + shift[c]: eval-mode BatchNorm1d folded to an affine,
                                  or train-mode BatchNorm1d once the batch statistics are known     */
 #define GNNOME_NORM_LAYER 1   /* y = (x-mean_row)/sqrt(var_row+1e-5)*scale[c] + shift[c]: LayerNorm */
+/* LayerNorm whose row statistics run over the first w channels only: a model narrower than the built width (64 / 128 / 256) runs
+ * zero-padded - its padded channels hold exact zeros and zero scale / shift - and normalises over its OWN width
+ * (configs/hyperparameters.py:22 takes any hidden_features).  Accepted wherever norm_kind is; w = hidden is GNNOME_NORM_LAYER. */
+#define GNNOME_NORM_LAYER_OVER(w) (GNNOME_NORM_LAYER | ((w) << 8))
 
 int gnnome_abi_version(void);
 const char* gnnome_last_error(void);
@@ -331,10 +335,12 @@ int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const float* scale,
  *   out = relu(LN(x) * gamma + beta) + res, LN over the `hidden` entries of each row (biased variance, eps 1e-5);
  *   backward: dx = rstd_row (g - mean_row(g) - xhat mean_row(g xhat)) with g = dy m gamma, m the relu mask;
  *   dbeta[c] = sum_r dy m, dgamma[c] = sum_r dy m xhat (deterministic; overwritten; workspace as colsum2). */
+/* norm_width (round 5): the statistics run over the first norm_width <= hidden channels (0 = hidden) - see GNNOME_NORM_LAYER_OVER;
+ * dx of a channel beyond norm_width is 0. */
 int gnnome_ln_relu_res_f32(const float* x, const float* gamma, const float* beta, const float* res, int64_t rows, int hidden,
-                           float* out, void* stream);
-int gnnome_ln_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, int64_t rows, int hidden, float* dx,
-                      float* dbeta, float* dgamma, void* workspace, size_t workspace_bytes, void* stream);
+                           int norm_width, float* out, void* stream);
+int gnnome_ln_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, int64_t rows, int hidden, int norm_width,
+                      float* dx, float* dbeta, float* dgamma, void* workspace, size_t workspace_bytes, void* stream);
 
 /* o1 = a*b, o2 = a*b*c (count floats, count % 4 == 0);  out = a + b;  dx = dy*(y > 0) */
 int gnnome_mul23_f32(const float* a, const float* b, const float* c, int64_t count, float* o1, float* o2, void* stream);

@@ -36,8 +36,9 @@ GraphViews = CpuViews
 def _norm(x, kind, scale, shift):
     if kind == NORM_AFFINE:
         return x * scale + shift
-    mu = x.mean(1, keepdim=True)
-    var = ((x - mu) ** 2).mean(1, keepdim=True)
+    w = (kind >> 8) or x.shape[1]      # GNNOME_NORM_LAYER_OVER(w): statistics over the first w channels (the rest are zero padding)
+    mu = x[:, :w].mean(1, keepdim=True)
+    var = ((x[:, :w] - mu) ** 2).mean(1, keepdim=True)
     return (x - mu) * torch.rsqrt(var + 1e-5) * scale + shift
 
 
@@ -256,25 +257,30 @@ def bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd, out=None):
     return out
 
 
-def _ln_parts(x):
-    mu = x.mean(1, keepdim=True)
-    rstd = torch.rsqrt(((x - mu) ** 2).mean(1, keepdim=True) + 1e-5)
-    return (x - mu) * rstd, rstd
+def _ln_parts(x, width=None):
+    w = width or x.shape[1]
+    mu = x[:, :w].mean(1, keepdim=True)
+    rstd = torch.rsqrt(((x[:, :w] - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+    xh = (x - mu) * rstd
+    xh[:, w:] = 0
+    return xh, rstd
 
 
-def ln_relu_res(x, gamma, beta, res, out=None):
-    y = torch.relu(_ln_parts(x)[0] * gamma + beta) + res
+def ln_relu_res(x, gamma, beta, res, out=None, width=None):
+    y = torch.relu(_ln_parts(x, width)[0] * gamma + beta) + res
     if out is None:
         return y
     out.copy_(y)
     return out
 
 
-def ln_bwd(dy, x, gamma, beta, out=None):
-    xh, rstd = _ln_parts(x)
+def ln_bwd(dy, x, gamma, beta, out=None, width=None):
+    w = width or x.shape[1]
+    xh, rstd = _ln_parts(x, width)
     dm = dy * (xh * gamma + beta > 0)
     g = dm * gamma
-    dx = rstd * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    dx = rstd * (g - g.sum(1, keepdim=True) / w - xh * (g * xh).sum(1, keepdim=True) / w)
+    dx[:, w:] = 0
     if out is not None:
         out.copy_(dx)
         dx = out

@@ -577,6 +577,20 @@ def test_goldens_wider_hidden_and_layernorm():
     assert _prob_diff(out, g["logits"]) < PROB_TOL
 
 
+def test_layernorm_at_widths_between_the_built_ones_golden_g12():
+    """normalization='layer' at (96, 48) and (160, 128): the gate / aggregation kernels' LayerNorm over the model's own channels
+    (GNNOME_NORM_LAYER_OVER) against the reference's logits."""
+    g = load_golden("g12_layernorm_widths.pt")
+    for case in g["cases"]:
+        sd = {k: v for k, v in random_state_dict(case["hidden"], num_layers=case["layers"], hidden_edge_scores=case["hs"], seed=case["seed"]).items()
+              if "running_" not in k and "num_batches" not in k}
+        m = gnnome_amd.SymGatedGCNModel(2, 2, case["hidden"], 16, case["layers"], case["hs"], "layer").eval()
+        m.load_state_dict(sd)
+        m.to(dev())
+        out = m((g["src"], g["dst"], g["num_nodes"]), g["x"].to(dev()), g["e"].to(dev()))
+        assert _prob_diff(out, case["eval_logits"]) < 2e-6 * 50    # (reference-exact up to fp32 reordering)
+
+
 def test_widths_between_the_built_ones():
     """hidden_features / hidden_edge_scores the kernels are not built for (the reference takes any, configs/hyperparameters.py:22-24) run on the
     next built width with zero-padded parameters (engine.BUILT_HIDDEN): the reference's own logits (golden G11), the oracle at 20k / 200k, the

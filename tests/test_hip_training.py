@@ -802,6 +802,22 @@ def test_layernorm_kernels(rows, H):
     assert all(torch.equal(p, q) for p, q in zip((dx, dgamma, dbeta), again))   # deterministic column sums
 
 
+def test_layernorm_training_step_at_widths_between_the_built_ones_golden_g12():
+    g = load_golden("g12_layernorm_widths.pt")
+    for case in g["cases"]:
+        sd = {k: v for k, v in random_state_dict(case["hidden"], num_layers=case["layers"], hidden_edge_scores=case["hs"], seed=case["seed"]).items()
+              if "running_" not in k and "num_batches" not in k}
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, case["hidden"], 16, case["layers"], case["hs"], "layer", dropout=0.0)
+        m.load_state_dict(sd)
+        m.to(dev()).train()
+        logits = m((g["src"], g["dst"], g["num_nodes"]), g["x"].to(dev()), g["e"].to(dev()))
+        loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), g["y"].to(dev()), pos_weight=g["pos_weight"].to(dev()))
+        loss.backward()
+        assert (torch.sigmoid(logits.detach().cpu()) - torch.sigmoid(case["logits"])).abs().max().item() < 1e-4
+        assert abs(loss.item() - case["loss"].item()) < 1e-5
+        _check_grads({k: p.grad for k, p in m.named_parameters()}, case["grads"], rtol=1e-3)
+
+
 def test_layernorm_training_step_matches_reference_golden_g8():
     g = load_golden("g8_layernorm_train_h64.pt")
     sd = {k: v for k, v in random_state_dict(64, seed=g["seed"]).items() if "running_" not in k and "num_batches" not in k}

@@ -118,7 +118,7 @@ def test_host_sequence_layernorm_and_reversed_graph():
 def test_widths_between_the_built_ones_run_zero_padded():
     """hidden_features / hidden_edge_scores outside {64,128,256} / {32,64,128} (the reference takes any): eval-mode BatchNorm models
     run on the next built width with zero-padded parameters - against the reference's own logits (golden G11) - and the cases
-    padding cannot serve are refused: LayerNorm (row statistics), widths above the largest built one.  (Train mode: tests/test_train_host.py.)"""
+    padding cannot serve are refused: widths above the largest built one (LayerNorm: golden G12 below).  (Train mode: tests/test_train_host.py.)"""
     g = load_golden("g11_widths.pt")
     for case in g["cases"]:
         sd = random_state_dict(case["hidden"], num_layers=case["layers"], hidden_edge_scores=case["hs"], seed=case["seed"])
@@ -135,8 +135,21 @@ def test_widths_between_the_built_ones_run_zero_padded():
         gnnome_amd.models.SymGatedGCNModel(2, 2, 257, 16, 1, 64, "batch")
     with pytest.raises(ValueError, match="up to 128"):
         gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 1, 129, "batch")
-    with pytest.raises(ValueError, match="LayerNorm"):
-        gnnome_amd.models.SymGatedGCNModel(2, 2, 96, 16, 1, 64, "layer")
+
+
+def test_layernorm_at_widths_between_the_built_ones_golden_g12():
+    """Round 5: normalization='layer' no longer needs a built width - the padded kernels take the row statistics over the model's own
+    channels (GNNOME_NORM_LAYER_OVER).  Eval logits of the host sequence on the checker backend against the reference's (golden G12)."""
+    g = load_golden("g12_layernorm_widths.pt")
+    for case in g["cases"]:
+        sd = {k: v for k, v in random_state_dict(case["hidden"], num_layers=case["layers"], hidden_edge_scores=case["hs"], seed=case["seed"]).items()
+              if "running_" not in k and "num_batches" not in k}
+        got = _host_forward(sd, g, normalization="layer", layers=case["layers"])
+        _close(got, case["eval_logits"], tol=2e-6)
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, case["hidden"], 16, case["layers"], case["hs"], "layer").eval()
+        m.load_state_dict(sd)
+        lw = engine.Prepared(m, CPU).layers[0]
+        assert lw.norm == (1 | (case["hidden"] << 8)) and lw.scale_e.numel() == engine.padded_width(case["hidden"])
 
 
 def test_views_definition():

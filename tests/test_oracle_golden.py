@@ -121,6 +121,28 @@ def test_g6_layernorm():
     _check(out, g["logits"])
 
 
+def test_g12_layernorm_at_widths_between_the_built_ones():
+    """The reference at (hidden_features, hidden_edge_scores) = (96, 48) and (160, 128) with normalization='layer': eval logits and a
+    train-mode step (loss + every gradient)."""
+    import torch.nn.functional as F
+    g = load_golden("g12_layernorm_widths.pt")
+    for case in g["cases"]:
+        sd = {k: v for k, v in random_state_dict(case["hidden"], num_layers=case["layers"], hidden_edge_scores=case["hs"], seed=case["seed"]).items()
+              if "running_" not in k and "num_batches" not in k}
+        m = OracleModel(2, 2, case["hidden"], 16, case["layers"], case["hs"], "layer", dropout=0.0)
+        m.load_state_dict(sd)
+        m.eval()
+        with torch.no_grad():
+            _check(m((g["src"], g["dst"], g["num_nodes"]), g["x"], g["e"]), case["eval_logits"])
+        m.train()
+        out = m((g["src"], g["dst"], g["num_nodes"]), g["x"], g["e"])
+        loss = F.binary_cross_entropy_with_logits(out.squeeze(-1), g["y"], pos_weight=g["pos_weight"])
+        loss.backward()
+        assert abs(loss.item() - case["loss"].item()) < 1e-6
+        for k, p_ in m.named_parameters():
+            assert torch.allclose(p_.grad, case["grads"][k], atol=1e-6, rtol=1e-4), k
+
+
 def test_known_answers_without_any_reference(shipped_weights):
     """edge-order equivariance, E=0, isolated nodes."""
     g = load_golden("g2_uniform_1k.pt")

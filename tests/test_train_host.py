@@ -52,6 +52,28 @@ def test_layernorm_training_step_on_checker_backend_matches_reference_golden_g8(
     check_grads({k: p.grad for k, p in m.named_parameters()}, g["grads"], rtol=1e-3)
 
 
+def test_layernorm_training_step_at_widths_between_the_built_ones_golden_g12():
+    """(96, 48) and (160, 128) with normalization='layer' in train mode: the zero-padded twin (train._padded_step) with LayerNorm over the
+    model's own channels, and hidden_edge_scores = 128 through the scorer's backward - loss and every gradient, in the model's own shapes,
+    against the reference's autograd."""
+    g = load_golden("g12_layernorm_widths.pt")
+    for case in g["cases"]:
+        sd = {k: v for k, v in random_state_dict(case["hidden"], num_layers=case["layers"], hidden_edge_scores=case["hs"], seed=case["seed"]).items()
+              if "running_" not in k and "num_batches" not in k}
+        m = gnnome_amd.models.SymGatedGCNModel(2, 2, case["hidden"], 16, case["layers"], case["hs"], "layer", dropout=0.0)
+        m.load_state_dict(sd)
+        m.train()
+        views = cpu_ops.CpuViews(g["src"], g["dst"], g["num_nodes"])
+        logits = train_forward_on(m, WholeGraph(views, cpu_ops), g["x"], g["e"])
+        loss = F.binary_cross_entropy_with_logits(logits.squeeze(-1), g["y"], pos_weight=g["pos_weight"])
+        loss.backward()
+        assert (torch.sigmoid(logits.detach()) - torch.sigmoid(case["logits"])).abs().max().item() < 1e-4
+        assert abs(loss.item() - case["loss"].item()) < 1e-5
+        grads = {k: p.grad for k, p in m.named_parameters()}
+        assert all(grads[k].shape == w.shape for k, w in case["grads"].items())
+        check_grads(grads, case["grads"], rtol=1e-3)
+
+
 def _fixed_masks(n, H, layers, p, seed):
     g = torch.Generator().manual_seed(seed)
     return [(torch.rand(n, H, generator=g) >= p).float() / (1.0 - p) for _ in range(layers)]
@@ -201,9 +223,4 @@ def test_training_step_at_widths_between_the_built_ones_matches_oracle_autograd(
             opt_o.step()
             opt_m.step()
         assert list(m.state_dict().keys()) == list(sd.keys()) and all(m.state_dict()[k].shape == v.shape for k, v in sd.items())
-    m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 1, 64, "batch").train()
-    m.gnn.convs[0].bn_e = torch.nn.LayerNorm(64)      # (a model patched after construction: the padded step only serves BatchNorm)
-    m.linear2_node = torch.nn.Linear(16, 72)
-    import pytest
-    with pytest.raises(ValueError, match="normalization='batch'"):
-        train_forward_on(m, WholeGraph(views, cpu_ops), x, gr["e"])
+    # (LayerNorm models at such widths: test_layernorm_training_step_at_widths_between_the_built_ones_golden_g12)
