@@ -142,12 +142,17 @@ def sample_edges(prob_edges, nb_paths):
 
 
 def sample_edges_device(prob_edges, nb_paths):
-    """The same distribution drawn on the device with ONE multinomial (with replacement) - no nb_paths-fold copy of the
-    probabilities, no trip through the host; a different random stream than the reference's."""
+    """The same distribution drawn on the device (with replacement) - no nb_paths-fold copy of the probabilities, no trip through the
+    host; a different random stream than the reference's.  Inverse-CDF in float64: torch.multinomial builds its CDF with a float32
+    device cumsum whose last bits are not reproducible from run to run, and with 10^6 edges x 100 draws x hundreds of iterations a draw
+    now and then landed on the other side of a boundary (round 5: tests/test_decode.py's same-seed-same-walks check failed once in five
+    runs).  In float64 the scan's reordering noise is 1e-16 of the total: two runs from one seed draw the same edges."""
     if prob_edges.shape[0] > 2 ** 24:
         prob_edges = prob_edges[:2 ** 24]
-    prob_edges = prob_edges.masked_fill(prob_edges < 1e-9, 1e-9)
-    return torch.multinomial(prob_edges / prob_edges.sum(), nb_paths, replacement=True)
+    p = prob_edges.double().clamp_min(1e-9)
+    cdf = torch.cumsum(p, 0)
+    u = torch.rand(nb_paths, dtype=torch.float64, device=p.device) * cdf[-1]
+    return torch.searchsorted(cdf, u, right=True).clamp_(max=p.shape[0] - 1)
 
 
 REFERENCE_SAMPLER_LIMIT = 2 ** 22   # remaining edges x nb_paths up to which the default sampler is the reference's own
