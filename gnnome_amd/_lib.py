@@ -87,6 +87,8 @@ SIGNATURES = {
     "gnnome_overlap_edit_distance": [_p, _p, _l, _p, _i, _p, _p, _p, _l, _p, _p, _p, _sz, _p],
     "gnnome_adjacency_support": [_p, _p, _p, _l, _l, _p, _p],
     "gnnome_bfs_levels": [_p, _p, _l, _p, _p, _p, _p, _p, _p, _p],
+    "gnnome_hem_propose": [_p, _p, _p, _p, _p, _l, _i, _p, _p],
+    "gnnome_kway_gains": [_p, _p, _p, _p, _l, _p, _p, _p],
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 

@@ -582,6 +582,21 @@ int gnnome_segment_sum2_x16(const uint16_t* X, int width, const int32_t* in_ptr,
 int gnnome_wgrad_x16(const uint16_t* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, float* C, int ldc,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- clusters for mini-batch training (round 5) ----------------------------------------------
+ * train.py:333-346 calls dgl.metis_partition(g.long(), num_clusters, extra_cached_hops=1): METIS 5.1.0's multilevel k-way partitioner
+ * behind DGL 0.8.1 (requirements.txt:23; neither is in the reference checkout).  gnnome_amd/partition.py runs the published scheme
+ * (Karypis & Kumar 1998: heavy-edge matching, a greedy-growing initial partition of the coarsest graph, greedy k-way boundary refinement
+ * while uncoarsening) on the device; these are its two inner loops over an undirected weighted CSR (ptr int32[n+1], adj / wgt int32[nnz],
+ * both directions stored, no self loops needed), deterministic and atomic-free:
+ *   gnnome_hem_propose: proposal[v] = the heaviest unmatched neighbour u of an unmatched v (match[.] < 0) with vwgt[v] + vwgt[u] <=
+ *     max_vwgt, ties to the lighter vertex, then the smaller id; -1 if none.  The caller pairs mutual proposals (handshake).
+ *   gnnome_kway_gains: best_part[v] = the part, other than label[v], that v's neighbours connect it to most heavily (ties: smaller id;
+ *     -1 for an interior vertex) and gain[v] = that connectivity - the connectivity to its own part. */
+int gnnome_hem_propose(const int32_t* ptr, const int32_t* adj, const int32_t* wgt, const int32_t* vwgt, const int32_t* match,
+                       int64_t num_vertices, int max_vwgt, int32_t* proposal, void* stream);
+int gnnome_kway_gains(const int32_t* ptr, const int32_t* adj, const int32_t* wgt, const int32_t* label, int64_t num_vertices,
+                      int32_t* best_part, int32_t* gain, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,193 @@
+"""ORACLE - test infrastructure only (imported by tests/; never by gnnome_amd/).
+
+The clustering behind train.py:333-346, `dgl.metis_partition(g.long(), num_clusters, extra_cached_hops=1)`, lives in two third-party
+dependencies that are absent from /root/reference: DGL 0.8.1 (requirements.txt:23), which hands the node assignment to METIS 5.1.0
+(`METIS_PartGraphKway`, bundled with DGL) and then builds one subgraph per part with `partition_graph_with_halo`.  Neither can be run
+here, and METIS is a randomised heuristic (its result is no function of the graph alone), so what is pinned is
+  (1) the published scheme, restated sequentially in plain Python below - Karypis & Kumar, "A Fast and High Quality Multilevel Scheme for
+      Partitioning Irregular Graphs", SIAM J. Sci. Comput. 20(1) 1998 (coarsening by heavy-edge matching, section 3; greedy graph growing
+      of the coarsest graph, section 4) and "Multilevel k-way Partitioning Scheme for Irregular Graphs", JPDC 48(1) 1998 (greedy k-way
+      refinement while uncoarsening, section 4; balance 1.03 = METIS's default ufactor 30) - as the QUALITY reference: the device
+      implementation must cut no more than a stated factor of what this restatement cuts, under the same balance constraint;
+  (2) DGL's halo rule, restated from `GetSubgraphWithHalo` (dgl/src/graph/graph_op.cc of 0.8.x): a part's subgraph holds its own nodes
+      first, then, hop by hop, the SOURCES of the in-edges of the nodes collected so far; its edges are those in-edges (hop 1: every edge
+      whose destination is an inner node); ndata['inner_node'] marks the part's own nodes, ndata/edata['_ID'] the original ids.
+parity unpinned against METIS / DGL themselves: no golden vector of either exists in the reference.
+"""
+import heapq
+import random
+
+
+def adjacency(src, dst, n):
+    """Undirected weighted adjacency: parallel and antiparallel edges merge (weight = multiplicity), self loops drop."""
+    nbr = [dict() for _ in range(n)]
+    for u, v in zip(src, dst):
+        u, v = int(u), int(v)
+        if u == v:
+            continue
+        nbr[u][v] = nbr[u].get(v, 0) + 1
+        nbr[v][u] = nbr[v].get(u, 0) + 1
+    return nbr
+
+
+def heavy_edge_matching(nbr, vwgt, max_vwgt, rng):
+    n = len(nbr)
+    match = [-1] * n
+    order = list(range(n))
+    rng.shuffle(order)
+    for v in order:
+        if match[v] >= 0:
+            continue
+        best, best_w = -1, -1
+        for u, w in nbr[v].items():
+            if match[u] < 0 and vwgt[v] + vwgt[u] <= max_vwgt and w > best_w:
+                best, best_w = u, w
+        if best >= 0:
+            match[v], match[best] = best, v
+        else:
+            match[v] = v
+    return match
+
+
+def contract(nbr, vwgt, match):
+    n = len(nbr)
+    cmap, nc = [-1] * n, 0
+    for v in range(n):
+        if cmap[v] < 0:
+            cmap[v] = nc
+            cmap[match[v]] = nc
+            nc += 1
+    cn = [dict() for _ in range(nc)]
+    cw = [0] * nc
+    for v in range(n):
+        cv = cmap[v]
+        cw[cv] += vwgt[v]
+        for u, w in nbr[v].items():
+            cu = cmap[u]
+            if cu != cv:
+                cn[cv][cu] = cn[cv].get(cu, 0) + w
+    return cn, cw, cmap
+
+
+def greedy_growing(nbr, vwgt, k, rng):
+    """k - 1 regions grown one after the other from a random free seed, always taking the free vertex most heavily connected to the
+    region, until the region holds its share of the weight; the rest is the last part."""
+    n, total = len(nbr), sum(vwgt)
+    label = [-1] * n
+    free = set(range(n))
+    for p in range(k - 1):
+        if not free:
+            break
+        target = (total - sum(vwgt[v] for v in range(n) if label[v] >= 0)) / (k - p)
+        seed = rng.choice(sorted(free))
+        heap, conn, size = [(0, seed)], {seed: 0}, 0
+        while size < target and free:
+            while heap and (heap[0][1] not in free or -heap[0][0] != conn.get(heap[0][1], None)):
+                heapq.heappop(heap)
+            if not heap:      # the region's component is exhausted: continue from another free vertex
+                v = min(free)
+                conn[v] = 0
+            else:
+                v = heapq.heappop(heap)[1]
+            free.discard(v)
+            label[v] = p
+            size += vwgt[v]
+            for u, w in nbr[v].items():
+                if u in free:
+                    conn[u] = conn.get(u, 0) + w
+                    heapq.heappush(heap, (-conn[u], u))
+    for v in free:
+        label[v] = k - 1
+    return label
+
+
+def refine(nbr, vwgt, label, k, max_pw, rng, passes=10):
+    pw = [0] * k
+    for v, p in enumerate(label):
+        pw[p] += vwgt[v]
+    n = len(nbr)
+    for _ in range(passes):
+        moved = 0
+        order = list(range(n))
+        rng.shuffle(order)
+        for v in order:
+            own = label[v]
+            conn = {}
+            for u, w in nbr[v].items():
+                conn[label[u]] = conn.get(label[u], 0) + w
+            internal = conn.get(own, 0)
+            best, best_gain = -1, 0
+            for p, c in conn.items():
+                if p == own or pw[p] + vwgt[v] > max_pw:
+                    continue
+                g = c - internal
+                if g > best_gain or (g == best_gain and g >= 0 and best >= 0 and pw[p] < pw[best]) or \
+                        (g == 0 and best < 0 and pw[p] + vwgt[v] < pw[own]):
+                    best, best_gain = p, g
+            if best >= 0 and (best_gain > 0 or pw[best] + vwgt[v] < pw[own]):
+                label[v] = best
+                pw[own] -= vwgt[v]
+                pw[best] += vwgt[v]
+                moved += 1
+        if moved == 0:
+            break
+    return label
+
+
+def partition(src, dst, n, k, ufactor=1.03, seed=0, trials=8):
+    """label[n] in [0, k): the multilevel k-way scheme."""
+    rng = random.Random(seed)
+    nbr, vwgt = adjacency(src, dst, n), [1] * n
+    levels = []
+    coarsen_to = max(30 * k, 200)
+    while len(nbr) > coarsen_to:
+        max_vwgt = max(1, int(1.5 * sum(vwgt) / coarsen_to))
+        match = heavy_edge_matching(nbr, vwgt, max_vwgt, rng)
+        cn, cw, cmap = contract(nbr, vwgt, match)
+        if len(cn) > 0.95 * len(nbr):     # the matching no longer shrinks the graph
+            break
+        levels.append((nbr, vwgt, cmap))
+        nbr, vwgt = cn, cw
+    max_pw = int(ufactor * n / k) + 1
+    # METIS computes several initial partitions of the coarsest graph and keeps the best (its `niparts`)
+    best, best_cut = None, None
+    for _ in range(trials):
+        cand = refine(nbr, vwgt, greedy_growing(nbr, vwgt, k, rng), k, max_pw, rng)
+        cut = sum(w for v in range(len(nbr)) for u, w in nbr[v].items() if cand[u] != cand[v])
+        if best is None or cut < best_cut:
+            best, best_cut = cand, cut
+    label = best
+    for fine_nbr, fine_vwgt, cmap in reversed(levels):
+        label = [label[c] for c in cmap]
+        label = refine(fine_nbr, fine_vwgt, label, k, max_pw, rng)
+    return label
+
+
+def edge_cut(src, dst, label):
+    return sum(1 for u, v in zip(src, dst) if label[int(u)] != label[int(v)])
+
+
+def halo_subgraph(src, dst, n, inner_nodes, hops):
+    """DGL's GetSubgraphWithHalo, restated: -> (node ids: inner first, then halo in discovery order; edge ids in discovery order;
+    inner_node flags).  Discovery walks the in-edges of the current frontier in (frontier order, edge id) order."""
+    in_edges = [[] for _ in range(n)]
+    for eid, (u, v) in enumerate(zip(src, dst)):
+        in_edges[int(v)].append((eid, int(u)))
+    nodes = [int(v) for v in inner_nodes]
+    seen = set(nodes)
+    edges, frontier = [], list(nodes)
+    for _ in range(max(int(hops), 1)):
+        nxt = []
+        for v in frontier:
+            for eid, u in in_edges[v]:
+                if int(hops) == 0 and u not in seen:
+                    continue
+                edges.append(eid)
+                if u not in seen:
+                    seen.add(u)
+                    nodes.append(u)
+                    nxt.append(u)
+        frontier = nxt
+        if int(hops) == 0:
+            break
+    return nodes, edges, [i < len(inner_nodes) for i in range(len(nodes))]

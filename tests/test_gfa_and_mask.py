@@ -136,7 +136,7 @@ def test_cluster_partition_with_halo():
     from gnnome_amd.synth import make_graph, random_state_dict
     n, e, k = 20_000, 200_000, 10
     gr = make_graph(n, e, seed=6)
-    parts = partition.cluster_partition((gr["src"], gr["dst"], n), k, extra_cached_hops=1, device=dev())
+    parts = partition.cluster_partition((gr["src"], gr["dst"], n), k, extra_cached_hops=1, device=dev(), method="region", halo="both")   # (the rounds 2-4 form; the default: tests/test_partition.py)
     assert len(parts) == k
     owner = torch.full((n,), -1, dtype=torch.long)
     src, dst = gr["src"].long(), gr["dst"].long()
@@ -156,7 +156,7 @@ def test_cluster_partition_with_halo():
         assert torch.equal(keep, want)
         assert torch.equal(sub.eid.cpu(), torch.nonzero(keep[src] & keep[dst]).squeeze(1))
     assert (owner >= 0).all()
-    again = partition.cluster_partition((gr["src"], gr["dst"], n), k, device=dev())
+    again = partition.cluster_partition((gr["src"], gr["dst"], n), k, device=dev(), method="region", halo="both")
     assert all(torch.equal(again[p].nid, parts[p].nid) for p in parts)                   # deterministic
     # one training step on a cluster (get_bce_loss_partition, train.py:148-156)
     from gnnome_amd.loss import bce_loss

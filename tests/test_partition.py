@@ -1,0 +1,132 @@
+"""Clusters for mini-batch training (train.py:333-346): the multilevel k-way partition on the device against the
+sequential restatement of the published scheme (oracle/metis_oracle.py) - cut quality and balance, not bits: METIS is a randomised
+heuristic - and DGL's halo rule against a hand-derived fixture."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gnnome_amd.synth import make_graph
+from oracle import metis_oracle as mo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _fixture():
+    with open(os.path.join(HERE, "golden", "g13_partition_halo.json")) as f:
+        return json.load(f)
+
+
+def _sorted_within_hops(nodes, edges, n_inner):
+    return nodes, sorted(edges)     # (the fixture lists a case's edges hop by hop; one hop: ascending)
+
+
+def test_oracle_halo_rule_against_the_hand_derived_fixture():
+    fx = _fixture()
+    for case in fx["cases"]:
+        inner = [v for v, p in enumerate(fx["part"]) if p == case["part"]]
+        nodes, edges, flags = mo.halo_subgraph(fx["src"], fx["dst"], fx["num_nodes"], inner, case["hops"])
+        assert set(nodes) == set(case["nid"]) and nodes[:len(inner)] == inner
+        assert sorted(edges) == sorted(case["eid"])
+        assert [int(f) for f in flags] == sorted(case["inner"], reverse=True)
+
+
+def _grid(w):
+    idx = np.arange(w * w).reshape(w, w)
+    a = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel()])
+    b = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel()])
+    return np.concatenate([a, b]), np.concatenate([b, a]), w * w
+
+
+def test_oracle_scheme_is_a_sane_quality_reference():
+    """The sequential restatement on graphs with known good cuts: a 40 x 40 grid into 4 (optimal: 80 undirected = 160 directed edges) and a
+    layout-ordered assembly graph into 8 (contiguous ranges are near-optimal there)."""
+    src, dst, n = _grid(40)
+    lab = mo.partition(src.tolist(), dst.tolist(), n, 4, seed=1)
+    sizes = np.bincount(lab, minlength=4)
+    assert sizes.max() <= 1.03 * n / 4 + 1 and mo.edge_cut(src, dst, lab) <= 1.7 * 160
+    g = make_graph(4000, 40000, 3, "banded")
+    s, d = g["src"].tolist(), g["dst"].tolist()
+    lab = mo.partition(s, d, 4000, 8, seed=1)
+    ranges = [min(v * 8 // 4000, 7) for v in range(4000)]
+    assert mo.edge_cut(s, d, lab) <= 1.6 * mo.edge_cut(s, d, ranges)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,e,k", [("grid", 0, 0, 4), ("grid", 0, 0, 16), ("banded", 8000, 80000, 8), ("permuted", 8000, 80000, 8),
+                                        ("banded", 20000, 200000, 20)])
+def test_multilevel_partition_against_the_oracle_scheme(kind, n, e, k):
+    """Balance within METIS's default tolerance, every part used, deterministic, and an edge cut no worse than 1.15 x the sequential
+    scheme's (best of three seeds is not taken: its median) - and far below region growing's where the ids carry no locality."""
+    from gnnome_amd import partition
+    dev = torch.device("cuda", 0)
+    if kind == "grid":
+        src, dst, n = _grid(64)
+    else:
+        g = make_graph(n, e, 3, kind)
+        src, dst = g["src"].numpy(), g["dst"].numpy()
+    ts, td = torch.as_tensor(src, dtype=torch.int32, device=dev), torch.as_tensor(dst, dtype=torch.int32, device=dev)
+    label = partition.multilevel_partition(ts, td, n, k)
+    again = partition.multilevel_partition(ts, td, n, k)
+    assert torch.equal(label, again)
+    sizes = torch.bincount(label, minlength=k)
+    assert int(sizes.min()) > 0 and int(sizes.max()) <= int(1.03 * n / k) + 1
+    cut = partition.edge_cut(ts, td, label)
+    ref = sorted(mo.edge_cut(src, dst, mo.partition(src.tolist(), dst.tolist(), n, k, seed=s)) for s in (1, 2, 3))[1]
+    region = partition.edge_cut(ts, td, partition.grow_regions(ts, td, n, k))
+    print(f"{kind} n={n} k={k}: cut {cut}, sequential scheme (median of 3 seeds) {ref}, region growing {region}")
+    assert cut <= 1.15 * ref + 8, (cut, ref)
+    if kind == "permuted":
+        assert cut < 0.6 * region
+    if kind == "banded":
+        ranges = torch.clamp(torch.arange(n, device=dev) * k // n, max=k - 1)
+        assert cut <= 1.6 * partition.edge_cut(ts, td, ranges)
+
+
+@pytest.mark.gpu
+def test_cluster_partition_follows_dgls_halo_rule_and_trains():
+    import gnnome_amd
+    from gnnome_amd import features, partition
+    from gnnome_amd.loss import bce_loss
+    from gnnome_amd.synth import random_state_dict
+    dev = torch.device("cuda", 0)
+    fx = _fixture()
+    src, dst = torch.tensor(fx["src"], dtype=torch.int32, device=dev), torch.tensor(fx["dst"], dtype=torch.int32, device=dev)
+    part = torch.tensor(fx["part"], device=dev)
+    for case in fx["cases"]:
+        nid, eid = partition._dgl_halo(src, dst, fx["num_nodes"], part == case["part"], case["hops"])
+        assert nid.tolist() == case["nid"] and eid.tolist() == case["eid"], (case, nid.tolist(), eid.tolist())
+    # the whole call on an assembly-shaped graph: every node inner in exactly one part, a part's edges = the in-edges of its inner nodes
+    n, e, k = 20_000, 200_000, 10
+    gr = make_graph(n, e, seed=6)
+    parts = partition.cluster_partition((gr["src"], gr["dst"], n), k, extra_cached_hops=1, device=dev)
+    assert len(parts) == k
+    s_l, d_l = gr["src"].long(), gr["dst"].long()
+    owner = torch.full((n,), -1, dtype=torch.long)
+    total_edges = 0
+    for p, sub in parts.items():
+        nid, inner, eid = sub.nid.cpu(), sub.inner_node.cpu(), sub.eid.cpu()
+        assert (owner[nid[inner]] == -1).all()
+        owner[nid[inner]] = p
+        assert int(inner.sum()) <= int(1.03 * n / k) + 1 and bool(inner[:int(inner.sum())].all())     # inner nodes first
+        mask = torch.zeros(n, dtype=torch.bool)
+        mask[nid[inner]] = True
+        assert torch.equal(eid, torch.nonzero(mask[d_l]).squeeze(1))                                    # exactly the in-edges of the inner nodes
+        assert set(nid[~inner].tolist()) == set(s_l[eid].tolist()) - set(nid[inner].tolist())           # halo = their outside sources
+        ss, dd = sub.edges()
+        assert torch.equal(nid[ss.cpu().long()], s_l[eid]) and torch.equal(nid[dd.cpu().long()], d_l[eid])
+        total_edges += int(eid.numel())
+    assert (owner >= 0).all() and total_edges == e          # with one hop every edge of the graph belongs to exactly one part
+    # one training step on a cluster (get_bce_loss_partition, train.py:148-156)
+    m = gnnome_amd.SymGatedGCNModel(2, 2, 64, 16, 2, 64, "batch").train()
+    m.load_state_dict(random_state_dict(64, num_layers=2, seed=1))
+    m.to(dev)
+    sub = parts[3]
+    in_deg, out_deg = features.stored_degrees(gnnome_amd.graph.views_for((gr["src"], gr["dst"], n), dev))
+    x = features.partition_degree_features(in_deg, out_deg, sub.nid)
+    logits = m(sub, x, gr["e"].to(dev)[sub.eid])
+    loss = bce_loss(logits.squeeze(-1), gr["y"].to(dev)[sub.eid], gr["pos_weight"].to(dev))
+    loss.backward()
+    assert torch.isfinite(loss) and all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in m.parameters())
