@@ -101,17 +101,38 @@ def undirected_csr(src, dst, num_nodes):
     return ptr.int(), col.int().contiguous(), counts.int().contiguous()
 
 
-def _hem_level(ptr, adj, wgt, vwgt, max_vwgt, rounds=8):
-    """Heavy-edge matching by proposals and handshakes -> cmap int64[n] (coarse id of every vertex), nc."""
-    lib = _lib.load()
-    n, dev = ptr.numel() - 1, ptr.device
-    match = torch.full((n,), -1, dtype=torch.int32, device=dev)
-    prop = torch.empty(n, dtype=torch.int32, device=dev)
-    ids = torch.arange(n, device=dev, dtype=torch.int32)
-    for _ in range(rounds):
+class _HipKernels:
+    """The two inner loops on the MI355X (csrc/partition.hip); tests inject a torch restatement of the same contracts (tests/cpu_ops.py) to run the
+    host logic on the CPU, as engine.py / dist.py do with their `ops`."""
+
+    @staticmethod
+    def hem_propose(ptr, adj, wgt, vwgt, match, max_vwgt):
+        lib = _lib.load()
+        n, dev = ptr.numel() - 1, ptr.device
+        prop = torch.empty(n, dtype=torch.int32, device=dev)
         with _on(dev):
             _lib.check(lib.gnnome_hem_propose(_ptr(ptr), _ptr(adj), _ptr(wgt), _ptr(vwgt), _ptr(match), n, int(max_vwgt), _ptr(prop), _stream(dev)),
                        "hem_propose")
+        return prop
+
+    @staticmethod
+    def kway_gains(ptr, adj, wgt, label):
+        lib = _lib.load()
+        n, dev = label.numel(), label.device
+        best_part = torch.empty(n, dtype=torch.int32, device=dev)
+        gain = torch.empty(n, dtype=torch.int32, device=dev)
+        with _on(dev):
+            _lib.check(lib.gnnome_kway_gains(_ptr(ptr), _ptr(adj), _ptr(wgt), _ptr(label), n, _ptr(best_part), _ptr(gain), _stream(dev)), "kway_gains")
+        return best_part, gain
+
+
+def _hem_level(ptr, adj, wgt, vwgt, max_vwgt, rounds=8, kernels=_HipKernels):
+    """Heavy-edge matching by proposals and handshakes -> cmap int64[n] (coarse id of every vertex), nc."""
+    n, dev = ptr.numel() - 1, ptr.device
+    match = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    ids = torch.arange(n, device=dev, dtype=torch.int32)
+    for _ in range(rounds):
+        prop = kernels.hem_propose(ptr, adj, wgt, vwgt, match, max_vwgt)
         has = prop >= 0
         if not bool(has.any()):
             break
@@ -139,8 +160,9 @@ def _contract(ptr, adj, wgt, vwgt, cmap, nc):
 
 def _greedy_growing(ptr, adj, wgt, vwgt, k):
     """The coarsest graph (a few thousand vertices) on the host, as METIS does it: k - 1 regions grown one after the other from the free
-    vertex with the smallest id, always taking the free vertex most heavily connected to the region (ties: smaller id), until the region
-    holds its share of the weight; the rest is the last part."""
+    vertex with the smallest id, always taking the free vertex most heavily connected to the region (ties: the one that became a neighbour of
+    the region first - breadth-first, compact regions; by smaller id a grid is cut into strips), until the region holds its share of the
+    weight; the rest is the last part."""
     import heapq
     ptr, adj, wgt, vwgt = (t.cpu().tolist() for t in (ptr, adj, wgt, vwgt))
     n = len(vwgt)
@@ -148,12 +170,13 @@ def _greedy_growing(ptr, adj, wgt, vwgt, k):
     next_free = 0
     for p in range(k - 1):
         target = (total - assigned_w) / (k - p)
-        heap, conn, size = [], {}, 0
+        heap, conn, size, tick = [], {}, 0, 0
+        first_seen = {}
         while size < target:
-            while heap and (label[heap[0][1]] >= 0 or -heap[0][0] != conn[heap[0][1]]):
+            while heap and (label[heap[0][2]] >= 0 or -heap[0][0] != conn[heap[0][2]]):
                 heapq.heappop(heap)
             if heap:
-                v = heapq.heappop(heap)[1]
+                v = heapq.heappop(heap)[2]
             else:
                 while next_free < n and label[next_free] >= 0:
                     next_free += 1
@@ -166,7 +189,10 @@ def _greedy_growing(ptr, adj, wgt, vwgt, k):
                 u = adj[q]
                 if label[u] < 0:
                     conn[u] = conn.get(u, 0) + wgt[q]
-                    heapq.heappush(heap, (-conn[u], u))
+                    if u not in first_seen:
+                        first_seen[u] = tick
+                        tick += 1
+                    heapq.heappush(heap, (-conn[u], first_seen[u], u))
         assigned_w += size
     return torch.tensor([k - 1 if x < 0 else x for x in label], dtype=torch.int32)
 
@@ -177,20 +203,16 @@ def _cut_weight(ptr, adj, wgt, label):
     return int(wgt[label[row] != label[adj.long()]].long().sum()) // 2
 
 
-def _refine(ptr, adj, wgt, vwgt, label, k, max_pw, passes=12):
+def _refine(ptr, adj, wgt, vwgt, label, k, max_pw, passes=12, kernels=_HipKernels):
     """Greedy k-way boundary refinement (Karypis & Kumar, JPDC 1998, section 4) as parallel passes: gains from the kernel, then per target part the
     candidates in order of decreasing gain as far as the part's weight allows; a pass moves vertices only towards higher (odd passes) or
     lower (even passes) part ids, so two neighbours never swap; the labelling with the smallest cut seen is what is returned."""
-    lib = _lib.load()
     n, dev = label.numel(), label.device
-    best_part = torch.empty(n, dtype=torch.int32, device=dev)
-    gain = torch.empty(n, dtype=torch.int32, device=dev)
     vw = vwgt.long()
     best_label, best_cut = label.clone(), _cut_weight(ptr, adj, wgt, label)
     stale = 0
     for it in range(passes):
-        with _on(dev):
-            _lib.check(lib.gnnome_kway_gains(_ptr(ptr), _ptr(adj), _ptr(wgt), _ptr(label), n, _ptr(best_part), _ptr(gain), _stream(dev)), "kway_gains")
+        best_part, gain = kernels.kway_gains(ptr, adj, wgt, label)
         pw = torch.zeros(k, dtype=torch.int64, device=dev).scatter_add_(0, label.long(), vw)
         up = (it % 2) == 0
         cand = (best_part >= 0) & ((best_part > label) if up else (best_part < label))
@@ -230,7 +252,7 @@ def _refine(ptr, adj, wgt, vwgt, label, k, max_pw, passes=12):
     return best_label
 
 
-def multilevel_partition(src, dst, num_nodes, num_clusters, ufactor=1.03):
+def multilevel_partition(src, dst, num_nodes, num_clusters, ufactor=1.03, kernels=_HipKernels):
     """label int64[N] in [0, num_clusters): the multilevel k-way scheme (module docstring) on the device of `src`."""
     n, k, dev = int(num_nodes), int(num_clusters), src.device
     if k <= 1 or n == 0:
@@ -242,17 +264,17 @@ def multilevel_partition(src, dst, num_nodes, num_clusters, ufactor=1.03):
     while ptr.numel() - 1 > coarsen_to:
         nv = ptr.numel() - 1
         max_vwgt = max(1, int(1.5 * n / coarsen_to))
-        cmap, nc = _hem_level(ptr, adj, wgt, vwgt, max_vwgt)
+        cmap, nc = _hem_level(ptr, adj, wgt, vwgt, max_vwgt, kernels=kernels)
         if nc > 0.95 * nv:          # the matching no longer shrinks the graph (stars, isolated vertices)
             break
         levels.append((ptr, adj, wgt, vwgt, cmap))
         ptr, adj, wgt, vwgt = _contract(ptr, adj, wgt, vwgt, cmap, nc)
     max_pw = int(ufactor * n / k) + 1
     label = _greedy_growing(ptr, adj, wgt, vwgt, k).to(dev)
-    label = _refine(ptr, adj, wgt, vwgt, label, k, max_pw)
+    label = _refine(ptr, adj, wgt, vwgt, label, k, max_pw, kernels=kernels)
     for fptr, fadj, fwgt, fvw, cmap in reversed(levels):
         label = label[cmap].contiguous()
-        label = _refine(fptr, fadj, fwgt, fvw, label, k, max_pw)
+        label = _refine(fptr, fadj, fwgt, fvw, label, k, max_pw, kernels=kernels)
     return label.long()
 
 

@@ -80,22 +80,23 @@ def greedy_growing(nbr, vwgt, k, rng):
             break
         target = (total - sum(vwgt[v] for v in range(n) if label[v] >= 0)) / (k - p)
         seed = rng.choice(sorted(free))
-        heap, conn, size = [(0, seed)], {seed: 0}, 0
+        heap, conn, size, tick = [(0, 0, seed)], {seed: 0}, 0, 1     # (priority, order of arrival, vertex): ties go to the earlier arrival
         while size < target and free:
-            while heap and (heap[0][1] not in free or -heap[0][0] != conn.get(heap[0][1], None)):
+            while heap and (heap[0][2] not in free or -heap[0][0] != conn.get(heap[0][2], None)):
                 heapq.heappop(heap)
             if not heap:      # the region's component is exhausted: continue from another free vertex
                 v = min(free)
                 conn[v] = 0
             else:
-                v = heapq.heappop(heap)[1]
+                v = heapq.heappop(heap)[2]
             free.discard(v)
             label[v] = p
             size += vwgt[v]
             for u, w in nbr[v].items():
                 if u in free:
                     conn[u] = conn.get(u, 0) + w
-                    heapq.heappush(heap, (-conn[u], u))
+                    heapq.heappush(heap, (-conn[u], tick, u))
+                    tick += 1
     for v in free:
         label[v] = k - 1
     return label

@@ -489,3 +489,48 @@ def stream_schedule(views, chunks, rps=16, slots=62):
         chunk_steps[c] = len(out)
     return {"chunk_node": chunk_node, "chunk_steps": chunk_steps, "steps": steps, "edge_meta": meta, "pending": pending, "far": far,
             "overflow": overflow}
+
+
+class PartitionKernels:
+    """The contracts of gnnome_hem_propose / gnnome_kway_gains (include/gnnome_hip.h) in plain Python: the checker backend of
+    gnnome_amd/partition.py's host logic."""
+
+    @staticmethod
+    def hem_propose(ptr, adj, wgt, vwgt, match, max_vwgt):
+        P, A, W, VW, M = (t.tolist() for t in (ptr, adj, wgt, vwgt, match))
+        n = len(VW)
+        out = [-1] * n
+        for v in range(n):
+            if M[v] >= 0:
+                continue
+            best, bw, bvw = -1, -1, 0
+            for q in range(P[v], P[v + 1]):
+                u = A[q]
+                if u == v or M[u] >= 0 or VW[v] + VW[u] > max_vwgt:
+                    continue
+                if W[q] > bw or (W[q] == bw and (VW[u] < bvw or (VW[u] == bvw and u < best))):
+                    best, bw, bvw = u, W[q], VW[u]
+            out[v] = best
+        return torch.tensor(out, dtype=torch.int32)
+
+    @staticmethod
+    def kway_gains(ptr, adj, wgt, label):
+        P, A, W, L = (t.tolist() for t in (ptr, adj, wgt, label))
+        n = len(L)
+        bp, gn = [-1] * n, [0] * n
+        for v in range(n):
+            conn, internal = {}, 0
+            for q in range(P[v], P[v + 1]):
+                u = A[q]
+                if u == v:
+                    continue
+                if L[u] == L[v]:
+                    internal += W[q]
+                elif L[u] in conn or len(conn) < 24:
+                    conn[L[u]] = conn.get(L[u], 0) + W[q]
+            best, bc = -1, -1
+            for p_, c in conn.items():
+                if c > bc or (c == bc and p_ < best):
+                    best, bc = p_, c
+            bp[v], gn[v] = best, (bc - internal if best >= 0 else 0)
+        return torch.tensor(bp, dtype=torch.int32), torch.tensor(gn, dtype=torch.int32)

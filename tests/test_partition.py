@@ -54,6 +54,27 @@ def test_oracle_scheme_is_a_sane_quality_reference():
     assert mo.edge_cut(s, d, lab) <= 1.6 * mo.edge_cut(s, d, ranges)
 
 
+def test_host_logic_of_the_multilevel_partition_on_the_checker_kernels():
+    """gnnome_amd/partition.py's levels, contraction, move selection and balance handling on the CPU, with tests/cpu_ops.PartitionKernels standing in
+    for the two HIP kernels: a 32 x 32 grid into 4 and 16 (optimal cuts 128 / 384 directed edges) and a layout-ordered assembly graph."""
+    import cpu_ops
+    from gnnome_amd import partition
+    src, dst, n = _grid(32)
+    ts, td = torch.as_tensor(src, dtype=torch.int32), torch.as_tensor(dst, dtype=torch.int32)
+    for k, optimal in ((4, 128), (16, 384)):
+        label = partition.multilevel_partition(ts, td, n, k, kernels=cpu_ops.PartitionKernels)
+        sizes = torch.bincount(label, minlength=k)
+        assert int(sizes.min()) > 0 and int(sizes.max()) <= int(1.03 * n / k) + 1
+        assert partition.edge_cut(ts, td, label) <= 1.25 * optimal
+    g = make_graph(3000, 30000, 3, "banded")
+    label = partition.multilevel_partition(g["src"], g["dst"], 3000, 6, kernels=cpu_ops.PartitionKernels)
+    ranges = torch.clamp(torch.arange(3000) * 6 // 3000, max=5)
+    assert int(torch.bincount(label, minlength=6).max()) <= int(1.03 * 3000 / 6) + 1
+    assert partition.edge_cut(g["src"], g["dst"], label) <= 1.3 * partition.edge_cut(g["src"], g["dst"], ranges)
+    ref = mo.edge_cut(g["src"].tolist(), g["dst"].tolist(), mo.partition(g["src"].tolist(), g["dst"].tolist(), 3000, 6, seed=1))
+    assert partition.edge_cut(g["src"], g["dst"], label) <= 1.15 * ref
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,e,k", [("grid", 0, 0, 4), ("grid", 0, 0, 16), ("banded", 8000, 80000, 8), ("permuted", 8000, 80000, 8),
                                         ("banded", 20000, 200000, 20)])
