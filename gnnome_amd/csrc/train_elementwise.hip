@@ -27,7 +27,18 @@ __device__ __forceinline__ void column_reduce(int64_t rows, int H, float* part, 
     f32x4 acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int64_t r = (int64_t)blockIdx.x * rpb + rsub; r < rows; r += (int64_t)gridDim.x * rpb) per_row(r, 4 * c4, acc);
+    // Round 5: every XCD (workgroup b runs on XCD b % 8, each with a private L2) walks its OWN contiguous eighth of the rows.  With the plain
+    // grid-stride walk the 8 row groups of a sweep went to 8 different XCDs, so a kernel that gathers node rows by the rows' endpoints
+    // (k_agg_edge_bwd_stats: six tables) pulled every table row into up to eight L2s: 3.15 GB fetched per launch at configs[2] against
+    // 1.85 GB of operands (profiles/r05_train_pmc_c2.json).  The partial sums stay per workgroup and are added in workgroup order as before.
+    if (gridDim.x % kXcds == 0) {
+        const int64_t per_xcd = ((rows + kXcds - 1) / kXcds + rpb - 1) / rpb * rpb;
+        const int64_t r0 = (int64_t)(blockIdx.x % kXcds) * per_xcd, r1 = min(rows, r0 + per_xcd);
+        const int64_t step = (int64_t)(gridDim.x / kXcds) * rpb;
+        for (int64_t r = r0 + (int64_t)(blockIdx.x / kXcds) * rpb + rsub; r < r1; r += step) per_row(r, 4 * c4, acc);
+    } else {
+        for (int64_t r = (int64_t)blockIdx.x * rpb + rsub; r < rows; r += (int64_t)gridDim.x * rpb) per_row(r, 4 * c4, acc);
+    }
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -348,8 +359,9 @@ using namespace gnnome;
 
 static unsigned col_grid(int64_t rows, int hidden) {
     const int rpb = kEwThreads / (hidden / 4);
-    const unsigned g = ew_grid((rows + rpb - 1) / rpb * kEwThreads / 4);
-    return g > (unsigned)kColMaxBlocks ? (unsigned)kColMaxBlocks : g;
+    unsigned g = ew_grid((rows + rpb - 1) / rpb * kEwThreads / 4);
+    g = g > (unsigned)kColMaxBlocks ? (unsigned)kColMaxBlocks : g;
+    return g >= 2 * kXcds ? g / kXcds * kXcds : g;   // whole multiples of the XCD count: column_reduce gives every XCD its own row range
 }
 
 extern "C" int gnnome_colsum_workspace_bytes(size_t* bytes_host) {

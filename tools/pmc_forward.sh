@@ -1,9 +1,9 @@
 #!/bin/bash
-# HBM traffic of every kernel of one forward (FETCH_SIZE / WRITE_SIZE, one counter per pass).  usage: tools/pmc_forward.sh <outdir> [workload]
-OUT=$1; W=${2:-c2}; R=${GRAFT_REPO_ROOT:-/root/repo}
+# HBM traffic of every kernel of one forward (FETCH_SIZE / WRITE_SIZE, one counter per pass).  usage: tools/pmc_forward.sh <outdir> [workload] [infer|train]
+OUT=$1; W=${2:-c2}; M=${3:-infer}; R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 150 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/$C -o p -- python $R/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-extras > /dev/null 2>&1 || echo "$C pass failed"
+  timeout 150 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/$C -o p -- python $R/bench.py --workload $W --mode $M --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-extras > /dev/null 2>&1 || echo "$C pass failed"
 done
 python - "$R/$OUT" <<'PY'
 import csv, sys, collections
