@@ -12,15 +12,15 @@ for mode in infer train; do
   rm -rf $O/prof_$mode
   head -14 $O/${TAG}_c2_$mode.kernel_stats.md
 done
-bash tools/pmc_traffic.sh $O/pmc
-python tools/pmc_to_json.py $O/pmc $O/${TAG}_gate_pmc.json k_edge_gate_ | tail -8   # k_edge_gate_pl at H = 128, k_edge_gate_bf at H = 64
-rm -rf $O/pmc
-bash tools/pmc_forward.sh $O/pmc_fwd > $O/${TAG}_forward_hbm_traffic.md 2>&1; tail -12 $O/${TAG}_forward_hbm_traffic.md
-rm -rf $O/pmc_fwd
-cp $O/${TAG}_gate_pmc.json profiles/   # so that the bench line below can quote the traffic of THIS build
+# PMC traffic of every kernel of one forward / one training step, stamped with the build (round 5: bench.py quotes `roofline.traffic` for whichever
+# kernel it names from profiles/<tag>_forward_pmc_<workload>.json)
+for w in c2 c4shard; do
+  bash tools/pmc_forward.sh $O/pmc_fwd_$w $w > $O/${TAG}_forward_hbm_traffic_$w.md 2>&1; tail -8 $O/${TAG}_forward_hbm_traffic_$w.md
+  python tools/pmc_forward_json.py $O/pmc_fwd_$w $O/${TAG}_forward_pmc_$w.json $w > /dev/null; cp $O/${TAG}_forward_pmc_$w.json profiles/; rm -rf $O/pmc_fwd_$w
+done
+bash tools/pmc_forward.sh $O/pmc_train c2 train > $O/${TAG}_train_hbm_traffic_c2.md 2>&1; python tools/pmc_forward_json.py $O/pmc_train $O/${TAG}_train_pmc_c2.json c2-train > /dev/null; rm -rf $O/pmc_train
 timeout 900 python bench.py > $O/${TAG}_bench_c2.json 2> $O/bench_c2.err; tail -c 400 $O/${TAG}_bench_c2.json
 for w in 10m parity64 c4shard; do timeout 400 python bench.py --workload $w --no-cpu-baseline --no-extras > $O/${TAG}_bench_$w.json 2>/dev/null; done
-timeout 400 python bench.py --kind uniform --no-cpu-baseline --no-extras > $O/${TAG}_bench_c2_uniform.json 2>/dev/null
 # the whole configs[3] graph and the configs[4] graph (inference) on ONE GPU: H = 256, 20M / 50M edges
 timeout 400 python bench.py --workload c4 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/${TAG}_bench_c4_one_gpu.json 2>/dev/null
 timeout 600 python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_bench_c5_one_gpu.json 2>/dev/null
@@ -38,14 +38,15 @@ python tools/rocpd_summary.py "$(find $O/prof_ecoli -name '*.db' | head -1)" > $
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c4 -o r -- python bench.py --workload c4shard --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-extras > /dev/null 2> $O/prof_c4.err
 python tools/rocpd_summary.py "$(find $O/prof_c4 -name '*.db' | head -1)" > $O/${TAG}_c4shard_infer.kernel_stats.md 2>&1; rm -rf $O/prof_c4
 timeout 200 python tools/gate_phase_profile.py --hidden 256 --edges 2500000 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gate256_phases.txt
-timeout 200 python tools/forward_ab.py 0,7 7 2>&1 | grep -v amdgpu.ids > $O/${TAG}_aggregation_without_in_edges.txt
-for f in c2 10m parity64 c4shard c4_one_gpu c5_one_gpu c2_uniform c3_train_step c3_train_bf16_storage c3_train_symmetry n2_plumbing n2_train_plumbing n2_train_h256_plumbing train_c4shard_h256 ecoli; do python - "$f" "$TAG" <<'PY'
+for k in permuted uniform; do timeout 400 python bench.py --kind $k --no-cpu-baseline --no-extras > $O/${TAG}_bench_c2_$k.json 2>/dev/null; done
+timeout 200 python tools/clock_sample.py > $O/${TAG}_clock_power_samples.jsonl 2>/dev/null
+for f in c2 10m parity64 c4shard c4_one_gpu c5_one_gpu c2_uniform c2_permuted c3_train_step c3_train_bf16_storage c3_train_symmetry n2_plumbing n2_train_plumbing n2_train_h256_plumbing train_c4shard_h256 ecoli; do python - "$f" "$TAG" <<'PY'
 import json,sys
 f,tag=sys.argv[1],sys.argv[2]
 try:
     d=json.loads([l for l in open(f"gpurun_out/final/{tag}_bench_{f}.json") if l.startswith("{")][-1])
     r=d.get("roofline",{})
-    print(f, round(d["ms_per_step"],3), "ms", round(d["value"]/1e6,1), "M edges/s | gate", round(r.get("avg_launch_ms",0),4), r.get("bound"), round(r.get("frac",0),3), "traffic", r.get("traffic"), "| cpu", (d.get("cpu_baseline") or {}).get("value"))
+    print(f, round(d["ms_per_step"],3), "ms", round(d["value"]/1e6,1), "M edges/s | roofline", r.get("kernel","")[:16], round(r.get("avg_launch_ms",0),4), r.get("bound"), round(r.get("frac",0),3), "traffic", r.get("traffic"), "| cpu", (d.get("cpu_baseline") or {}).get("value"))
 except Exception as ex:
     print(f, "FAILED", ex)
 PY
