@@ -76,6 +76,8 @@ SIGNATURES = {
     "gnnome_bn_bwd_dgrad_out_x16": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_agg_edge_bwd_stats_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_agg_edge_bwd_stats_x16": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gnnome_agg_bwd_fused_f32": [_p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gnnome_agg_bwd_fused_x16": [_p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_bn_bwd_terms_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p],
     "gnnome_pack_layer_f32": [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p],
     "gnnome_bn_train_finish_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _i, _p, _p, _p, _p, _p],
@@ -92,7 +94,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

@@ -19,26 +19,12 @@ constexpr int kEwThreads = 256;
 constexpr int kColMaxBlocks = 1024;
 constexpr size_t kColWorkspaceBytes = sizeof(float) * kColMaxBlocks * 2 * 256;
 
-template <int NACC, class F>
-__device__ __forceinline__ void column_reduce(int64_t rows, int H, float* part, F&& per_row) {
+// The workgroup's column sums of the threads' accumulators -> part[a][c][workgroup] (thread t holds columns 4 (t % (H/4)) .. + 3 of its rows)
+template <int NACC>
+__device__ __forceinline__ void column_fold(const f32x4 (&acc)[NACC], int H, float* part) {
     __shared__ float red[NACC][kEwThreads * 4];
     const int lpr = H / 4, tid = threadIdx.x;
     const int c4 = tid % lpr, rsub = tid / lpr, rpb = kEwThreads / lpr;
-    f32x4 acc[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Round 5: every XCD (workgroup b runs on XCD b % 8, each with a private L2) walks its OWN contiguous eighth of the rows.  With the plain
-    // grid-stride walk the 8 row groups of a sweep went to 8 different XCDs, so a kernel that gathers node rows by the rows' endpoints
-    // (k_agg_edge_bwd_stats: six tables) pulled every table row into up to eight L2s: 3.15 GB fetched per launch at configs[2] against
-    // 1.85 GB of operands (profiles/r05_train_pmc_c2.json).  The partial sums stay per workgroup and are added in workgroup order as before.
-    if (gridDim.x % kXcds == 0) {
-        const int64_t per_xcd = ((rows + kXcds - 1) / kXcds + rpb - 1) / rpb * rpb;
-        const int64_t r0 = (int64_t)(blockIdx.x % kXcds) * per_xcd, r1 = min(rows, r0 + per_xcd);
-        const int64_t step = (int64_t)(gridDim.x / kXcds) * rpb;
-        for (int64_t r = r0 + (int64_t)(blockIdx.x / kXcds) * rpb + rsub; r < r1; r += step) per_row(r, 4 * c4, acc);
-    } else {
-        for (int64_t r = (int64_t)blockIdx.x * rpb + rsub; r < rows; r += (int64_t)gridDim.x * rpb) per_row(r, 4 * c4, acc);
-    }
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -52,6 +38,34 @@ __device__ __forceinline__ void column_reduce(int64_t rows, int H, float* part, 
             part[((int64_t)a * H + c) * kColMaxBlocks + blockIdx.x] = s;   // [a][c][workgroup]: the finish reads along b
         }
     }
+}
+
+// The rows thread t of workgroup b visits: first row, end, stride (see column_reduce)
+struct RowWalk { int64_t r, r1, step; };
+__device__ __forceinline__ RowWalk column_walk(int64_t rows, int H) {
+    const int lpr = H / 4, rsub = threadIdx.x / lpr, rpb = kEwThreads / lpr;
+    if (gridDim.x % kXcds == 0) {
+        const int64_t per_xcd = ((rows + kXcds - 1) / kXcds + rpb - 1) / rpb * rpb;
+        const int64_t r0 = (int64_t)(blockIdx.x % kXcds) * per_xcd;
+        return RowWalk{r0 + (int64_t)(blockIdx.x / kXcds) * rpb + rsub, min(rows, r0 + per_xcd), (int64_t)(gridDim.x / kXcds) * rpb};
+    }
+    return RowWalk{(int64_t)blockIdx.x * rpb + rsub, rows, (int64_t)gridDim.x * rpb};
+}
+
+template <int NACC, class F>
+__device__ __forceinline__ void column_reduce(int64_t rows, int H, float* part, F&& per_row) {
+    const int lpr = H / 4, tid = threadIdx.x;
+    const int c4 = tid % lpr;
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Round 5: every XCD (workgroup b runs on XCD b % 8, each with a private L2) walks its OWN contiguous eighth of the rows.  With the plain
+    // grid-stride walk the 8 row groups of a sweep went to 8 different XCDs, so a kernel that gathers node rows by the rows' endpoints
+    // (k_agg_edge_bwd_stats: six tables) pulled every table row into up to eight L2s: 3.15 GB fetched per launch at configs[2] against
+    // 1.85 GB of operands (profiles/r05_train_pmc_c2.json).  The partial sums stay per workgroup and are added in workgroup order as before.
+    const RowWalk w = column_walk(rows, H);
+    for (int64_t r = w.r; r < w.r1; r += w.step) per_row(r, 4 * c4, acc);
+    column_fold<NACC>(acc, H, part);
 }
 
 // out[a][c] = sum_b part[a][c][b] in a FIXED order: one wave per (a, c) pair, lane l adds b = l, l + 64, ... and
@@ -598,7 +612,7 @@ extern "C" int gnnome_gate_center_f32(const float* e, int64_t num_edges, int hid
 // (m = relu mask rebuilt from the forward's expression).  One read of xe here replaces gnnome_bn_bwd_stats_f32's reads of de'
 // and xe.
 namespace gnnome {
-template <int H, bool X16, bool BATCH = true>
+template <int H, bool X16, bool BATCH = true, bool NT = false>
 __global__ __launch_bounds__(kEwThreads) void k_agg_edge_bwd_stats(const float* __restrict__ e, int64_t E, const float* __restrict__ Tf,
                                                                    const float* __restrict__ Uf, const float* __restrict__ Tb,
                                                                    const float* __restrict__ Ub, const float* __restrict__ A2h,
@@ -610,9 +624,11 @@ __global__ __launch_bounds__(kEwThreads) void k_agg_edge_bwd_stats(const float* 
     column_reduce<2>(E, H, part, [&](int64_t p, int c, f32x4 (&acc)[2]) {
         // the three row loads whose addresses need no index go out with the index loads; the six gathers follow when the indices are in
         const int64_t s_ = srt_src[p], d_ = srt_dst[p];
-        const f32x4 x = *reinterpret_cast<const f32x4*>(e + p * H + c);
-        const f32x4 xv = load4_as<X16>(xe, p * H + c);
-        f32x4 g = *reinterpret_cast<const f32x4*>(de + p * H + c);
+        // NT: the three streams (each row read once by the whole launch) go past the L2's replacement order, which then keeps the six tables' rows
+        const f32x4 x = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e + p * H + c)) : *reinterpret_cast<const f32x4*>(e + p * H + c);
+        const f32x4 xv = (NT && !X16) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(xe) + p * H + c))
+                                      : load4_as<X16>(xe, p * H + c);
+        f32x4 g = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(de + p * H + c)) : *reinterpret_cast<const f32x4*>(de + p * H + c);
         const f32x4 tf = *reinterpret_cast<const f32x4*>(Tf + d_ * H + c), uf = *reinterpret_cast<const f32x4*>(Uf + d_ * H + c);
         const f32x4 tb = *reinterpret_cast<const f32x4*>(Tb + s_ * H + c), ub = *reinterpret_cast<const f32x4*>(Ub + s_ * H + c);
         const f32x4 a2 = *reinterpret_cast<const f32x4*>(A2h + s_ * ldn + c), a3 = *reinterpret_cast<const f32x4*>(A3h + d_ * ldn + c);
@@ -629,6 +645,144 @@ __global__ __launch_bounds__(kEwThreads) void k_agg_edge_bwd_stats(const float* 
         }
         *reinterpret_cast<f32x4*>(de + p * H + c) = g;
     });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The aggregation's WHOLE backward over the edges in one launch (round 5): the node sums of gnnome_node_aggregate_raw_f32 mode 2
+//   sum_in[i] = sum_{p: dst_p = i} s_p Tb[src_p],   sum_out[i] = sum_{p: src_p = i} s_p Tf[dst_p],   s = sigmoid(e')
+// AND the per-edge pass above (de' += s(1-s)(...), bn_e's backward statistics) - both read every e' row and evaluate its sigmoid;
+// as two launches they stream e' from HBM twice (0.20 + 0.49 ms at configs[2]).  One wave per node, as the aggregation walks the
+// lists: the in-edge rows of node i are the contiguous sorted positions in_ptr[i] .. in_ptr[i+1], so the rows of e', xe and de' of those
+// edges are streamed once here, three of the per-edge pass's six gathers (Tf, Uf, A3h at dst = i) become ONE row per node, and
+// the out-edge pass reads the e' rows its neighbours' in-edge passes have just brought into the L2.
+// Workgroups walk the 4-node groups as column_reduce walks rows (an XCD owns a contiguous eighth, its workgroups interleave in it: many
+// CUs stream adjacent rows at the same time); the statistics leave as per-workgroup partial sums in a fixed order (k_col_finish).
+// A node of any degree is walked by its one wave (64 items at a time): correct for hubs, not fast.
+template <int H, bool X16>
+__global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(4))) void k_agg_bwd_fused(const float* __restrict__ e, int64_t n_nodes, int64_t n_edges, const float* __restrict__ Tf,
+                                                              const float* __restrict__ Uf, const float* __restrict__ Tb,
+                                                              const float* __restrict__ Ub, const float* __restrict__ A2h,
+                                                              const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr,
+                                                              const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_ptr,
+                                                              const int32_t* __restrict__ out_pos, const int32_t* __restrict__ out_dst,
+                                                              float* __restrict__ de, const void* __restrict__ xe,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ mean, float* __restrict__ sum_in,
+                                                              float* __restrict__ sum_out, float* __restrict__ part) {
+    constexpr int LPR = H / 4, G = 64 / LPR, UI = 2, UO = 4, WAVES = kEwThreads / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int group = lane / LPR, c = (lane % LPR) * 4;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    const f32x4 mn = *reinterpret_cast<const f32x4*>(mean + c);
+    const int64_t groups = (n_nodes + WAVES - 1) / WAVES;
+    int64_t g0, g1, gstep;
+    if (gridDim.x % kXcds == 0) {
+        const int64_t per_xcd = (groups + kXcds - 1) / kXcds;
+        g0 = (int64_t)(blockIdx.x % kXcds) * per_xcd;
+        g1 = min(groups, g0 + per_xcd);
+        g0 += blockIdx.x / kXcds;
+        gstep = gridDim.x / kXcds;
+    } else {
+        g0 = blockIdx.x, g1 = groups, gstep = gridDim.x;
+    }
+    for (int64_t gi = g0; gi < g1; gi += gstep) {
+        const int64_t node = gi * WAVES + wave;
+        if (node >= n_nodes) continue;   // (no barrier inside the loop)
+        const int ib = in_ptr[node], din = in_ptr[node + 1] - ib;
+        const int ob = out_ptr[node], dout = out_ptr[node + 1] - ob;
+        const f32x4 tf = *reinterpret_cast<const f32x4*>(Tf + node * H + c), uf = *reinterpret_cast<const f32x4*>(Uf + node * H + c);
+        const f32x4 a3 = *reinterpret_cast<const f32x4*>(A3h + node * ldn + c);
+        f32x4 nf = {0.f, 0.f, 0.f, 0.f}, nb = nf;
+        // the neighbour indices of the first 64 items of BOTH lists go out together, unconditionally (a lane past the end of a list repeats a
+        // valid position): the out-list's two index loads are then under way while the in-edges are walked
+        const int64_t last = n_edges - 1;
+        const int first_n = srt_src[min((int64_t)ib + min(lane, max(din - 1, 0)), last)];
+        const int64_t oq = min((int64_t)ob + min(lane, max(dout - 1, 0)), last);
+        const int first_op = out_pos[oq], first_on = out_dst[oq];
+        // ---- in-edges: rows ib .. ib + din of e', xe, de' (streamed), the tables at src (gathered)
+        for (int base = 0; base < din; base += 64) {
+            const int m = min(64, din - base);
+            int my_n = first_n;
+            if (base > 0) my_n = lane < m ? srt_src[ib + base + lane] : 0;
+            for (int j0 = 0; j0 < m; j0 += G * UI) {
+                f32x4 x[UI], xv[UI], g[UI], tb[UI], ub[UI], a2[UI];
+                bool live[UI];
+                int64_t p[UI];
+#pragma unroll
+                for (int u = 0; u < UI; ++u) {
+                    const int item = j0 + u * G + group;
+                    live[u] = item < m;
+                    p[u] = ib + base + (live[u] ? item : 0);
+                    // e' stays in the L2's ordinary order (the out-edge pass of a neighbour reads the row again); xe and de' are read once
+                    x[u] = *reinterpret_cast<const f32x4*>(e + p[u] * H + c);
+                    xv[u] = X16 ? load4_as<true>(xe, p[u] * H + c)
+                                : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(xe) + p[u] * H + c));
+                    g[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(de + p[u] * H + c));
+                }
+#pragma unroll
+                for (int u = 0; u < UI; ++u) {
+                    const int64_t nn = __shfl(my_n, live[u] ? j0 + u * G + group : 0);
+                    tb[u] = *reinterpret_cast<const f32x4*>(Tb + nn * H + c);
+                    ub[u] = *reinterpret_cast<const f32x4*>(Ub + nn * H + c);
+                    a2[u] = *reinterpret_cast<const f32x4*>(A2h + nn * ldn + c);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // all twelve loads of the step are in flight before the first use
+#pragma unroll
+                for (int u = 0; u < UI; ++u) {
+                    // a dead slot (its loads repeat the batch's first item) adds +0 everywhere: no branch around the arithmetic
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float sg = live[u] ? sigmoidf_(x[u][k]) : 0.f;
+                        nf[k] += sg * tb[u][k];
+                        g[u][k] += sg * (1.f - sg) * (tf[k] * a2[u][k] - uf[k] + tb[u][k] * a3[k] - ub[u][k]);
+                        const float gm = (live[u] && xv[u][k] * sc[k] + sh[k] > 0.f) ? g[u][k] : 0.f;
+                        acc[0][k] += gm;
+                        acc[1][k] += gm * (xv[u][k] - mn[k]);
+                    }
+                    if (live[u]) __builtin_nontemporal_store(g[u], reinterpret_cast<f32x4*>(de + p[u] * H + c));
+                }
+            }
+        }
+        // ---- out-edges: e' rows through out_pos (rows a neighbour's in-edge pass streams at about this time), Tf at dst
+        for (int base = 0; base < dout; base += 64) {
+            const int m = min(64, dout - base);
+            int my_p = first_op, my_n = first_on;
+            if (base > 0) {
+                my_p = lane < m ? out_pos[ob + base + lane] : 0;
+                my_n = lane < m ? out_dst[ob + base + lane] : 0;
+            }
+            for (int j0 = 0; j0 < m; j0 += G * UO) {
+                f32x4 x[UO], t[UO];
+                bool live[UO];
+#pragma unroll
+                for (int u = 0; u < UO; ++u) {
+                    const int item = j0 + u * G + group;
+                    live[u] = item < m;
+                    const int64_t pp = __shfl(my_p, live[u] ? item : 0), nn = __shfl(my_n, live[u] ? item : 0);
+                    x[u] = *reinterpret_cast<const f32x4*>(e + pp * H + c);
+                    t[u] = *reinterpret_cast<const f32x4*>(Tf + nn * H + c);
+                }
+#pragma unroll
+                for (int u = 0; u < UO; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) nb[k] += (live[u] ? sigmoidf_(x[u][k]) : 0.f) * t[u][k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int mm = LPR; mm < 64; mm <<= 1) {
+                nf[k] += __shfl_xor(nf[k], mm);
+                nb[k] += __shfl_xor(nb[k], mm);
+            }
+        }
+        if (group == 0) {
+            *reinterpret_cast<f32x4*>(sum_in + node * H + c) = nf;
+            *reinterpret_cast<f32x4*>(sum_out + node * H + c) = nb;
+        }
+    }
+    column_fold<2>(acc, H, part);
 }
 }  // namespace gnnome
 
@@ -647,17 +801,17 @@ static int agg_edge_bwd_stats_impl(const float* e, int64_t num_edges, int hidden
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = col_grid(num_edges, hidden);
 #define GN_AEBS(HH, XX)                                                                                                              \
-    hipLaunchKernelGGL((k_agg_edge_bwd_stats<HH, XX>), dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, \
-                       srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace)
+    do {                                                                                                                             \
+        if (tuning(kTuneGateExperiment) == 77)   /* A/B: the three streams through the L2's ordinary replacement order */            \
+            hipLaunchKernelGGL((k_agg_edge_bwd_stats<HH, XX>), dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, \
+                               ld_node, srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace);                            \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_agg_edge_bwd_stats<HH, XX, true, true>), dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, \
+                               A2h, A3h, ld_node, srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace);                  \
+    } while (0)
     switch (hidden) {
         case 64: if (x16) GN_AEBS(64, true); else GN_AEBS(64, false); break;
-        case 128:
-            if (x16) GN_AEBS(128, true);
-            else if (tuning(kTuneGateExperiment) == 77)   // A/B: the compiler's own load placement
-                hipLaunchKernelGGL((k_agg_edge_bwd_stats<128, false, false>), dim3(grid), dim3(kEwThreads), 0, s, e, num_edges, Tf, Uf, Tb, Ub, A2h, A3h,
-                                   ld_node, srt_src, srt_dst, de, xe, scale, shift, mean, (float*)workspace);
-            else GN_AEBS(128, false);
-            break;
+        case 128: if (x16) GN_AEBS(128, true); else GN_AEBS(128, false); break;
         case 256: if (x16) GN_AEBS(256, true); else GN_AEBS(256, false); break;
         default: set_error("agg_edge_bwd_stats: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
     }
@@ -666,6 +820,66 @@ static int agg_edge_bwd_stats_impl(const float* e, int64_t num_edges, int hidden
     hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, s, (const float*)workspace, (int)grid, hidden, s1, s2);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
+}
+
+static int agg_bwd_fused_impl(const float* e, int64_t num_nodes, int64_t num_edges, int hidden, const float* Tf, const float* Uf, const float* Tb,
+                              const float* Ub, const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr, const int32_t* srt_src,
+                              const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst, float* de, const void* xe, bool x16,
+                              const float* scale, const float* shift, const float* mean, float* sum_in, float* sum_out, float* s1, float* s2,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(num_nodes >= 1 && num_edges >= 0, "agg_bwd_fused: needs at least one node");
+    GN_REQUIRE(Tf && Uf && Tb && Ub && A2h && A3h && in_ptr && out_ptr && scale && shift && mean && sum_in && sum_out && s1 && s2 &&
+                   ld_node % 4 == 0 && ld_node >= hidden,
+               "agg_bwd_fused: bad arguments");
+    GN_REQUIRE(num_edges == 0 || (e && srt_src && out_pos && out_dst && de && xe), "agg_bwd_fused: null edge operand");
+    GN_REQUIRE(workspace && workspace_bytes >= kColWorkspaceBytes && (uintptr_t)workspace % 16 == 0,
+               "agg_bwd_fused: workspace too small or misaligned (gnnome_colsum_workspace_bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    if (num_edges == 0) {   // nothing to walk: the sums of empty lists
+        GN_HIP(hipMemsetAsync(sum_in, 0, sizeof(float) * (size_t)num_nodes * hidden, s));
+        GN_HIP(hipMemsetAsync(sum_out, 0, sizeof(float) * (size_t)num_nodes * hidden, s));
+        GN_HIP(hipMemsetAsync(s1, 0, sizeof(float) * hidden, s));
+        GN_HIP(hipMemsetAsync(s2, 0, sizeof(float) * hidden, s));
+        return GNNOME_OK;
+    }
+    const int64_t groups = (num_nodes + kEwThreads / 64 - 1) / (kEwThreads / 64);
+    unsigned grid = (unsigned)std::min<int64_t>(groups, kColMaxBlocks);
+    if (grid >= 2 * kXcds) grid = grid / kXcds * kXcds;
+#define GN_ABF(HH, XX)                                                                                                               \
+    hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, in_ptr, \
+                       srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out, (float*)workspace)
+    switch (hidden) {
+        case 64: if (x16) GN_ABF(64, true); else GN_ABF(64, false); break;
+        case 128: if (x16) GN_ABF(128, true); else GN_ABF(128, false); break;
+        case 256: if (x16) GN_ABF(256, true); else GN_ABF(256, false); break;
+        default: set_error("agg_bwd_fused: hidden=%d not in {64,128,256}", hidden); return GNNOME_EINVAL;
+    }
+#undef GN_ABF
+    GN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, s, (const float*)workspace, (int)grid, hidden, s1, s2);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
+extern "C" int gnnome_agg_bwd_fused_f32(const float* e, int64_t num_nodes, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                                        const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
+                                        const int32_t* in_ptr, const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
+                                        const int32_t* out_dst, float* de, const float* xe, const float* scale, const float* shift,
+                                        const float* mean, float* sum_in, float* sum_out, float* s1, float* s2, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    return agg_bwd_fused_impl(e, num_nodes, num_edges, hidden, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de,
+                              xe, false, scale, shift, mean, sum_in, sum_out, s1, s2, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gnnome_agg_bwd_fused_x16(const float* e, int64_t num_nodes, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                                        const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
+                                        const int32_t* in_ptr, const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
+                                        const int32_t* out_dst, float* de, const uint16_t* xe, const float* scale, const float* shift,
+                                        const float* mean, float* sum_in, float* sum_out, float* s1, float* s2, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    return agg_bwd_fused_impl(e, num_nodes, num_edges, hidden, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de,
+                              xe, true, scale, shift, mean, sum_in, sum_out, s1, s2, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gnnome_agg_edge_bwd_stats_f32(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf,

@@ -72,8 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, 
     const float* b_col = B + j0 + 4 * c4;
     const bool sums = colsum_part != nullptr && blockIdx.y == 0;
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
-    f32x4 av[4], bv[4];
-    auto fetch = [&](int64_t r0) {
+    auto fetch = [&](f32x4 (&av)[4], f32x4 (&bv)[4], int64_t r0) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int64_t row = r0 + 4 * rr + t;
@@ -99,15 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, 
     // fragment f of wave half w: slots 64 w + 32 f + (lane & 31), rows 16 s + 8 (lane >> 5) .. + 7
     const unsigned char* ap = Ap + (64 * wi + (lane & 31)) * kWgColBytes + 16 * (lane >> 5);
     const unsigned char* bp = Bp + (64 * wj + (lane & 31)) * kWgColBytes + 16 * (lane >> 5);
-    fetch(r_begin);
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
-        if (!(ABL & 4) || r0 == r_begin) {
-            stage(Ap, av);
-            stage(Bp, bv);
-        }
-        if (sums) cs += (av[0] + av[1]) + (av[2] + av[3]);
-        __syncthreads();
-        if (r0 + kWgRows < r_end && !(ABL & 1)) fetch(r0 + kWgRows);
+    auto products = [&]() {
 #pragma unroll
         for (int s = 0; s < ((ABL & 2) ? 0 : kWgRows / 16); ++s) {
             uint4 a1[2], a2[2], a3[2], b1[2], b2[2], b3[2];
@@ -136,7 +127,66 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, 
                     acc[a][b] = c;
                 }
         }
-        __syncthreads();
+    };
+    if (ABL & 8) {
+        // One slab in flight per workgroup (32 KB, two workgroups per CU) is 16 MB on the chip: at the 3-4 us a request takes under load that
+        // is the ~3.8 TB/s measured.  Here TWO slabs are in flight - slab s + 2 is requested while slab s is multiplied - in two register
+        // sets that take turns (the body handles a pair of slabs; a chunk with an odd count multiplies one slab of zeros at its end).
+        // Every request is unconditional (rows past the chunk's end repeat its last row and are zeroed when they are staged): hipcc's wait
+        // counts ignore loads behind a branch, and a `vmcnt(0)` at the top of the body would drain both sets.
+        const float* b_safe = b_in ? b_col : B;   // (a_col is inside A already when a_in is false)
+        auto request = [&](f32x4 (&av)[4], f32x4 (&bv)[4], int64_t r0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t row = min(r0 + 4 * rr + t, r_end - 1);
+                av[t] = X16 ? load4_as<true>(a_base16, a_off16 + row * lda) : *reinterpret_cast<const f32x4*>(a_col + row * lda);
+                bv[t] = *reinterpret_cast<const f32x4*>(b_safe + row * ldb);
+            }
+        };
+        auto zeroed = [&](f32x4 (&v)[4], int64_t r0, bool in) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (!in || r0 + 4 * rr + t >= r_end) v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        f32x4 av0[4], bv0[4], av1[4], bv1[4];
+        request(av0, bv0, r_begin);
+        __builtin_amdgcn_sched_barrier(0);   // in this order: the body's wait counts are the minimum over both ways into it
+        request(av1, bv1, r_begin + kWgRows);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * kWgRows) {
+            zeroed(av0, r0, a_in);
+            zeroed(bv0, r0, b_in);
+            stage(Ap, av0);
+            stage(Bp, bv0);
+            if (sums) cs += (av0[0] + av0[1]) + (av0[2] + av0[3]);
+            __syncthreads();
+            request(av0, bv0, r0 + 2 * kWgRows);
+            products();
+            __syncthreads();
+            zeroed(av1, r0 + kWgRows, a_in);
+            zeroed(bv1, r0 + kWgRows, b_in);
+            stage(Ap, av1);
+            stage(Bp, bv1);
+            if (sums) cs += (av1[0] + av1[1]) + (av1[2] + av1[3]);
+            __syncthreads();
+            request(av1, bv1, r0 + 3 * kWgRows);
+            products();
+            __syncthreads();
+        }
+    } else {
+        f32x4 av[4], bv[4];
+        fetch(av, bv, r_begin);
+        for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
+            if (!(ABL & 4) || r0 == r_begin) {
+                stage(Ap, av);
+                stage(Bp, bv);
+            }
+            if (sums) cs += (av[0] + av[1]) + (av[2] + av[3]);
+            __syncthreads();
+            if (r0 + kWgRows < r_end && !(ABL & 1)) fetch(av, bv, r0 + kWgRows);
+            products();
+            __syncthreads();
+        }
     }
     float* out = partial + ((int64_t)blockIdx.z * Ka + i0) * Kb + j0;
 #pragma unroll
@@ -690,6 +740,8 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
         hipLaunchKernelGGL((k_wgrad_partial<false, 4>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
     else if (tuning(kTuneGateAblation) == 5)
         hipLaunchKernelGGL((k_wgrad_partial<false, 5>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
+    else if (tuning(kTuneGateAblation) == 8)
+        hipLaunchKernelGGL((k_wgrad_partial<false, 8>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
     else
         hipLaunchKernelGGL(k_wgrad_partial<false>, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
     GN_LAUNCH_CHECK();

@@ -924,6 +924,29 @@ def agg_edge_bwd_stats(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift,
     return de, s[0], s[1]
 
 
+def agg_bwd_fused(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift, mean, num_nodes):
+    """node_aggregate_raw(e, None, Tb, Tf, views, 2, num_nodes) and agg_edge_bwd_stats(...) in one launch (gnnome_agg_bwd_fused_f32: one
+    read of e from HBM instead of two) -> (sum_in, sum_out, de, s1, s2); de is updated in place."""
+    A2h, ldn = _rows(A2h, "agg_bwd_fused.A2h")
+    A3h, l3 = _rows(A3h, "agg_bwd_fused.A3h")
+    assert ldn == l3
+    H, dev = e.shape[1], e.device
+    for name, t in (("Tf", Tf), ("Uf", Uf), ("Tb", Tb), ("Ub", Ub)):
+        if t.shape != (num_nodes, H) or not t.is_contiguous() or t.dtype != torch.float32:
+            raise ValueError(f"agg_bwd_fused.{name}: expected a contiguous float32 [{num_nodes}, {H}] tensor, got {tuple(t.shape)} {t.dtype}")
+    if A2h.shape[0] < num_nodes or A3h.shape[0] < num_nodes:
+        raise ValueError("agg_bwd_fused: A2h / A3h have fewer rows than num_nodes")
+    sums = torch.empty((2, num_nodes, H), dtype=torch.float32, device=dev)
+    s = torch.empty((2, H), dtype=torch.float32, device=dev)
+    ws = _col_workspace(dev)
+    xe, x16 = _act(xe, "agg_bwd_fused.xe")
+    _call("gnnome_agg_bwd_fused_x16" if x16 else "gnnome_agg_bwd_fused_f32", dev, _ptr(_dense(e, "e")), num_nodes, e.shape[0], H, _ptr(Tf), _ptr(Uf),
+          _ptr(Tb), _ptr(Ub), _ptr(A2h), _ptr(A3h), ldn, _ptr(views.in_ptr), _ptr(views.srt_src), _ptr(views.out_ptr), _ptr(views.out_pos),
+          _ptr(views.out_dst), _ptr(_dense(de, "de")), _ptr(xe), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(sums[0]), _ptr(sums[1]), _ptr(s[0]),
+          _ptr(s[1]), _ptr(ws), ws.numel())
+    return sums[0], sums[1], de, s[0], s[1]
+
+
 def encode_hidden(x, W1, b1, gather=None, rows=None):
     x = x.contiguous()
     rows = int(x.shape[0] if rows is None else rows)

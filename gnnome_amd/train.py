@@ -136,6 +136,7 @@ def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out, stats=None, 
 
 
 ACTIVATION_STORAGE = ("fp32", "bf16")
+FUSED_AGG_BWD = True   # the aggregation's node sums and per-edge backward as one launch (gnnome_agg_bwd_fused_f32; tools/train_ab.py switches it)
 TWO_PASS_GATE = True   # the single-rank BatchNorm forward at hidden 128 as statistics pass + fused gate (tools/train_ab.py switches it for A/B runs)
 
 
@@ -357,12 +358,21 @@ class _TrainStep(torch.autograd.Function):
             # v = A1h + fwd + bwd
             Tf, Uf = ops.mul23(dv, s["rdf"], s["hf"])
             Tb, Ub = ops.mul23(dv, s["rdb"], s["hb"])
-            sum_in, sum_out = ops.node_aggregate_raw(s["e_new"], None, Tb, Tf, views, 2, n_local)   # = dA3(role), dA2(role)
             if s["xe"] is None:     # model.recompute_gate: xe was not kept - one more gate launch instead of an [E,H] tensor per layer
                 _, layer_norm_, storage_ = s["gate_path"]
                 _, s["xe"], _ = _raw_gate(sh, conv, s["e"], blk(s["P"], "B1"), blk(s["P"], "B2"), layer_norm_, storage_, path=s["gate_path"][0])
             stats_e = None
-            if s["sc_e"] is not None and hasattr(ops, "agg_edge_bwd_stats"):
+            fused = s["sc_e"] is not None and FUSED_AGG_BWD and hasattr(ops, "agg_bwd_fused")
+            if fused:
+                # the node sums (dA3 / dA2 by role), de += ... and bn_e's backward statistics in ONE pass over the e' rows
+                sum_in, sum_out, _, s1_e, s2_e = ops.agg_bwd_fused(s["e_new"], Tf, Uf, Tb, Ub, blk(s["P"], "A2"), blk(s["P"], "A3"), views, de,
+                                                                   s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], n_local)
+                stats_e = (s1_e, s2_e)
+            else:
+                sum_in, sum_out = ops.node_aggregate_raw(s["e_new"], None, Tb, Tf, views, 2, n_local)   # = dA3(role), dA2(role)
+            if fused:
+                pass
+            elif s["sc_e"] is not None and hasattr(ops, "agg_edge_bwd_stats"):
                 # de += ... and bn_e's backward statistics of the result in the same pass over the edges
                 _, s1_e, s2_e = ops.agg_edge_bwd_stats(s["e_new"], Tf, Uf, Tb, Ub, blk(s["P"], "A2"), blk(s["P"], "A3"), views, de, s["xe"],
                                                        s["sc_e"], s["sh_e"], s["mean_e"])

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 11
+#define GNNOME_ABI_VERSION 12
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -459,6 +459,19 @@ int gnnome_agg_edge_bwd_stats_f32(const float* e, int64_t num_edges, int hidden,
                                   const float* shift, const float* mean, float* s1, float* s2, void* workspace,
                                   size_t workspace_bytes, void* stream);
 
+/* The aggregation's whole backward over the edges in ONE launch (round 5; the backward of gated_gcn_full.py:118-126's two gated
+ * sums as autograd derives it): gnnome_node_aggregate_raw_f32 mode 2 with the tables (Tb at src, Tf at dst)
+ *   sum_in[i,:]  = sum_{p: dst_p = i} sigmoid(e[p,:]) Tb[src_p,:]      sum_out[i,:] = sum_{p: src_p = i} sigmoid(e[p,:]) Tf[dst_p,:]
+ * AND gnnome_agg_edge_bwd_stats_f32 (de updated in place, s1 / s2 of the result) - as two launches they stream e from HBM twice.
+ * One wave per node over the destination-sorted views; num_nodes rows of Tf/Uf/Tb/Ub [., hidden] and A2h/A3h (row stride ld_node),
+ * sum_in / sum_out [num_nodes, hidden] overwritten.  Equal to the two launches up to fp32 reassociation of the sums; every sum is
+ * formed in an order that depends on the graph and the launch geometry only (same bits on every run).  workspace as gnnome_colsum2_f32. */
+int gnnome_agg_bwd_fused_f32(const float* e, int64_t num_nodes, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                             const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
+                             const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst, float* de,
+                             const float* xe, const float* scale, const float* shift, const float* mean, float* sum_in, float* sum_out,
+                             float* s1, float* s2, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The per-channel arithmetic of a train-mode BatchNorm1d call in one launch (gated_gcn_full.py:106,119,132 with
  * nn.BatchNorm1d's buffer semantics): from shifted column sums d1 = sum(x - center), d2 = sum((x - center)^2) over `rows`
  * rows -> mean, rstd = 1/sqrt(biased var + eps), scale = gamma*rstd, shift = beta - mean*scale, and `updates` momentum
@@ -554,7 +567,7 @@ int gnnome_bfs_levels(const int32_t* ptr, const int32_t* adj, int64_t num_nodes,
  * when written, widened exactly when read; every sum, product and statistic is still fp32, and the residual streams e, e', de,
  * h stay fp32 (|e| reaches several hundred with per-layer updates of order one: bf16 there would drop the updates).  Each entry
  * is its _f32 namesake with the marked tensor as uint16_t (bf16 bits), contiguous, 8-byte aligned:
- *   raw_stats: x_out (the statistics are those of the ROUNDED values);  bn_relu_res: x;  agg_edge_bwd_stats: xe;
+ *   raw_stats: x_out (the statistics are those of the ROUNDED values);  bn_relu_res: x;  agg_edge_bwd_stats, agg_bwd_fused: xe;
  *   bn_bwd_dgrad: X and dxe (C += dxe W^T uses the unrounded dxe);  segment_sum2: X;  wgrad: A (lda in elements). */
 int gnnome_edge_gate_raw_stats_x16(const float* e_in, uint16_t* x_out, int64_t num_edges, int hidden, const float* B1h, const float* B2h,
                                    int ld_node, const int32_t* srt_src, const int32_t* srt_dst, const float* W3, int ldw,
@@ -569,6 +582,11 @@ int gnnome_agg_edge_bwd_stats_x16(const float* e, int64_t num_edges, int hidden,
                                   const float* Ub, const float* A2h, const float* A3h, int ld_node, const int32_t* srt_src,
                                   const int32_t* srt_dst, float* de, const uint16_t* xe, const float* scale, const float* shift,
                                   const float* mean, float* s1, float* s2, void* workspace, size_t workspace_bytes, void* stream);
+int gnnome_agg_bwd_fused_x16(const float* e, int64_t num_nodes, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
+                             const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
+                             const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst, float* de,
+                             const uint16_t* xe, const float* scale, const float* shift, const float* mean, float* sum_in, float* sum_out,
+                             float* s1, float* s2, void* workspace, size_t workspace_bytes, void* stream);
 int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift, const float* a,
                             const float* c1, const float* c2, const float* mean, const float* rstd, const float* W, int ldw,
                             uint16_t* dxe, void* stream);

@@ -370,6 +370,13 @@ def agg_edge_bwd_stats(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift,
     return de, s1, s2
 
 
+def agg_bwd_fused(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift, mean, num_nodes):
+    """ops.agg_bwd_fused: node_aggregate_raw mode 2 (tables Tb at src, Tf at dst) and agg_edge_bwd_stats as one op."""
+    sum_in, sum_out = node_aggregate_raw(e, None, Tb, Tf, views, 2, num_nodes)
+    _, s1, s2 = agg_edge_bwd_stats(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift, mean)
+    return sum_in, sum_out, de, s1, s2
+
+
 def can_fuse_bn_bwd_dgrad(de, W, xe=None):
     return de.shape[0] > 0
 

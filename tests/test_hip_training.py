@@ -517,6 +517,85 @@ def test_fused_backward_kernels_equal_their_unfused_pairs(hidden, e):
         assert (c - want_c).abs().max().item() <= 2e-5 * max(1.0, want_c.abs().max().item()), once
 
 
+@pytest.mark.parametrize("hidden,n,e,kind", [(128, 500, 50_001, "uniform"), (64, 300, 7000, "uniform"), (128, 40, 31, "uniform"), (256, 500, 40_003, "uniform"),
+                                             (128, 3000, 30_000, "banded"), (128, 200, 20_000, "hub"), (128, 50, 0, "uniform"), (64, 1, 5, "uniform")])
+def test_fused_aggregation_backward_equals_the_two_launches(hidden, n, e, kind):
+    """gnnome_agg_bwd_fused_f32 (round 5) = gnnome_node_aggregate_raw_f32 mode 2 + gnnome_agg_edge_bwd_stats_f32: the node sums, the updated
+    de and bn_e's backward statistics of ONE pass over the e rows against the two launches it replaces (fp32 reassociation of the sums
+    only), against the checker's torch restatement, with xe as bf16, and the same bits on every run.  Graphs: uniform (nodes without
+    in- or out-edges), banded (the assembly layout), one hub with > 64 items in both lists (several 64-item batches in one wave), no
+    edges at all, a single node with self-loops."""
+    g = torch.Generator().manual_seed(hidden + e + n)
+    H = hidden
+    if kind == "banded":
+        gr = make_graph(n, e, seed=3)
+        src, dst = gr["src"].int(), gr["dst"].int()
+    else:
+        src, dst = torch.randint(0, n, (e,), generator=g).int(), torch.randint(0, n, (e,), generator=g).int()
+        if kind == "hub":   # node 7: ~ a third of all edges in, another third out
+            src[: e // 3] = 7
+            dst[e // 3: 2 * e // 3] = 7
+    views = ops.GraphViews(src.to(dev()), dst.to(dev()), n)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev())  # noqa: E731
+    ee, xe, de0 = 2 * r(e, H), 3 * r(e, H), r(e, H)
+    Tf, Uf, Tb, Ub, P = r(n, H), r(n, H), r(n, H), r(n, H), r(n, 2 * H)
+    scale, shift, mean = (torch.rand(H, generator=g) + 0.5).to(dev()), r(H), r(H)
+    A2, A3 = P[:, :H], P[:, H:]
+    w_in, w_out = ops.node_aggregate_raw(ee, None, Tb, Tf, views, 2, n)
+    w_de, w1, w2 = ops.agg_edge_bwd_stats(ee, Tf, Uf, Tb, Ub, A2, A3, views, de0.clone(), xe, scale, shift, mean)
+    got = ops.agg_bwd_fused(ee, Tf, Uf, Tb, Ub, A2, A3, views, de0.clone(), xe, scale, shift, mean, n)
+    deg = max(1.0, float(e) / max(n, 1)) if kind != "hub" else float(e)
+    for name, a, b, tol in (("sum_in", got[0], w_in, 2e-6 * deg), ("sum_out", got[1], w_out, 2e-6 * deg), ("de", got[2], w_de, 2e-6),
+                            ("s1", got[3], w1, 1e-4), ("s2", got[4], w2, 1e-4)):
+        assert a.shape == b.shape, name
+        if a.numel():
+            assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), (name, (a - b).abs().max().item())
+    # the checker's torch restatement (tests/cpu_ops.py) on the host
+    if e > 0:
+        import types
+        cv = types.SimpleNamespace(srt_src=views.srt_src.cpu(), srt_dst=views.srt_dst.cpu())   # the same sorted order of the edges
+        c = lambda t: t.cpu()  # noqa: E731
+        want = cpu_ops.agg_bwd_fused(c(ee), c(Tf), c(Uf), c(Tb), c(Ub), c(A2), c(A3), cv, c(de0).clone(), c(xe), c(scale), c(shift), c(mean), n)
+        for name, a, b, tol in zip(("sum_in", "sum_out", "de", "s1", "s2"), got, want, (1e-4, 1e-4, 1e-5, 2e-4, 2e-4)):
+            assert (a.cpu() - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), (name, (a.cpu() - b).abs().max().item())
+    again = ops.agg_bwd_fused(ee, Tf, Uf, Tb, Ub, A2, A3, views, de0.clone(), xe, scale, shift, mean, n)
+    assert all(torch.equal(u, v) for u, v in zip(got, again))
+    if e > 0:   # xe stored as bfloat16: the fp32 kernel on the widened values, bit for bit
+        x16 = xe.to(torch.bfloat16)
+        a_ = ops.agg_bwd_fused(ee, Tf, Uf, Tb, Ub, A2, A3, views, de0.clone(), x16, scale, shift, mean, n)
+        b_ = ops.agg_bwd_fused(ee, Tf, Uf, Tb, Ub, A2, A3, views, de0.clone(), x16.float(), scale, shift, mean, n)
+        assert all(torch.equal(u, v) for u, v in zip(a_, b_))
+    with pytest.raises(ValueError):
+        ops.agg_bwd_fused(ee, Tf[:-1] if n > 1 else Tf.t(), Uf, Tb, Ub, A2, A3, views, de0.clone(), xe, scale, shift, mean, n)
+
+
+def test_training_step_is_the_same_with_and_without_the_fused_aggregation_backward():
+    """train.FUSED_AGG_BWD: the whole step (8 layers, H = 128, 40k edges) with the one launch and with the two it replaces - loss equal,
+    every gradient within fp32 reassociation."""
+    import gnnome_amd.train as train
+    n, e, hidden = 4000, 40_000, 128
+    gr = make_graph(n, e, seed=2)
+    sd = random_state_dict(hidden, seed=4)
+    grads = {}
+    for on in (True, False):
+        train.FUSED_AGG_BWD = on
+        try:
+            m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch", dropout=0.0)
+            m.load_state_dict(sd)
+            m.to(dev()).train()
+            x = degree_features(gr["src"], gr["dst"], n).to(dev())
+            got = m((gr["src"].to(dev()), gr["dst"].to(dev()), n), x, gr["e"].to(dev()))
+            loss = F.binary_cross_entropy_with_logits(got.squeeze(-1), gr["y"].to(dev()), pos_weight=gr["pos_weight"].to(dev()))
+            loss.backward()
+            grads[on] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
+        finally:
+            train.FUSED_AGG_BWD = True
+    assert grads[True][0] == grads[False][0]
+    num = sum(((grads[True][1][k] - grads[False][1][k]).double() ** 2).sum().item() for k in grads[True][1]) ** 0.5
+    den = sum((grads[False][1][k].double() ** 2).sum().item() for k in grads[False][1]) ** 0.5
+    assert num / den < 1e-5, num / den
+
+
 @pytest.mark.parametrize("hidden,e", [(128, 50_001), (64, 7000), (128, 31), (256, 40_001)])   # 256: round 4 (fp16x3 raw gate, plane-form mode 3, 256 x 256 wgrad)
 def test_bf16_storage_kernels_equal_the_fp32_kernels_on_rounded_tensors(hidden, e):
     """The *_x16 entry points (xe / dxe stored as bfloat16): each equals its _f32 namesake fed the SAME values widened to fp32

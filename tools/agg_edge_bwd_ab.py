@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Same-process A/B of gnnome_agg_edge_bwd_stats_f32's two forms (tuning 4 = 77: one row of a thread per trip to memory; default: two),
-launches alternating, HIP events around single calls, results compared:  python tools/agg_edge_bwd_ab.py [H] [nodes] [edges] [kind]"""
+"""Same-process A/B of gnnome_agg_edge_bwd_stats_f32's forms (tuning 4: 77 = the three streams as plain loads, 0 = the default: nontemporal) and of the
+fused launch (gnnome_agg_bwd_fused_f32) against the pair it replaces, launches alternating, HIP events around single calls, results compared:
+python tools/agg_edge_bwd_ab.py [H] [nodes] [edges] [kind] [membw]"""
 import json
 import os
 import sys
@@ -36,20 +37,22 @@ def run(variant, de):
         ops.set_tuning(KEY, 0)
 
 
+VARIANTS = (77, 0)
 outs = {}
-for v in (77, 0):
+for v in VARIANTS:
     de = de0.clone()
     _, s1, s2 = run(v, de)
     outs[v] = (de, s1.clone(), s2.clone())
 torch.cuda.synchronize()
-same_de = torch.equal(outs[77][0], outs[0][0])
 rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()   # noqa: E731
-print(json.dumps({"de_bit_equal": same_de, "s1_rel": rel(outs[0][1], outs[77][1]), "s2_rel": rel(outs[0][2], outs[77][2])}))
+for v in VARIANTS[1:]:
+    print(json.dumps({"variant": v, "de_bit_equal_to_77": torch.equal(outs[77][0], outs[v][0]), "s1_rel": rel(outs[v][1], outs[77][1]),
+                      "s2_rel": rel(outs[v][2], outs[77][2])}))
 
 scratch = de0.clone()
-times = {77: [], 0: []}
+times = {v: [] for v in VARIANTS}
 for rep in range(40):
-    for v in (77, 0):
+    for v in VARIANTS:
         s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         run(v, scratch)
@@ -57,8 +60,39 @@ for rep in range(40):
         times[v].append((s, t))
 torch.cuda.synchronize()
 rec = {"H": H, "nodes": n, "edges": e, "kind": kind}
-for v, name in ((77, "one_row_ms"), (0, "two_rows_ms")):
+for v, name in ((77, "plain_loads_ms"), (0, "default_nontemporal_ms")):
     ts = sorted(a.elapsed_time(b) for a, b in times[v][5:])
+    rec[name] = round(ts[len(ts) // 2], 4)
+    rec[name + "_min"] = round(ts[0], 4)
+print(json.dumps(rec))
+
+# ---- the pair (node sums, then the per-edge pass) against the one fused launch
+def pair(de):
+    si, so = ops.node_aggregate_raw(ee, None, Tb, Tf, views, 2, n)
+    _, s1, s2 = ops.agg_edge_bwd_stats(ee, Tf, Uf, Tb, Ub, A2, A3, views, de, xe, sc, sh, mn)
+    return si, so, de, s1, s2
+
+
+def fused(de):
+    return ops.agg_bwd_fused(ee, Tf, Uf, Tb, Ub, A2, A3, views, de, xe, sc, sh, mn, n)
+
+
+a, b = pair(de0.clone()), fused(de0.clone())
+torch.cuda.synchronize()
+print(json.dumps({"fused_vs_pair": {k: rel(y.clone(), x.clone()) for k, x, y in zip(("sum_in", "sum_out", "de", "s1", "s2"), a, b)},
+                  "fused_same_bits_twice": all(torch.equal(u, v) for u, v in zip(fused(de0.clone()), b))}))
+times = {"pair_ms": [], "fused_ms": []}
+for rep in range(40):
+    for name, fn in (("pair_ms", pair), ("fused_ms", fused)):
+        s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn(scratch)
+        t.record()
+        times[name].append((s, t))
+torch.cuda.synchronize()
+rec = {"H": H, "nodes": n, "edges": e, "kind": kind}
+for name in times:
+    ts = sorted(x.elapsed_time(y) for x, y in times[name][5:])
     rec[name] = round(ts[len(ts) // 2], 4)
     rec[name + "_min"] = round(ts[0], 4)
 print(json.dumps(rec))
