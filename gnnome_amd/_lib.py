@@ -49,6 +49,7 @@ SIGNATURES = {
     "gnnome_bn_relu_res_x16": [_p, _p, _p, _p, _l, _i, _p, _p],
     "gnnome_bn_bwd_stats_f32": [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _sz, _p],
     "gnnome_bn_bwd_apply_f32": [_p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
+    "gnnome_bn_bwd_apply_tables_f32": [_p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_ln_relu_res_f32": [_p, _p, _p, _p, _l, _i, _i, _p, _p],
     "gnnome_ln_bwd_f32": [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _sz, _p],
     "gnnome_mul23_f32": [_p, _p, _p, _l, _p, _p, _p],

@@ -146,6 +146,40 @@ __global__ __launch_bounds__(kEwThreads) void k_bn_bwd_apply(const float* __rest
     }
 }
 
+// k_bn_bwd_apply for the node BatchNorm of a layer WITH the four node tables of the aggregation's backward (the two k_mul23 launches that
+// followed it, each reading dx again):  Tf = dx rdf, Uf = Tf hf, Tb = dx rdb, Ub = Tb hb  - one pass over the [rows, H] tensors.
+__global__ __launch_bounds__(kEwThreads) void k_bn_bwd_apply_tables(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    int64_t rows, int H, const float* __restrict__ a,
+                                                                    const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                    const float* __restrict__ rdf, const float* __restrict__ hf,
+                                                                    const float* __restrict__ rdb, const float* __restrict__ hb,
+                                                                    float* __restrict__ dx, float* __restrict__ Tf, float* __restrict__ Uf,
+                                                                    float* __restrict__ Tb, float* __restrict__ Ub) {
+    const int64_t total = rows * (H / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (H / 4)) * 4;
+        const int64_t off = (i / (H / 4)) * H + c;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + off);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(rdf + off), h1 = *reinterpret_cast<const f32x4*>(hf + off);
+        const f32x4 r2 = *reinterpret_cast<const f32x4*>(rdb + off), h2 = *reinterpret_cast<const f32x4*>(hb + off);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g = (xv[j] * scale[c + j] + shift[c + j] > 0.f) ? d[j] : 0.f;
+            o[j] = a[c + j] * (g - c1[c + j] - (xv[j] - mean[c + j]) * rstd[c + j] * c2[c + j]);
+        }
+        const f32x4 t1 = o * r1, t2 = o * r2;
+        *reinterpret_cast<f32x4*>(dx + off) = o;
+        *reinterpret_cast<f32x4*>(Tf + off) = t1;
+        *reinterpret_cast<f32x4*>(Uf + off) = t1 * h1;
+        *reinterpret_cast<f32x4*>(Tb + off) = t2;
+        *reinterpret_cast<f32x4*>(Ub + off) = t2 * h2;
+    }
+}
+
 // out = relu(x * scale + shift) + res
 template <bool X16>
 __global__ __launch_bounds__(kEwThreads) void k_bn_relu_res(const void* __restrict__ x, const float* __restrict__ scale,
@@ -431,6 +465,20 @@ extern "C" int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const fl
     return GNNOME_OK;
 }
 
+extern "C" int gnnome_bn_bwd_apply_tables_f32(const float* dy, const float* x, const float* scale, const float* shift, int64_t rows,
+                                              int hidden, const float* a, const float* c1, const float* c2, const float* mean,
+                                              const float* rstd, const float* rdf, const float* hf, const float* rdb, const float* hb,
+                                              float* dx, float* Tf, float* Uf, float* Tb, float* Ub, void* stream) {
+    GN_REQUIRE(rows >= 0 && hidden > 0 && hidden % 4 == 0, "bn_bwd_apply_tables: bad shape");
+    if (rows == 0) return GNNOME_OK;
+    GN_REQUIRE(dy && x && scale && shift && a && c1 && c2 && mean && rstd && rdf && hf && rdb && hb && dx && Tf && Uf && Tb && Ub,
+               "bn_bwd_apply_tables: null pointer");
+    hipLaunchKernelGGL(k_bn_bwd_apply_tables, dim3(ew_grid(rows * (hidden / 4))), dim3(kEwThreads), 0, (hipStream_t)stream, dy, x, scale,
+                       shift, rows, hidden, a, c1, c2, mean, rstd, rdf, hf, rdb, hb, dx, Tf, Uf, Tb, Ub);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+
 static int bn_relu_res_impl(const void* x, bool x16, const float* scale, const float* shift, const float* res, int64_t rows, int hidden,
                             float* out, void* stream) {
     GN_REQUIRE(rows >= 0 && hidden > 0 && hidden % 4 == 0, "bn_relu_res: bad shape");
@@ -658,8 +706,8 @@ __global__ __launch_bounds__(kEwThreads) void k_agg_edge_bwd_stats(const float* 
 // Workgroups walk the 4-node groups as column_reduce walks rows (an XCD owns a contiguous eighth, its workgroups interleave in it: many
 // CUs stream adjacent rows at the same time); the statistics leave as per-workgroup partial sums in a fixed order (k_col_finish).
 // A node of any degree is walked by its one wave (64 items at a time): correct for hubs, not fast.
-template <int H, bool X16>
-__global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(4))) void k_agg_bwd_fused(const float* __restrict__ e, int64_t n_nodes, int64_t n_edges, const float* __restrict__ Tf,
+template <int H, bool X16, int UI = 2, int UO = 4, int WPE = 4>
+__global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(WPE))) void k_agg_bwd_fused(const float* __restrict__ e, int64_t n_nodes, int64_t n_edges, const float* __restrict__ Tf,
                                                               const float* __restrict__ Uf, const float* __restrict__ Tb,
                                                               const float* __restrict__ Ub, const float* __restrict__ A2h,
                                                               const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr,
@@ -669,12 +717,18 @@ __global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(4)))
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ mean, float* __restrict__ sum_in,
                                                               float* __restrict__ sum_out, float* __restrict__ part) {
-    constexpr int LPR = H / 4, G = 64 / LPR, UI = 2, UO = 4, WAVES = kEwThreads / 64;
+    constexpr int LPR = H / 4, G = 64 / LPR, WAVES = kEwThreads / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int group = lane / LPR, c = (lane % LPR) * 4;
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
-    const f32x4 mn = *reinterpret_cast<const f32x4*>(mean + c);
+    // the three per-channel vectors live in LDS (12 registers per lane otherwise: the kernel is held to 128 for four waves per SIMD)
+    __shared__ __attribute__((aligned(16))) float cst[3][H];
+    for (int i = threadIdx.x; i < H; i += kEwThreads) {
+        cst[0][i] = scale[i];
+        cst[1][i] = shift[i];
+        cst[2][i] = mean[i];
+    }
+    __syncthreads();
     const int64_t groups = (n_nodes + WAVES - 1) / WAVES;
     int64_t g0, g1, gstep;
     if (gridDim.x % kXcds == 0) {
@@ -686,20 +740,24 @@ __global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(4)))
     } else {
         g0 = blockIdx.x, g1 = groups, gstep = gridDim.x;
     }
+    // (Measured and dropped: requesting the NEXT node's list pointers at the top of a node and its index lists before the out-edge pass, so
+    // that a node starts with its rows - 0.620 against 0.566 ms: inside 128 registers the values held ahead are spilled as they arrive.)
+    const int64_t last = n_edges - 1;
     for (int64_t gi = g0; gi < g1; gi += gstep) {
         const int64_t node = gi * WAVES + wave;
         if (node >= n_nodes) continue;   // (no barrier inside the loop)
+        const bool live_node = true;
+        const int64_t nrow = node;
         const int ib = in_ptr[node], din = in_ptr[node + 1] - ib;
         const int ob = out_ptr[node], dout = out_ptr[node + 1] - ob;
-        const f32x4 tf = *reinterpret_cast<const f32x4*>(Tf + node * H + c), uf = *reinterpret_cast<const f32x4*>(Uf + node * H + c);
-        const f32x4 a3 = *reinterpret_cast<const f32x4*>(A3h + node * ldn + c);
-        f32x4 nf = {0.f, 0.f, 0.f, 0.f}, nb = nf;
         // the neighbour indices of the first 64 items of BOTH lists go out together, unconditionally (a lane past the end of a list repeats a
         // valid position): the out-list's two index loads are then under way while the in-edges are walked
-        const int64_t last = n_edges - 1;
         const int first_n = srt_src[min((int64_t)ib + min(lane, max(din - 1, 0)), last)];
         const int64_t oq = min((int64_t)ob + min(lane, max(dout - 1, 0)), last);
         const int first_op = out_pos[oq], first_on = out_dst[oq];
+        const f32x4 tf = *reinterpret_cast<const f32x4*>(Tf + nrow * H + c), uf = *reinterpret_cast<const f32x4*>(Uf + nrow * H + c);
+        const f32x4 a3 = *reinterpret_cast<const f32x4*>(A3h + nrow * ldn + c);
+        f32x4 nf = {0.f, 0.f, 0.f, 0.f}, nb = nf;
         // ---- in-edges: rows ib .. ib + din of e', xe, de' (streamed), the tables at src (gathered)
         for (int base = 0; base < din; base += 64) {
             const int m = min(64, din - base);
@@ -728,6 +786,8 @@ __global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(4)))
                     a2[u] = *reinterpret_cast<const f32x4*>(A2h + nn * ldn + c);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // all twelve loads of the step are in flight before the first use
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(&cst[0][c]), sh = *reinterpret_cast<const f32x4*>(&cst[1][c]);
+                const f32x4 mn = *reinterpret_cast<const f32x4*>(&cst[2][c]);
 #pragma unroll
                 for (int u = 0; u < UI; ++u) {
                     // a dead slot (its loads repeat the batch's first item) adds +0 everywhere: no branch around the arithmetic
@@ -777,7 +837,7 @@ __global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(4)))
                 nb[k] += __shfl_xor(nb[k], mm);
             }
         }
-        if (group == 0) {
+        if (group == 0 && live_node) {
             *reinterpret_cast<f32x4*>(sum_in + node * H + c) = nf;
             *reinterpret_cast<f32x4*>(sum_out + node * H + c) = nb;
         }
@@ -847,8 +907,20 @@ static int agg_bwd_fused_impl(const float* e, int64_t num_nodes, int64_t num_edg
     unsigned grid = (unsigned)std::min<int64_t>(groups, kColMaxBlocks);
     if (grid >= 2 * kXcds) grid = grid / kXcds * kXcds;
 #define GN_ABF(HH, XX)                                                                                                               \
-    hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, in_ptr, \
-                       srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out, (float*)workspace)
+    do {                                                                                                                             \
+        if (tuning(kTuneGateExperiment) == 81)   /* A/B: five out-edge items per lane group and step */                              \
+            hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX, 2, 5>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, A2h, \
+                               A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out,    \
+                               (float*)workspace);                                                                                   \
+        else if (tuning(kTuneGateExperiment) == 82)   /* A/B: three in-edge items per step, three waves per SIMD */                 \
+            hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX, 3, 4, 3>), dim3(grid / 4 * 3), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, \
+                               Ub, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in,    \
+                               sum_out, (float*)workspace);                                                                          \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, \
+                               ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out,         \
+                               (float*)workspace);                                                                                   \
+    } while (0)
     switch (hidden) {
         case 64: if (x16) GN_ABF(64, true); else GN_ABF(64, false); break;
         case 128: if (x16) GN_ABF(128, true); else GN_ABF(128, false); break;
@@ -857,6 +929,7 @@ static int agg_bwd_fused_impl(const float* e, int64_t num_nodes, int64_t num_edg
     }
 #undef GN_ABF
     GN_LAUNCH_CHECK();
+    if (tuning(kTuneGateExperiment) == 82) grid = grid / 4 * 3;
     hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, s, (const float*)workspace, (int)grid, hidden, s1, s2);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;

@@ -734,6 +734,22 @@ def bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd, out=None):
     return dx
 
 
+def bn_bwd_apply_tables(dy, x, scale, shift, a, c1, c2, mean, rstd, rdf, hf, rdb, hb, out=None):
+    """bn_bwd_apply and the two mul23 calls that follow it for a layer's node BatchNorm, one launch: -> (dx, Tf, Uf, Tb, Ub) with
+    Tf = dx*rdf, Uf = Tf*hf, Tb = dx*rdb, Ub = Tb*hb."""
+    dx = torch.empty_like(x) if out is None else _dense(out, "bn_bwd_apply_tables.out")
+    t = torch.empty((4,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+    if x.shape[0] == 0:
+        return dx, t[0], t[1], t[2], t[3]
+    for name, v in (("rdf", rdf), ("hf", hf), ("rdb", rdb), ("hb", hb)):
+        if v.shape != x.shape:
+            raise ValueError(f"bn_bwd_apply_tables.{name}: shape {tuple(v.shape)} != {tuple(x.shape)}")
+    _call("gnnome_bn_bwd_apply_tables_f32", x.device, _ptr(_dense(dy, "dy")), _ptr(_dense(x, "x")), _ptr(scale), _ptr(shift), x.shape[0],
+          x.shape[1], _ptr(a), _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(_dense(rdf, "rdf")), _ptr(_dense(hf, "hf")),
+          _ptr(_dense(rdb, "rdb")), _ptr(_dense(hb, "hb")), _ptr(dx), _ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(t[3]))
+    return dx, t[0], t[1], t[2], t[3]
+
+
 def ln_relu_res(x, gamma, beta, res, out=None, width=None):
     """relu(LayerNorm(x) * gamma + beta) + res (normalization='layer' in train mode).  width: the statistics run over the first `width`
     channels (a zero-padded narrower model; default: all)."""

@@ -136,6 +136,7 @@ def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out, stats=None, 
 
 
 ACTIVATION_STORAGE = ("fp32", "bf16")
+FUSED_NODE_TABLES = True   # bn_h's backward apply + the four node tables of the aggregation's backward as one launch (gnnome_bn_bwd_apply_tables_f32)
 FUSED_AGG_BWD = True   # the aggregation's node sums and per-edge backward as one launch (gnnome_agg_bwd_fused_f32; tools/train_ab.py switches it)
 TWO_PASS_GATE = True   # the single-rank BatchNorm forward at hidden 128 as statistics pass + fused gate (tools/train_ab.py switches it for A/B runs)
 
@@ -351,13 +352,24 @@ class _TrainStep(torch.autograd.Function):
             if s["sc_h"] is None:   # LayerNorm: per-row backward, linear in dy, so partial gradients of replicas simply add
                 _, g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = ops.ln_bwd(dh[:n_own], s["v"][:n_own], d(conv.bn_h.weight),
                                                                              d(conv.bn_h.bias), out=dv[:n_own], width=ln_width)
+                tables = None
+            elif n_local == n_own and FUSED_NODE_TABLES and hasattr(ops, "bn_bwd_apply_tables"):
+                # bn_h's backward and the four node tables of the aggregation's backward (Tf, Uf, Tb, Ub) in one pass over the node rows
+                g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"], c1, c2 = _bn_bwd(sh, dh, s["v"], s["sc_h"], s["sh_h"], s["mean_h"], s["rstd_h"],
+                                                                               sh.n_global, n_own, None, apply=False)
+                _, *tables = ops.bn_bwd_apply_tables(dh, s["v"], s["sc_h"], s["sh_h"], s["sc_h"], c1, c2, s["mean_h"], s["rstd_h"], s["rdf"],
+                                                     s["hf"], s["rdb"], s["hb"], out=dv)
             else:
                 g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = _bn_bwd(sh, dh[:n_own], s["v"][:n_own], s["sc_h"], s["sh_h"], s["mean_h"],
                                                                        s["rstd_h"], sh.n_global, n_own, dv[:n_own])
+                tables = None
             dh_in = dh
             # v = A1h + fwd + bwd
-            Tf, Uf = ops.mul23(dv, s["rdf"], s["hf"])
-            Tb, Ub = ops.mul23(dv, s["rdb"], s["hb"])
+            if tables is not None:
+                Tf, Uf, Tb, Ub = tables
+            else:
+                Tf, Uf = ops.mul23(dv, s["rdf"], s["hf"])
+                Tb, Ub = ops.mul23(dv, s["rdb"], s["hb"])
             if s["xe"] is None:     # model.recompute_gate: xe was not kept - one more gate launch instead of an [E,H] tensor per layer
                 _, layer_norm_, storage_ = s["gate_path"]
                 _, s["xe"], _ = _raw_gate(sh, conv, s["e"], blk(s["P"], "B1"), blk(s["P"], "B2"), layer_norm_, storage_, path=s["gate_path"][0])

@@ -331,6 +331,14 @@ int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const float* scale,
                             int hidden, const float* a, const float* c1, const float* c2, const float* mean,
                             const float* rstd, float* dx, void* stream);
 
+/* gnnome_bn_bwd_apply_f32 for bn_h of a layer WITH the four node tables of the aggregation's backward in the same pass (round 5; what two
+ * gnnome_mul23_f32 launches made of dx, each reading it again):  Tf = dx rdf,  Uf = Tf hf,  Tb = dx rdb,  Ub = Tb hb, all [rows, hidden]
+ * contiguous; rdf / hf / rdb / hb are the forward's gnnome_node_aggregate_raw_f32 mode-1 outputs aux1 / aux0 / aux3 / aux2. */
+int gnnome_bn_bwd_apply_tables_f32(const float* dy, const float* x, const float* scale, const float* shift, int64_t rows, int hidden,
+                                   const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
+                                   const float* rdf, const float* hf, const float* rdb, const float* hb, float* dx, float* Tf, float* Uf,
+                                   float* Tb, float* Ub, void* stream);
+
 /* LayerNorm variant (normalization='layer', gated_gcn_full.py:40-42,106,119,132) of the two groups above:
  *   out = relu(LN(x) * gamma + beta) + res, LN over the `hidden` entries of each row (biased variance, eps 1e-5);
  *   backward: dx = rstd_row (g - mean_row(g) - xhat mean_row(g xhat)) with g = dy m gamma, m the relu mask;

@@ -257,6 +257,12 @@ def bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd, out=None):
     return out
 
 
+def bn_bwd_apply_tables(dy, x, scale, shift, a, c1, c2, mean, rstd, rdf, hf, rdb, hb, out=None):
+    dx = bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd, out=out)
+    tf, tb = dx * rdf, dx * rdb
+    return dx, tf, tf * hf, tb, tb * hb
+
+
 def _ln_parts(x, width=None):
     w = width or x.shape[1]
     mu = x[:, :w].mean(1, keepdim=True)

@@ -569,16 +569,41 @@ def test_fused_aggregation_backward_equals_the_two_launches(hidden, n, e, kind):
         ops.agg_bwd_fused(ee, Tf[:-1] if n > 1 else Tf.t(), Uf, Tb, Ub, A2, A3, views, de0.clone(), xe, scale, shift, mean, n)
 
 
-def test_training_step_is_the_same_with_and_without_the_fused_aggregation_backward():
-    """train.FUSED_AGG_BWD: the whole step (8 layers, H = 128, 40k edges) with the one launch and with the two it replaces - loss equal,
-    every gradient within fp32 reassociation."""
+@pytest.mark.parametrize("rows,hidden", [(5000, 128), (33, 64), (1, 256), (0, 128)])
+def test_bn_backward_with_node_tables_equals_the_three_launches(rows, hidden):
+    """gnnome_bn_bwd_apply_tables_f32 (round 5) = gnnome_bn_bwd_apply_f32 + two gnnome_mul23_f32: same expressions, same bits."""
+    g = torch.Generator().manual_seed(rows + hidden)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev())  # noqa: E731
+    H = hidden
+    dy, x, rdf, hf, rdb, hb = (r(rows, H) for _ in range(6))
+    scale, shift, a, c1, c2, mean, rstd = ((torch.rand(H, generator=g) + 0.5).to(dev()) if k in (0, 6) else r(H) for k in range(7))
+    want_dx = ops.bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd)
+    want = (want_dx,) + tuple(ops.mul23(want_dx, rdf, hf)) + tuple(ops.mul23(want_dx, rdb, hb))
+    out = torch.empty_like(x)
+    got = ops.bn_bwd_apply_tables(dy, x, scale, shift, a, c1, c2, mean, rstd, rdf, hf, rdb, hb, out=out)
+    assert got[0].data_ptr() == out.data_ptr()
+    for name, u, v in zip(("dx", "Tf", "Uf", "Tb", "Ub"), got, want):
+        assert u.shape == v.shape and torch.equal(u, v), name
+    twin = cpu_ops.bn_bwd_apply_tables(*(t.cpu() for t in (dy, x, scale, shift, a, c1, c2, mean, rstd, rdf, hf, rdb, hb)))
+    for name, u, v in zip(("dx", "Tf", "Uf", "Tb", "Ub"), got, twin):
+        if u.numel():
+            assert (u.cpu() - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), name
+    if rows:
+        with pytest.raises(ValueError):
+            ops.bn_bwd_apply_tables(dy, x, scale, shift, a, c1, c2, mean, rstd, rdf[:-1], hf, rdb, hb)
+
+
+@pytest.mark.parametrize("switch", ["FUSED_AGG_BWD", "FUSED_NODE_TABLES"])
+def test_training_step_is_the_same_with_and_without_the_fused_backward_launches(switch):
+    """train.FUSED_AGG_BWD / train.FUSED_NODE_TABLES: the whole step (8 layers, H = 128, 40k edges) with the one launch and with the launches it
+    replaces - loss equal, every gradient within fp32 reassociation."""
     import gnnome_amd.train as train
     n, e, hidden = 4000, 40_000, 128
     gr = make_graph(n, e, seed=2)
     sd = random_state_dict(hidden, seed=4)
     grads = {}
     for on in (True, False):
-        train.FUSED_AGG_BWD = on
+        setattr(train, switch, on)
         try:
             m = gnnome_amd.models.SymGatedGCNModel(2, 2, hidden, 16, 8, 64, "batch", dropout=0.0)
             m.load_state_dict(sd)
@@ -589,7 +614,7 @@ def test_training_step_is_the_same_with_and_without_the_fused_aggregation_backwa
             loss.backward()
             grads[on] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
         finally:
-            train.FUSED_AGG_BWD = True
+            setattr(train, switch, True)
     assert grads[True][0] == grads[False][0]
     num = sum(((grads[True][1][k] - grads[False][1][k]).double() ** 2).sum().item() for k in grads[True][1]) ** 0.5
     den = sum((grads[False][1][k].double() ** 2).sum().item() for k in grads[False][1]) ** 0.5

@@ -77,13 +77,24 @@ def fused(de):
     return ops.agg_bwd_fused(ee, Tf, Uf, Tb, Ub, A2, A3, views, de, xe, sc, sh, mn, n)
 
 
+def fused_variant(v):
+    def run_(de):
+        ops.set_tuning(KEY, v)
+        try:
+            return fused(de)
+        finally:
+            ops.set_tuning(KEY, 0)
+    return run_
+
+
 a, b = pair(de0.clone()), fused(de0.clone())
 torch.cuda.synchronize()
 print(json.dumps({"fused_vs_pair": {k: rel(y.clone(), x.clone()) for k, x, y in zip(("sum_in", "sum_out", "de", "s1", "s2"), a, b)},
                   "fused_same_bits_twice": all(torch.equal(u, v) for u, v in zip(fused(de0.clone()), b))}))
-times = {"pair_ms": [], "fused_ms": []}
+cases = (("pair_ms", pair), ("fused_ms", fused), ("fused_out5_ms", fused_variant(81)), ("fused_in3_3waves_ms", fused_variant(82)))
+times = {name: [] for name, _ in cases}
 for rep in range(40):
-    for name, fn in (("pair_ms", pair), ("fused_ms", fused)):
+    for name, fn in cases:
         s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn(scratch)
