@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgnnome_hip.so")
+# GNNOME_HIP_LIB: another build of the SAME library (same ABI) for A/B measurements of two builds on one box - never a fallback
+LIB_PATH = os.environ.get("GNNOME_HIP_LIB") or os.path.join(_HERE, "lib", "libgnnome_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gnnome_hip.h")
 
 _p = ctypes.c_void_p

@@ -173,11 +173,15 @@ __global__ __launch_bounds__(kThreads) void k_edge_loss(const float* __restrict_
     }
 }
 
+// one wave: lane l adds partials l, l + 64, ... and the 64 lane sums are folded by a butterfly - a fixed order (one thread walking the
+// list alone took 65 us of dependent loads per training step)
 __global__ void k_finish_loss(const double* __restrict__ partial, int blocks, int64_t E, float* __restrict__ loss) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += partial[b];
-    loss[0] = (float)(s / (double)E);
+    for (int b = threadIdx.x; b < blocks; b += 64) s += partial[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) loss[0] = (float)(s / (double)E);
 }
 
 int grid_for(int64_t rows) {

@@ -78,7 +78,8 @@ void hub_cache_invalidate() {
 }
 
 // (called with g_hub_guard held)
-static HubScratch* hub_scratch(hipStream_t s, bool* capturing_unallocated) {
+static HubScratch* hub_scratch(hipStream_t s, bool* capturing_unallocated, const void* in_ptr = nullptr, const void* out_ptr = nullptr,
+                               int64_t n = -1) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     auto it = g_hub_table.find(std::make_pair(dev, s));
@@ -87,6 +88,15 @@ static HubScratch* hub_scratch(hipStream_t s, bool* capturing_unallocated) {
         if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
             // a capture runs on a stream of its own and must not allocate: it records against the scratch the eager warm-up on this device
             // left (the recording then shares it with that stream - replays of graphs WITH hubs must not overlap eager aggregations there)
+            // ... preferably the one that knows THIS graph (round 5: taking the first one found - often the default stream's, keyed to another
+            // graph - recorded k_find_hubs and the two hub launches of every aggregation into the training step's hipGraph: 25 launches that
+            // find nothing on a graph the warm-up had already found hub-free)
+            for (auto& kv : g_hub_table) {
+                const HubScratch& h = kv.second;
+                if (kv.first.first == dev && h.partials != nullptr && h.key_n == n &&
+                    ((h.key_in == in_ptr && h.key_out == out_ptr) || (h.key_in == out_ptr && h.key_out == in_ptr)))
+                    return &kv.second;
+            }
             for (auto& kv : g_hub_table)
                 if (kv.first.first == dev && kv.second.partials != nullptr) return &kv.second;
             *capturing_unallocated = true;
@@ -585,7 +595,7 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
     // the hub path (see the header comment): find the long lists, reduce them chunk-wise, let the node's wave add the chunks
     bool capturing_unallocated = false;
     std::lock_guard<std::mutex> hub_lock(g_hub_guard);   // the scratch's host-side state is read and written below, up to the launches
-    HubScratch* hub = tuning(kTuneAggHubs) == 1 ? nullptr : hub_scratch(s, &capturing_unallocated);
+    HubScratch* hub = tuning(kTuneAggHubs) == 1 ? nullptr : hub_scratch(s, &capturing_unallocated, in_ptr, out_ptr, n_out);
     GN_REQUIRE(!capturing_unallocated, "node_aggregate: first call on this device inside a stream capture - run one eager call first "
                                        "(the hub scratch is allocated on first use)");
     // the hub list is a function of in-degree + out-degree: the same for a graph and its reversed views (in_ptr / out_ptr swapped)
