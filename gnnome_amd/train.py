@@ -136,8 +136,13 @@ def _bn_bwd(sh, dy, x, scale, shift, mean, rstd, rows, n_once, out, stats=None, 
 
 
 ACTIVATION_STORAGE = ("fp32", "bf16")
-FUSED_NODE_TABLES = True   # bn_h's backward apply + the four node tables of the aggregation's backward as one launch (gnnome_bn_bwd_apply_tables_f32)
-FUSED_AGG_BWD = True   # the aggregation's node sums and per-edge backward as one launch (gnnome_agg_bwd_fused_f32; tools/train_ab.py switches it)
+def _switch(name):   # GNNOME_<NAME>=0 in the environment turns a switch off for a whole process (bench.py A/B runs of one build)
+    import os
+    return os.environ.get("GNNOME_" + name, "1") != "0"
+
+
+FUSED_NODE_TABLES = _switch("FUSED_NODE_TABLES")   # bn_h's backward apply + the four node tables of the aggregation's backward as one launch (gnnome_bn_bwd_apply_tables_f32)
+FUSED_AGG_BWD = _switch("FUSED_AGG_BWD")   # the aggregation's node sums and per-edge backward as one launch (gnnome_agg_bwd_fused_f32; tools/train_ab.py switches it)
 TWO_PASS_GATE = True   # the single-rank BatchNorm forward at hidden 128 as statistics pass + fused gate (tools/train_ab.py switches it for A/B runs)
 
 
