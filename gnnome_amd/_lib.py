@@ -61,6 +61,7 @@ SIGNATURES = {
     "gnnome_segment_sum2_x16": [_p, _i, _p, _p, _p, _l, _p, _i, _p, _i, _p],
     "gnnome_wgrad_workspace_bytes": [_l, _i, _i, ctypes.POINTER(_sz)],
     "gnnome_wgrad_f32": [_p, _i, _i, _p, _i, _i, _l, _p, _i, _p, _sz, _p],
+    "gnnome_wgrad_scaled_f32": [_p, _i, _i, _p, _i, _i, _l, _p, _p, _i, _p, _sz, _p],
     "gnnome_wgrad_x16": [_p, _i, _i, _p, _i, _i, _l, _p, _i, _p, _sz, _p],
     "gnnome_wgrad_blocks_f32": [_p, _i, _i, _i, _p, _i, _i, _l, _p, _i, _p, _p, _sz, _p],
     "gnnome_linear_blocks_f32": [_p, _i, _i, _l, _i, _p, _i, _i, _p, _i, _i, _p],
@@ -73,6 +74,7 @@ SIGNATURES = {
     "gnnome_degree_features_f32": [_p, _p, _l, _i, _p, _p, _sz, _p],
     "gnnome_edge_features_f32": [_p, _p, _l, _p, _p, _sz, _p],
     "gnnome_bn_bwd_dgrad_f32": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "gnnome_bn_bwd_dgrad_amax_f32": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
     "gnnome_bn_bwd_dgrad_out_f32": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_bn_bwd_dgrad_x16": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_bn_bwd_dgrad_out_x16": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
@@ -96,7 +98,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

@@ -32,6 +32,7 @@ struct GateBnBwd {
     const float *a, *c1, *c2, *mean, *rstd, *scale, *shift;   // [H] each
     float* a_out;                                              // [E,H]
     int64_t n_once;   // rows [0, n_once) get the mean-subtraction terms c1, c2; the rest (replicas of rows another rank owns) do not
+    unsigned* amax_bits = nullptr;   // NULL or: max |a_out| as the bits of a non-negative float, raised with atomicMax (zeroed by the launcher)
 };
 
 // Arguments of the bf16x6 edge-tile kernel (edge_gate_bf.hip); mode 0 gate, 1 raw gate + statistics, 2 C += A W^T, 3 see GateBnBwd.

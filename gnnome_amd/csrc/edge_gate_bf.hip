@@ -695,6 +695,7 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
         const float* Xs = reinterpret_cast<const float*>(S);
         long long t_top = 0, t_split = 0, t_done = 0, t_epi = 0, t0 = 0, t1 = 0;
         f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1;   // MODE 1: this lane's running shifted sums of its four columns
+        float amax3 = 0.f;                             // MODE 3: max |dxe| over this lane's elements
         for (int r = group; r < n; r += RING) {
             const unsigned use = (unsigned)(r / RING) + 1u;
             if (a.prof) { t0 = __builtin_readcyclecounter(); asm volatile("" ::"v"(av[0][0]), "v"(g1[NP - 1][0])); t1 = __builtin_readcyclecounter(); t_top += t1 - t0; t0 = t1; }
@@ -720,7 +721,10 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                         t[j] = ka[j] * (gm - on * (k1[j] + (av[p][j] - km[j]) * kr[j] * k2[j]));
                     }
                     av[p] = t;
-                    if (r0 + p * RSTEP < valid3) store4_as<X16>(a.bnb.a_out, base3 + (off_row + (unsigned)(p * RSTEP * H)), t);
+                    if (r0 + p * RSTEP < valid3) {
+                        store4_as<X16>(a.bnb.a_out, base3 + (off_row + (unsigned)(p * RSTEP * H)), t);
+                        amax3 = fmaxf(fmaxf(amax3, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
+                    }
                 }
             }
 #pragma unroll
@@ -809,6 +813,14 @@ __global__ __launch_bounds__(768) void k_edge_gate_pl(GateBfArgs a) {
                 issue_late(r + RING);
                 if (ENC) encode_pending();
             }
+        }
+        if (MODE == 3 && a.bnb.amax_bits != nullptr) {
+            // max |dxe| for the consumer that scales dxe into fp16's range (gnnome_wgrad_scaled_f32): one atomicMax per load wave on the bits
+            // of a non-negative float - a maximum does not depend on the order it is formed in.  (A NaN row fails every comparison here and
+            // is caught by its own products downstream.)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) amax3 = fmaxf(amax3, __shfl_xor(amax3, o));
+            if (lane == 0) atomicMax(a.bnb.amax_bits, __float_as_uint(amax3));
         }
         if (MODE == 1) {
             // lanes l and l + 32 hold different rows of the same four columns: fold them, then every load wave leaves one row of
@@ -1154,7 +1166,7 @@ extern "C" int gnnome_debug_gate_profile(void* counters) {
 // gnnome_linear_acc_f32 in ONE pass over the [E,H] tensors (the A tile never comes from HBM: the load waves compute it).
 static int bn_bwd_dgrad_impl(float* C, const void* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift,
                              const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
-                             const float* W, int ldw, void* dxe, void* stream, bool x16) {
+                             const float* W, int ldw, void* dxe, void* stream, bool x16, unsigned* amax_bits = nullptr) {
     using namespace gnnome;
     GN_REQUIRE(rows >= 0 && (hidden == 64 || hidden == 128), "bn_bwd_dgrad: hidden=%d not in {64,128}", hidden);
     GN_REQUIRE(rows_once >= 0 && rows_once <= rows, "bn_bwd_dgrad: rows_once=%lld outside [0, rows]", (long long)rows_once);
@@ -1166,6 +1178,11 @@ static int bn_bwd_dgrad_impl(float* C, const void* X, int64_t rows, int64_t rows
     GateBfArgs g = {};
     g.e_in = (const float*)X; g.e_out = C; g.E = rows; g.B1h = C; g.ldn = hidden; g.W3 = W; g.ldw = ldw;
     g.bnb = GateBnBwd{a, c1, c2, mean, rstd, scale, shift, (float*)dxe, rows_once};
+    if (amax_bits != nullptr) {
+        GN_REQUIRE(hidden == 128 && tuning(kTuneGateVariant) != 8, "bn_bwd_dgrad_amax: hidden = 128 on the plane-form kernel only");
+        GN_HIP(hipMemsetAsync(amax_bits, 0, sizeof(unsigned), (hipStream_t)stream));
+        g.bnb.amax_bits = amax_bits;
+    }
     return gate_bf_launch(hidden, 3, false, g, (hipStream_t)stream, x16);
 }
 
@@ -1173,6 +1190,14 @@ extern "C" int gnnome_bn_bwd_dgrad_f32(float* C, const float* X, int64_t rows, i
                                        const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
                                        const float* W, int ldw, float* dxe, void* stream) {
     return bn_bwd_dgrad_impl(C, X, rows, rows_once, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, false);
+}
+
+// ... and max |dxe| left at amax_bits (the bits of a non-negative float) for gnnome_wgrad_scaled_f32
+extern "C" int gnnome_bn_bwd_dgrad_amax_f32(float* C, const float* X, int64_t rows, int64_t rows_once, int hidden, const float* scale,
+                                            const float* shift, const float* a, const float* c1, const float* c2, const float* mean,
+                                            const float* rstd, const float* W, int ldw, float* dxe, unsigned* amax_bits, void* stream) {
+    GN_REQUIRE(amax_bits != nullptr, "bn_bwd_dgrad_amax: null amax_bits");
+    return bn_bwd_dgrad_impl(C, X, rows, rows_once, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, false, amax_bits);
 }
 
 extern "C" int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift,

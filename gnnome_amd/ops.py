@@ -814,9 +814,10 @@ def segment_sum2(X, views, num_nodes, out_in=None, out_out=None):
     return out_in, out_out
 
 
-def wgrad(A, B, out=None):
+def wgrad(A, B, out=None, amax=None):
     """out[Ka,Kb] = A^T @ B over the rows (nn.Linear weight gradient dW = dY^T X).  A may be a contiguous bfloat16 tensor
-    (the dxe rows of the bf16-storage training step)."""
+    (the dxe rows of the bf16-storage training step).  amax: a one-element int32 device tensor holding the bits of max |A| (what
+    bn_bwd_dgrad(..., amax=) leaves) - the product then runs as fp16x3 with A scaled into fp16's range (gnnome_wgrad_scaled_f32)."""
     x16 = A.dtype == torch.bfloat16
     A, lda = (_act(A, "wgrad.A")[0], A.shape[1]) if x16 else _rows(A, "wgrad.A")
     B, ldb = _rows(B, "wgrad.B")
@@ -827,6 +828,11 @@ def wgrad(A, B, out=None):
     need = ctypes.c_size_t(0)
     _lib.check(_lib.load().gnnome_wgrad_workspace_bytes(rows, Ka, Kb, ctypes.byref(need)), "wgrad_workspace_bytes")
     ws = torch.empty(max(int(need.value), 4), dtype=torch.uint8, device=A.device)
+    if amax is not None and not x16 and rows > 0:
+        if amax.dtype != torch.int32 or amax.numel() != 1 or amax.device != A.device:
+            raise ValueError("wgrad.amax: a one-element int32 tensor on A's device (the bits of max |A|)")
+        _call("gnnome_wgrad_scaled_f32", A.device, _ptr(A), lda, Ka, _ptr(B), ldb, Kb, rows, _ptr(amax), _ptr(out), ldc, _ptr(ws), ws.numel())
+        return out
     _call("gnnome_wgrad_x16" if x16 else "gnnome_wgrad_f32", A.device, _ptr(A), lda, Ka, _ptr(B), ldb, Kb, rows, _ptr(out), ldc, _ptr(ws),
           ws.numel())
     return out
@@ -901,7 +907,12 @@ def can_fuse_bn_bwd_dgrad(de, W, xe=None):
     return de.shape[1] in (64, 128, 256) and de.shape[0] > 0 and de.is_contiguous() and W.stride(0) % 4 == 0
 
 
-def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None):
+def can_dgrad_amax(de, xe):
+    """bn_bwd_dgrad can leave max |dxe| (amax=): hidden = 128, fp32 storage, the plane-form kernel."""
+    return de.shape[1] == 128 and de.shape[0] > 0 and xe.dtype == torch.float32 and _TUNING.get(0, 0) != 8
+
+
+def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None, amax=None):
     """dxe = BatchNorm-backward(de, xe) (as bn_bwd_apply) and de += dxe @ Wt.T in ONE pass (gnnome_bn_bwd_dgrad_f32): the
     edge-tile kernel's load waves compute the A tile instead of reading it.  Returns dxe; de is updated in place.
     rows_once: the mean terms c1, c2 enter the first rows_once rows only (a partition's owned in-edges); default all rows."""
@@ -919,6 +930,12 @@ def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None
             de.copy_(out)
         else:
             de.set_(out)
+        return dxe
+    if amax is not None:   # (a one-element int32 tensor: the bits of max |dxe| as a non-negative float, for wgrad(dxe, ., amax=))
+        if not can_dgrad_amax(de, xe) or amax.dtype != torch.int32 or amax.numel() != 1 or amax.device != de.device:
+            raise ValueError("bn_bwd_dgrad.amax: needs hidden = 128, fp32 storage and a one-element int32 tensor on the same device")
+        _call("gnnome_bn_bwd_dgrad_amax_f32", de.device, _ptr(de), _ptr(xe), de.shape[0], once, de.shape[1], _ptr(scale), _ptr(shift),
+              _ptr(a), _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe), _ptr(amax))
         return dxe
     _call("gnnome_bn_bwd_dgrad_x16" if x16 else "gnnome_bn_bwd_dgrad_f32", de.device, _ptr(de), _ptr(xe), de.shape[0], once, de.shape[1], _ptr(scale), _ptr(shift),
           _ptr(a), _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))

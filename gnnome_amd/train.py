@@ -141,6 +141,7 @@ def _switch(name):   # GNNOME_<NAME>=0 in the environment turns a switch off for
     return os.environ.get("GNNOME_" + name, "1") != "0"
 
 
+SCALED_WGRAD = _switch("SCALED_WGRAD")   # B_3's weight gradient as fp16x3 on dxe scaled by its maximum (gnnome_wgrad_scaled_f32) instead of bf16x6
 FUSED_NODE_TABLES = _switch("FUSED_NODE_TABLES")   # bn_h's backward apply + the four node tables of the aggregation's backward as one launch (gnnome_bn_bwd_apply_tables_f32)
 FUSED_AGG_BWD = _switch("FUSED_AGG_BWD")   # the aggregation's node sums and per-edge backward as one launch (gnnome_agg_bwd_fused_f32; tools/train_ab.py switches it)
 TWO_PASS_GATE = True   # the single-rank BatchNorm forward at hidden 128 as statistics pass + fused gate (tools/train_ab.py switches it for A/B runs)
@@ -379,6 +380,7 @@ class _TrainStep(torch.autograd.Function):
                 _, layer_norm_, storage_ = s["gate_path"]
                 _, s["xe"], _ = _raw_gate(sh, conv, s["e"], blk(s["P"], "B1"), blk(s["P"], "B2"), layer_norm_, storage_, path=s["gate_path"][0])
             stats_e = None
+            amax_dxe = None
             fused = s["sc_e"] is not None and FUSED_AGG_BWD and hasattr(ops, "agg_bwd_fused")
             if fused:
                 # the node sums (dA3 / dA2 by role), de += ... and bn_e's backward statistics in ONE pass over the e' rows
@@ -406,7 +408,11 @@ class _TrainStep(torch.autograd.Function):
                     # BatchNorm backward and d e_in = d e' + dxe W3 in one pass over the edges (dxe computed by the load waves)
                     g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"], c1, c2 = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
                                                                                    sh.e_global, e_own, None, stats=stats_e, apply=False)
-                    dxe = ops.bn_bwd_dgrad(de, s["xe"], s["sc_e"], s["sh_e"], s["sc_e"], c1, c2, s["mean_e"], s["rstd_e"], W3t, rows_once=e_own)
+                    if SCALED_WGRAD and hasattr(ops, "can_dgrad_amax") and ops.can_dgrad_amax(de, s["xe"]):
+                        # the kernel that writes dxe also leaves max |dxe|: B_3's weight gradient below then runs as fp16x3 on the scaled rows
+                        amax_dxe = torch.empty(1, dtype=torch.int32, device=dev)
+                    dxe = ops.bn_bwd_dgrad(de, s["xe"], s["sc_e"], s["sh_e"], s["sc_e"], c1, c2, s["mean_e"], s["rstd_e"], W3t, rows_once=e_own,
+                                           **({"amax": amax_dxe} if amax_dxe is not None else {}))
                     W3t = None
                 elif s["xe"].dtype != torch.float32:
                     raise _no_bf16_storage()
@@ -414,7 +420,7 @@ class _TrainStep(torch.autograd.Function):
                     dxe = torch.empty_like(de)
                     g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
                                                                            sh.e_global, e_own, dxe, stats=stats_e)
-            g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"])
+            g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"], amax=amax_dxe) if amax_dxe is not None else ops.wgrad(dxe, s["e"])
             if s["sc_e"] is None or W3t is not None:
                 ops.linear(dxe, s["W3T"] if s["W3T"] is not None else d(conv.B_3.weight).t().contiguous(), None, out=de,
                            accumulate=True)   # d e_in = d e' + dxe W3

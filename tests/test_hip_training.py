@@ -593,7 +593,57 @@ def test_bn_backward_with_node_tables_equals_the_three_launches(rows, hidden):
             ops.bn_bwd_apply_tables(dy, x, scale, shift, a, c1, c2, mean, rstd, rdf[:-1], hf, rdb, hb)
 
 
-@pytest.mark.parametrize("switch", ["FUSED_AGG_BWD", "FUSED_NODE_TABLES"])
+def _bits(x):
+    return x.abs().max().reshape(1).float().view(torch.int32)
+
+
+@pytest.mark.parametrize("rows,Ka,Kb,spread", [(50_001, 128, 128, 1e-3), (7000, 64, 128, 1e-9), (31, 128, 64, 1.0), (200_000, 128, 128, 1e-6),
+                                               (4097, 256, 128, 1e-4)])
+def test_scaled_weight_gradient_is_fp32_faithful(rows, Ka, Kb, spread):
+    """gnnome_wgrad_scaled_f32 (round 5): A^T B as fp16x3 with the GRADIENT operand scaled by the power of two its maximum asks for.  Against
+    the fp64 product: within 2e-7 of max sum |a||b| (bf16x6's own contract) for operands whose magnitudes span `spread` .. 1 times a tiny
+    overall scale; equal to the bf16x6 kernel to that tolerance; exact zeros for a zero gradient; overall scales from 1e-30 to 1e30."""
+    g = torch.Generator().manual_seed(rows + Ka)
+    mag = torch.exp(torch.rand(rows, 1, generator=g) * torch.log(torch.tensor(1.0 / spread))) * spread   # per-row magnitudes in [spread, 1]
+    A0 = (torch.randn(rows, Ka, generator=g) * mag).to(dev())
+    B = (30 * torch.randn(rows, Kb, generator=g)).to(dev())
+    for overall in (3e-5, 1e-30, 1e30, 1.0):
+        A = (A0 * overall).contiguous()
+        want = A.double().t() @ B.double()
+        bound = (A.double().abs().t() @ B.double().abs()).max().item()
+        got = ops.wgrad(A, B, amax=_bits(A))
+        plain = ops.wgrad(A, B)
+        assert torch.isfinite(got).all()
+        assert (got.double() - want).abs().max().item() <= 2e-7 * bound, overall
+        assert (got - plain).abs().max().item() <= 4e-7 * bound
+    z = torch.zeros_like(A0)
+    assert not ops.wgrad(z, B, amax=_bits(z)).any()
+    with pytest.raises(ValueError):
+        ops.wgrad(A0, B, amax=torch.zeros(2, dtype=torch.int32, device=dev()))
+
+
+def test_dgrad_leaves_the_maximum_of_dxe():
+    """gnnome_bn_bwd_dgrad_amax_f32: the same dxe and de as gnnome_bn_bwd_dgrad_f32, bit for bit, and amax = the bits of max |dxe| exactly
+    (atomicMax on the unsigned bits of non-negative floats), also when the last tile is ragged and when rows_once cuts a tile."""
+    g = torch.Generator().manual_seed(11)
+    H = 128
+    r = lambda *s: torch.randn(*s, generator=g).to(dev())  # noqa: E731
+    for e, once in ((50_001, None), (33, 20), (128, 0)):
+        de0, xe = 1e-3 * r(e, H), 3 * r(e, H)
+        scale, shift, a, c1, c2, mean, rstd = ((torch.rand(H, generator=g) + 0.5).to(dev()) if k in (0, 6) else r(H) for k in range(7))
+        Wt = (torch.randn(H, H, generator=g) / H ** 0.5).to(dev())
+        assert ops.can_dgrad_amax(de0, xe)
+        c_a, c_b = de0.clone(), de0.clone()
+        want = ops.bn_bwd_dgrad(c_a, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=once)
+        amax = torch.full((1,), 12345, dtype=torch.int32, device=dev())
+        got = ops.bn_bwd_dgrad(c_b, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=once, amax=amax)
+        assert torch.equal(got, want) and torch.equal(c_a, c_b)
+        assert amax.item() == _bits(want).item()
+    with pytest.raises(ValueError):
+        ops.bn_bwd_dgrad(de0.clone(), xe.to(torch.bfloat16), scale, shift, a, c1, c2, mean, rstd, Wt, amax=amax)
+
+
+@pytest.mark.parametrize("switch", ["FUSED_AGG_BWD", "FUSED_NODE_TABLES", "SCALED_WGRAD"])
 def test_training_step_is_the_same_with_and_without_the_fused_backward_launches(switch):
     """train.FUSED_AGG_BWD / train.FUSED_NODE_TABLES: the whole step (8 layers, H = 128, 40k edges) with the one launch and with the launches it
     replaces - loss equal, every gradient within fp32 reassociation."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Launch time of the weight-gradient product C[Ka,Kb] = A[R,Ka]^T B[R,Kb] (gnnome_wgrad_f32) with the kernel's measurement-only
-ablations (gnnome_set_tuning key 1: 1 = no re-fetch of slabs, 2 = no MFMAs, 4 = no staging, 5 = neither loads nor staging)."""
+ablations (gnnome_set_tuning key 1: 1 = no re-fetch of slabs, 2 = no MFMAs, 4 = no staging, 5 = neither loads nor staging, 8 = two slabs ahead, 16 = fp16x3 without a scale)."""
 import os
 import sys
 
@@ -19,6 +19,8 @@ A = torch.randn(rows, Ka, device=dev, generator=gen)
 B = torch.randn(rows, Kb, device=dev, generator=gen)
 out = torch.empty(Ka, Kb, device=dev)
 flops = 2.0 * rows * Ka * Kb * 6
+want = A.double().t() @ B.double()
+bound = (A.double().abs().t() @ B.double().abs()).max().item()
 for rnd in range(2):
     for abl in abls:
         ops.set_tuning(1, abl)
@@ -34,5 +36,7 @@ for rnd in range(2):
         torch.cuda.synchronize()
         ts = sorted(x.elapsed_time(y) for x, y in evs)
         med = ts[len(ts) // 2]
-        print(f"round {rnd} ablation {abl}: median {med:.4f} ms  {flops / med / 1e9:.0f} bf16 TF/s  {(rows * (Ka + Kb) * 4) / med / 1e9:.2f} TB/s", flush=True)
+        err = (out.double() - want).abs().max().item() / bound
+        print(f"round {rnd} ablation {abl}: median {med:.4f} ms  {flops / med / 1e9:.0f} bf16 TF/s  {(rows * (Ka + Kb) * 4) / med / 1e9:.2f} TB/s  "
+              f"max error / max sum|a||b| {err:.2e}", flush=True)
 ops.set_tuning(1, 0)
