@@ -691,7 +691,8 @@ static int raw_stats_impl(const float* e_in, void* x_out, int64_t num_edges, int
     GN_REQUIRE(e_in && x_out != (const void*)e_in && B1h && B2h && srt_src && srt_dst && W3 && center && stats_partial,
                "edge_gate_raw_stats: bad pointers");
     // x_out == NULL: the statistics alone (the first pass of the two-pass training forward; hidden = 128, the plane form)
-    GN_REQUIRE(x_out || (hidden == 128 && tuning(kTuneGateVariant) == 0), "edge_gate_raw_stats: x_out may be NULL at hidden = 128 only (default kernels)");
+    GN_REQUIRE(x_out || ((hidden == 128 || (hidden == 256 && tuning(kTuneArith) == 0 && !x16)) && tuning(kTuneGateVariant) == 0),
+               "edge_gate_raw_stats: x_out may be NULL at hidden = 128 and, as fp16x3 with fp32 storage, 256 (default kernels)");
     GN_REQUIRE(hidden == 64 || hidden == 128 || hidden == 256, "edge_gate_raw_stats: hidden=%d not in {64,128,256}", hidden);
     GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ldw >= hidden && ldw % 4 == 0, "edge_gate_raw_stats: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)W3 % 16 == 0) && ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0),
@@ -736,13 +737,15 @@ static int gate_bn_impl(const float* e_in, float* e_out, void* x_out, int64_t nu
     if (num_edges == 0) return GNNOME_OK;
     GN_REQUIRE(e_in && e_out && x_out && x_out != (const void*)e_in && x_out != (void*)e_out && B1h && B2h && srt_src && srt_dst && W3 && scale && shift,
                "edge_gate_bn: bad pointers");
-    GN_REQUIRE(hidden == 128 && tuning(kTuneGateVariant) == 0, "edge_gate_bn: built at hidden = 128 (default kernels), got %d", hidden);
+    GN_REQUIRE((hidden == 128 || (hidden == 256 && tuning(kTuneArith) == 0 && !x16)) && tuning(kTuneGateVariant) == 0,
+               "edge_gate_bn: built at hidden = 128 and, as fp16x3 with fp32 storage, 256 (default kernels), got %d", hidden);
     GN_REQUIRE(ld_node >= hidden && ld_node % 4 == 0 && ldw >= hidden && ldw % 4 == 0, "edge_gate_bn: bad strides");
     GN_REQUIRE(((uintptr_t)e_in % 16 == 0) && ((uintptr_t)e_out % 16 == 0) && ((uintptr_t)x_out % 16 == 0) && ((uintptr_t)W3 % 16 == 0) &&
                    ((uintptr_t)B1h % 16 == 0) && ((uintptr_t)B2h % 16 == 0), "edge_gate_bn: 16-byte alignment required");
     GateBfArgs a = {};
     a.e_in = e_in; a.e_out = e_out; a.E = num_edges; a.B1h = B1h; a.B2h = B2h; a.ldn = ld_node; a.srt_src = srt_src; a.srt_dst = srt_dst;
     a.W3 = W3; a.ldw = ldw; a.scale = scale; a.shift = shift; a.bnb.a_out = (float*)x_out;
+    if (hidden == 256) return gate_pl256_launch(0, a, (hipStream_t)stream, false);   // (edge_tile_f16.hip: the gate writes xe when bnb.a_out is set)
     return gate_bf_launch(hidden, 0, false, a, (hipStream_t)stream, x16, 1);
 }
 

@@ -436,16 +436,21 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
                     if (!((fr >> p) & 1u)) g2[S][p] = g2[S][p - 1];   // same destination as the row above: the same B2h row
             }
             float* out = a.e_out + ((int64_t)tile_of(i) * TM + rl) * ldo + colh + 4 * c4;
+            // round 5, the two-pass training forward at this width: the gate (mode 0) ALSO writes the pre-normalisation rows xe = x + G to
+            // a.bnb.a_out when that is set; the raw gate (mode 1) with a.e_out = NULL leaves its statistics alone (both wave-uniform tests)
+            float* xe_out = (GATE && a.bnb.a_out != nullptr) ? a.bnb.a_out + ((int64_t)tile_of(i) * TM + rl) * ldo + colh + 4 * c4 : nullptr;
+            const bool stats_only = MODE == 1 && a.e_out == nullptr;
             auto pieces = [&](auto full_tile) {
                 constexpr bool FULL = decltype(full_tile)::value;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    f32x4 y;
+                    f32x4 y, xg = {0.f, 0.f, 0.f, 0.f};
                     if (GATE) {
                         const f32x4 g = g1[S][p] + g2[S][p];
+                        xg = x[p] + g;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const float t = (x[p][k] + g[k]) * sc4[k] + sh4[k];
+                            const float t = xg[k] * sc4[k] + sh4[k];
                             // (t - t is 0 for a finite t and NaN otherwise: an operand beyond fp16's range must not come out of the relu as 0)
                             y[k] = (t - t == 0.f) ? fmaxf(t, 0.f) + ek[S][p][k] : __builtin_nanf("");
                         }
@@ -465,8 +470,11 @@ __global__ __launch_bounds__(512) void k_edge_tile_f16(GateBfArgs a) {
                             st1 += dlt;
                             st2 += dlt * dlt;
                         }
+                        if (GATE && xe_out != nullptr) __builtin_nontemporal_store(xg, reinterpret_cast<f32x4*>(xe_out + (int64_t)p * ldo));
                         if (PROBE & 16)
                             asm volatile("" ::"v"(y));
+                        else if (stats_only)
+                            ;
                         else if (X16)
                             *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.e_out) + ((int64_t)tile_of(i) * TM + rl + p) * ldo + colh + 4 * c4) = pk;
                         else if (GATE && !(PROBE & 128))   // nontemporal: the e' rows are not read again by this launch - the L2 is for the e rows the pair shares

@@ -615,7 +615,8 @@ def edge_gate_raw_moments(e, B1h, B2h, views, W3, storage=torch.float32):
 def can_two_pass_gate(e, B1h, B2h, storage=None):
     """The training forward's gate in two passes instead of three (round 4): statistics alone, then gate + xe out.  hidden = 128, the
     default kernels (gnnome_set_tuning key 0 untouched), 16-byte aligned row tables."""
-    return (e.shape[1] == 128 and e.shape[0] > 0 and e.is_contiguous() and B1h.stride(0) % 4 == 0 and B2h.stride(0) % 4 == 0 and
+    wide = e.shape[1] == 256 and storage in (None, torch.float32) and _TUNING.get(10, 0) == 0   # round 5: the fp16x3 kernel, fp32 storage
+    return ((e.shape[1] == 128 or wide) and e.shape[0] > 0 and e.is_contiguous() and B1h.stride(0) % 4 == 0 and B2h.stride(0) % 4 == 0 and
             B1h.data_ptr() % 16 == 0 and B2h.data_ptr() % 16 == 0 and _TUNING.get(0, 0) == 0)
 
 

@@ -144,7 +144,8 @@ def _switch(name):   # GNNOME_<NAME>=0 in the environment turns a switch off for
 SCALED_WGRAD = _switch("SCALED_WGRAD")   # B_3's weight gradient as fp16x3 on dxe scaled by its maximum (gnnome_wgrad_scaled_f32) instead of bf16x6
 FUSED_NODE_TABLES = _switch("FUSED_NODE_TABLES")   # bn_h's backward apply + the four node tables of the aggregation's backward as one launch (gnnome_bn_bwd_apply_tables_f32)
 FUSED_AGG_BWD = _switch("FUSED_AGG_BWD")   # the aggregation's node sums and per-edge backward as one launch (gnnome_agg_bwd_fused_f32; tools/train_ab.py switches it)
-TWO_PASS_GATE = True   # the single-rank BatchNorm forward at hidden 128 as statistics pass + fused gate (tools/train_ab.py switches it for A/B runs)
+TWO_PASS_GATE_WIDE = __import__("os").environ.get("GNNOME_TWO_PASS_GATE_WIDE", "0") == "1"   # ... also at hidden 256 (measured slower there)
+TWO_PASS_GATE = _switch("TWO_PASS_GATE")   # the single-rank BatchNorm forward at hidden 128 as statistics pass + fused gate (tools/train_ab.py switches it for A/B runs)
 
 
 def _storage_dtype(model):
@@ -239,8 +240,10 @@ class _TrainStep(torch.autograd.Function):
                 raise _no_bf16_storage()
             # (fp32 storage only - measured, tools/train_two_pass_ab.py: 24.90 against 25.28 ms per step; with bf16 storage the third pass moves half
             #  the bytes and the two forms are level, 24.2 against 24.1)
+            # (hidden = 256, round 5: the kernels exist - edge_tile_f16.hip - and measure 134.4 against 132.9 ms per step at the 2.5M-edge shard: the
+            #  product formed twice costs more than the pass it saves at that width; GNNOME_TWO_PASS_GATE_WIDE=1 selects it)
             two_pass = (TWO_PASS_GATE and not layer_norm and not recompute and storage == torch.float32 and _can_fuse_bn(sh, conv.bn_e) and hasattr(ops, "edge_gate_bn") and
-                        ops.can_two_pass_gate(e, blk(P, "B1"), blk(P, "B2"), storage))
+                        (H == 128 or TWO_PASS_GATE_WIDE) and ops.can_two_pass_gate(e, blk(P, "B1"), blk(P, "B2"), storage))
             if two_pass:
                 # round 4: statistics alone (nothing stored), then the gate with the statistics folded in, which also leaves xe for the
                 # backward - the [E,H] tensor is written once and not read back in the forward (2 GB per layer instead of 2.5 at configs[2])
