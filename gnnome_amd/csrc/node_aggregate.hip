@@ -203,7 +203,7 @@ __device__ __forceinline__ void accumulate_items(const float* __restrict__ e, co
 // and inside the in-loop all row loads go out first, then the neighbour indices are awaited and the table rows gathered.
 // NOBR: the accumulation of a dead item (past the end of its list: its loads were clamped to a live one) is masked arithmetically
 // instead of being branched around - every live item still adds the same values in the same order (a dead one adds +0): same bits.
-template <int H, int U = (H == 256 ? 8 : 4), bool NOBR = false>
+template <int H, int U = (H == 256 ? 8 : 4), bool NOBR = false, bool NTOUT = false>
 __device__ __forceinline__ void accumulate_items_split(const float* __restrict__ e, const float* __restrict__ A2h, const float* __restrict__ A3h,
                                                        int ldn, const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_pos,
                                                        const int32_t* __restrict__ out_dst, int ib, int din, int ob, int lo, int hi, int lane,
@@ -261,7 +261,10 @@ __device__ __forceinline__ void accumulate_items_split(const float* __restrict__
                 live[u] = item >= m_in && item < m;
                 const int it = live[u] ? item : m_in;   // (m_in < m here: a valid out-item)
                 const int p = __shfl(my_p, it), nn = __shfl(my_n, it);
-                x[u] = *reinterpret_cast<const f32x4*>(e + (int64_t)p * H + c);
+                // NTOUT (variant 14): the out-edge pass is an e' row's LAST use in this launch - read past the L2's replacement order, so that the
+                // rows the in-edge passes have just brought in (and whose out-edge use is still to come) stay
+                x[u] = NTOUT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e + (int64_t)p * H + c))
+                             : *reinterpret_cast<const f32x4*>(e + (int64_t)p * H + c);
                 a[u] = *reinterpret_cast<const f32x4*>(A3h + (int64_t)nn * ldn + c);
             }
 #pragma unroll
@@ -389,6 +392,8 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
         if (SPLIT == 2)   // MEASUREMENT ONLY (variant 7, wrong results): the out-edges alone - what the aggregation would cost if the in-edge half
                           // were done elsewhere (inside the gate's store waves); see DESIGN.md, round 3
             accumulate_items_split<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, 0, ob, 0, cnt - din, lane, group, c, nf, df, nb, db);
+        else if (SPLIT == 4)   // variant 14: nontemporal out-edge loads of e'
+            accumulate_items_split<H, U, false, true>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
         else if (SPLIT == 3)   // variant 8: the split loop without branches around dead items
             accumulate_items_split<H, U, true>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
         else if (SPLIT == 1)
@@ -672,6 +677,7 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
             case 6: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 0); break;   // the unsplit item loop (in-edge rows requested after the index wait)
             case 7: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 2); break;   // measurement only: out-edges alone
             case 8: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 3); break;   // no branches around dead items
+            case 14: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 4); break;  // nontemporal out-edge loads of e' 
             case 11:   // ... walked as contiguous chunks by persistent workgroups (4 per CU)
             case 12:   // ... with nontemporal e loads
             case 13:   // the same, 8 workgroups per CU
