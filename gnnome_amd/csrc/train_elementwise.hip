@@ -757,8 +757,6 @@ __global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(WPE)
     for (int64_t gi = g0; gi < g1; gi += gstep) {
         const int64_t node = gi * WAVES + wave;
         if (node >= n_nodes) continue;   // (no barrier inside the loop)
-        const bool live_node = true;
-        const int64_t nrow = node;
         const int ib = in_ptr[node], din = in_ptr[node + 1] - ib;
         const int ob = out_ptr[node], dout = out_ptr[node + 1] - ob;
         // the neighbour indices of the first 64 items of BOTH lists go out together, unconditionally (a lane past the end of a list repeats a
@@ -766,8 +764,8 @@ __global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(WPE)
         const int first_n = srt_src[min((int64_t)ib + min(lane, max(din - 1, 0)), last)];
         const int64_t oq = min((int64_t)ob + min(lane, max(dout - 1, 0)), last);
         const int first_op = out_pos[oq], first_on = out_dst[oq];
-        const f32x4 tf = *reinterpret_cast<const f32x4*>(Tf + nrow * H + c), uf = *reinterpret_cast<const f32x4*>(Uf + nrow * H + c);
-        const f32x4 a3 = *reinterpret_cast<const f32x4*>(A3h + nrow * ldn + c);
+        const f32x4 tf = *reinterpret_cast<const f32x4*>(Tf + node * H + c), uf = *reinterpret_cast<const f32x4*>(Uf + node * H + c);
+        const f32x4 a3 = *reinterpret_cast<const f32x4*>(A3h + node * ldn + c);
         f32x4 nf = {0.f, 0.f, 0.f, 0.f}, nb = nf;
         // ---- in-edges: rows ib .. ib + din of e', xe, de' (streamed), the tables at src (gathered)
         for (int base = 0; base < din; base += 64) {
@@ -848,7 +846,7 @@ __global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(WPE)
                 nb[k] += __shfl_xor(nb[k], mm);
             }
         }
-        if (group == 0 && live_node) {
+        if (group == 0) {
             *reinterpret_cast<f32x4*>(sum_in + node * H + c) = nf;
             *reinterpret_cast<f32x4*>(sum_out + node * H + c) = nb;
         }
@@ -917,19 +915,24 @@ static int agg_bwd_fused_impl(const float* e, int64_t num_nodes, int64_t num_edg
     const int64_t groups = (num_nodes + kEwThreads / 64 - 1) / (kEwThreads / 64);
     unsigned grid = (unsigned)std::min<int64_t>(groups, kColMaxBlocks);
     if (grid >= 2 * kXcds) grid = grid / kXcds * kXcds;
+    // Occupancy against requests per step, measured (tools/agg_edge_bwd_ab.py; profiles/r05_train_step_ab.txt): three waves per SIMD with
+    // 3 in-edge / 4 out-edge items per lane group and step beat four waves with 2 / 4 by 3-4 % at H <= 128 (0.529 against 0.548 ms), two waves
+    // with 5 / 5 by 6.5 % at H = 256 (0.524 against 0.561); 4 / 4 at three waves spills (0.677).  The grid is cut to the resident waves.
+    const int wpe = hidden == 256 ? 2 : 3;
+    if (tuning(kTuneGateExperiment) != 88) grid = std::max(1u, grid / 4 * wpe / kXcds * kXcds);
 #define GN_ABF(HH, XX)                                                                                                               \
     do {                                                                                                                             \
-        if (tuning(kTuneGateExperiment) == 81)   /* A/B: five out-edge items per lane group and step */                              \
-            hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX, 2, 5>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, A2h, \
-                               A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out,    \
+        if (tuning(kTuneGateExperiment) == 88)   /* A/B: four waves per SIMD, 2 / 4 items (the first form) */                        \
+            hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX, 2, 4, 4>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, \
+                               A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out, \
                                (float*)workspace);                                                                                   \
-        else if (tuning(kTuneGateExperiment) == 82)   /* A/B: three in-edge items per step, three waves per SIMD */                 \
-            hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX, 3, 4, 3>), dim3(grid / 4 * 3), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, \
-                               Ub, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in,    \
-                               sum_out, (float*)workspace);                                                                          \
+        else if (HH == 256)                                                                                                          \
+            hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX, 5, 5, 2>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, \
+                               A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out, \
+                               (float*)workspace);                                                                                   \
         else                                                                                                                         \
-            hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, A2h, A3h, \
-                               ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out,         \
+            hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX, 3, 4, 3>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, \
+                               A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out, \
                                (float*)workspace);                                                                                   \
     } while (0)
     switch (hidden) {
@@ -940,7 +943,6 @@ static int agg_bwd_fused_impl(const float* e, int64_t num_nodes, int64_t num_edg
     }
 #undef GN_ABF
     GN_LAUNCH_CHECK();
-    if (tuning(kTuneGateExperiment) == 82) grid = grid / 4 * 3;
     hipLaunchKernelGGL(k_col_finish, dim3(2 * hidden / 4), dim3(256), 0, s, (const float*)workspace, (int)grid, hidden, s1, s2);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;

@@ -91,7 +91,7 @@ a, b = pair(de0.clone()), fused(de0.clone())
 torch.cuda.synchronize()
 print(json.dumps({"fused_vs_pair": {k: rel(y.clone(), x.clone()) for k, x, y in zip(("sum_in", "sum_out", "de", "s1", "s2"), a, b)},
                   "fused_same_bits_twice": all(torch.equal(u, v) for u, v in zip(fused(de0.clone()), b))}))
-cases = (("pair_ms", pair), ("fused_ms", fused), ("fused_out5_ms", fused_variant(81)), ("fused_in3_3waves_ms", fused_variant(82)))
+cases = (("pair_ms", pair), ("fused_ms", fused), ("fused_4_waves_2_4_items_ms", fused_variant(88)))
 times = {name: [] for name, _ in cases}
 for rep in range(40):
     for name, fn in cases:
