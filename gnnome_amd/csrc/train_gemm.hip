@@ -128,65 +128,20 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial(WgradA a_op, int lda, 
                 }
         }
     };
-    if (ABL & 8) {
-        // One slab in flight per workgroup (32 KB, two workgroups per CU) is 16 MB on the chip: at the 3-4 us a request takes under load that
-        // is the ~3.8 TB/s measured.  Here TWO slabs are in flight - slab s + 2 is requested while slab s is multiplied - in two register
-        // sets that take turns (the body handles a pair of slabs; a chunk with an odd count multiplies one slab of zeros at its end).
-        // Every request is unconditional (rows past the chunk's end repeat its last row and are zeroed when they are staged): hipcc's wait
-        // counts ignore loads behind a branch, and a `vmcnt(0)` at the top of the body would drain both sets.
-        const float* b_safe = b_in ? b_col : B;   // (a_col is inside A already when a_in is false)
-        auto request = [&](f32x4 (&av)[4], f32x4 (&bv)[4], int64_t r0) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int64_t row = min(r0 + 4 * rr + t, r_end - 1);
-                av[t] = X16 ? load4_as<true>(a_base16, a_off16 + row * lda) : *reinterpret_cast<const f32x4*>(a_col + row * lda);
-                bv[t] = *reinterpret_cast<const f32x4*>(b_safe + row * ldb);
-            }
-        };
-        auto zeroed = [&](f32x4 (&v)[4], int64_t r0, bool in) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (!in || r0 + 4 * rr + t >= r_end) v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        };
-        f32x4 av0[4], bv0[4], av1[4], bv1[4];
-        request(av0, bv0, r_begin);
-        __builtin_amdgcn_sched_barrier(0);   // in this order: the body's wait counts are the minimum over both ways into it
-        request(av1, bv1, r_begin + kWgRows);
-        __builtin_amdgcn_sched_barrier(0);
-        for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * kWgRows) {
-            zeroed(av0, r0, a_in);
-            zeroed(bv0, r0, b_in);
-            stage(Ap, av0);
-            stage(Bp, bv0);
-            if (sums) cs += (av0[0] + av0[1]) + (av0[2] + av0[3]);
-            __syncthreads();
-            request(av0, bv0, r0 + 2 * kWgRows);
-            products();
-            __syncthreads();
-            zeroed(av1, r0 + kWgRows, a_in);
-            zeroed(bv1, r0 + kWgRows, b_in);
-            stage(Ap, av1);
-            stage(Bp, bv1);
-            if (sums) cs += (av1[0] + av1[1]) + (av1[2] + av1[3]);
-            __syncthreads();
-            request(av1, bv1, r0 + 3 * kWgRows);
-            products();
-            __syncthreads();
+    // (Measured and dropped, round 5: a SECOND slab in flight per workgroup, two register sets taking turns - 0.27-0.32 against 0.25-0.28 ms; the
+    // kernel is balanced between matrix work and memory: 0.18 ms of MFMAs + fragment reads alone, 0.204 without re-fetching, 0.214 without MFMAs.)
+    f32x4 av[4], bv[4];
+    fetch(av, bv, r_begin);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
+        if (!(ABL & 4) || r0 == r_begin) {
+            stage(Ap, av);
+            stage(Bp, bv);
         }
-    } else {
-        f32x4 av[4], bv[4];
-        fetch(av, bv, r_begin);
-        for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgRows) {
-            if (!(ABL & 4) || r0 == r_begin) {
-                stage(Ap, av);
-                stage(Bp, bv);
-            }
-            if (sums) cs += (av[0] + av[1]) + (av[2] + av[3]);
-            __syncthreads();
-            if (r0 + kWgRows < r_end && !(ABL & 1)) fetch(av, bv, r0 + kWgRows);
-            products();
-            __syncthreads();
-        }
+        if (sums) cs += (av[0] + av[1]) + (av[2] + av[3]);
+        __syncthreads();
+        if (r0 + kWgRows < r_end && !(ABL & 1)) fetch(av, bv, r0 + kWgRows);
+        products();
+        __syncthreads();
     }
     float* out = partial + ((int64_t)blockIdx.z * Ka + i0) * Kb + j0;
 #pragma unroll
@@ -913,8 +868,6 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
         hipLaunchKernelGGL((k_wgrad_partial<false, 4>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
     else if (tuning(kTuneGateAblation) == 5)
         hipLaunchKernelGGL((k_wgrad_partial<false, 5>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
-    else if (tuning(kTuneGateAblation) == 8)
-        hipLaunchKernelGGL((k_wgrad_partial<false, 8>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
     else if (tuning(kTuneGateAblation) == 16)   // timing only: fp16x3 without a scale
         hipLaunchKernelGGL(k_wgrad_partial_h, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, (const unsigned*)nullptr, partial, colsum_part);
     else if (amax_bits != nullptr && a_op.width >= Ka && tuning(kTuneArith) != 1 && tuning(kTuneGateAblation) != 17)
