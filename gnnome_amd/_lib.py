@@ -50,7 +50,7 @@ SIGNATURES = {
     "gnnome_bn_relu_res_x16": [_p, _p, _p, _p, _l, _i, _p, _p],
     "gnnome_bn_bwd_stats_f32": [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _sz, _p],
     "gnnome_bn_bwd_apply_f32": [_p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
-    "gnnome_bn_bwd_apply_tables_f32": [_p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "gnnome_bn_bwd_apply_tables_f32": [_p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_ln_relu_res_f32": [_p, _p, _p, _p, _l, _i, _i, _p, _p],
     "gnnome_ln_bwd_f32": [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _sz, _p],
     "gnnome_mul23_f32": [_p, _p, _p, _l, _p, _p, _p],
@@ -58,12 +58,14 @@ SIGNATURES = {
     "gnnome_relu_bwd_f32": [_p, _p, _l, _p, _p],
     "gnnome_segment_sum_f32": [_p, _i, _p, _p, _l, _p, _i, _p],
     "gnnome_segment_sum2_f32": [_p, _i, _p, _p, _p, _l, _p, _i, _p, _i, _p],
+    "gnnome_segment_sum2_amax_f32": [_p, _i, _p, _p, _p, _l, _p, _i, _p, _i, _p, _p],
     "gnnome_segment_sum2_x16": [_p, _i, _p, _p, _p, _l, _p, _i, _p, _i, _p],
     "gnnome_wgrad_workspace_bytes": [_l, _i, _i, ctypes.POINTER(_sz)],
     "gnnome_wgrad_f32": [_p, _i, _i, _p, _i, _i, _l, _p, _i, _p, _sz, _p],
     "gnnome_wgrad_scaled_f32": [_p, _i, _i, _p, _i, _i, _l, _p, _p, _i, _p, _sz, _p],
     "gnnome_wgrad_x16": [_p, _i, _i, _p, _i, _i, _l, _p, _i, _p, _sz, _p],
     "gnnome_wgrad_blocks_f32": [_p, _i, _i, _i, _p, _i, _i, _l, _p, _i, _p, _p, _sz, _p],
+    "gnnome_wgrad_blocks_scaled_f32": [_p, _i, _i, _i, _p, _i, _i, _l, _p, _p, _i, _p, _p, _sz, _p],
     "gnnome_linear_blocks_f32": [_p, _i, _i, _l, _i, _p, _i, _i, _p, _i, _i, _p],
     "gnnome_score_tail_bwd_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_agg_edge_bwd_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
@@ -80,8 +82,8 @@ SIGNATURES = {
     "gnnome_bn_bwd_dgrad_out_x16": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_agg_edge_bwd_stats_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_agg_edge_bwd_stats_x16": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
-    "gnnome_agg_bwd_fused_f32": [_p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
-    "gnnome_agg_bwd_fused_x16": [_p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gnnome_agg_bwd_fused_f32": [_p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gnnome_agg_bwd_fused_x16": [_p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_bn_bwd_terms_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p],
     "gnnome_pack_layer_f32": [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p],
     "gnnome_bn_train_finish_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, ctypes.c_float, ctypes.c_float, _i, _p, _p, _p, _p, _p],
@@ -98,7 +100,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

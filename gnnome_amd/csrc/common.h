@@ -155,6 +155,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // aggregation kernels evaluate this E*H*2 times per layer
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// max |.| of a wave's values into amax_bits[0] (the bits of a non-negative float; unsigned order = float order): one atomicMax per wave, and
+// only when the value read first is smaller - a maximum does not depend on the order it is formed in, so results stay reproducible.
+__device__ __forceinline__ void wave_amax_to(unsigned* amax_bits, float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned b = __float_as_uint(v);
+        if (b > __hip_atomic_load(amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_bits, b);
+    }
+}
+
 // sum over the 32 lanes that share (lane >> 5)
 __device__ __forceinline__ float half_wave_sum(float v) {
     v += __shfl_xor(v, 1);

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(kEwThreads) void k_bn_bwd_apply_tables(const float*
                                                                     const float* __restrict__ rdf, const float* __restrict__ hf,
                                                                     const float* __restrict__ rdb, const float* __restrict__ hb,
                                                                     float* __restrict__ dx, float* __restrict__ Tf, float* __restrict__ Uf,
-                                                                    float* __restrict__ Tb, float* __restrict__ Ub) {
+                                                                    float* __restrict__ Tb, float* __restrict__ Ub, unsigned* __restrict__ amax_bits) {
+    float amax = 0.f;   // (of dx, for the consumers that scale it into fp16's range)
     const int64_t total = rows * (H / 4);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % (H / 4)) * 4;
@@ -180,12 +181,14 @@ __global__ __launch_bounds__(kEwThreads) void k_bn_bwd_apply_tables(const float*
             o[j] = a[c + j] * (g - c1[c + j] - (xv[j] - mean[c + j]) * rstd[c + j] * c2[c + j]);
         }
         const f32x4 t1 = o * r1, t2 = o * r2;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         *reinterpret_cast<f32x4*>(dx + off) = o;
         *reinterpret_cast<f32x4*>(Tf + off) = t1;
         *reinterpret_cast<f32x4*>(Uf + off) = t1 * h1;
         *reinterpret_cast<f32x4*>(Tb + off) = t2;
         *reinterpret_cast<f32x4*>(Ub + off) = t2 * h2;
     }
+    if (amax_bits != nullptr) wave_amax_to(amax_bits, amax);
 }
 
 // out = relu(x * scale + shift) + res
@@ -355,7 +358,7 @@ template <int W, bool X16>
 __global__ __launch_bounds__(256) void k_segment_sum2(const void* __restrict__ X, const int32_t* __restrict__ in_ptr,
                                                       const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos,
                                                       int64_t n_nodes, float* __restrict__ out_in, int ld_in, float* __restrict__ out_out,
-                                                      int ld_out, int total_blocks) {
+                                                      int ld_out, int total_blocks, unsigned* __restrict__ amax_bits) {
     constexpr int LPR = W / 4, G = 64 / LPR, U = 4;
     const int lane = threadIdx.x & 63;
     const int64_t node = (int64_t)xcd_remap(blockIdx.x, total_blocks) * 4 + (threadIdx.x >> 6);
@@ -397,6 +400,12 @@ __global__ __launch_bounds__(256) void k_segment_sum2(const void* __restrict__ X
     if (group == 0) {
         *reinterpret_cast<f32x4*>(out_in + node * ld_in + c) = acc[0];
         *reinterpret_cast<f32x4*>(out_out + node * ld_out + c) = acc[1];
+    }
+    if (amax_bits != nullptr) {   // max |.| of both outputs, for the consumers that scale them into fp16's range
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(acc[0][j]), fabsf(acc[1][j])));
+        wave_amax_to(amax_bits, amax);
     }
 }
 
@@ -476,13 +485,13 @@ extern "C" int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const fl
 extern "C" int gnnome_bn_bwd_apply_tables_f32(const float* dy, const float* x, const float* scale, const float* shift, int64_t rows,
                                               int hidden, const float* a, const float* c1, const float* c2, const float* mean,
                                               const float* rstd, const float* rdf, const float* hf, const float* rdb, const float* hb,
-                                              float* dx, float* Tf, float* Uf, float* Tb, float* Ub, void* stream) {
+                                              float* dx, float* Tf, float* Uf, float* Tb, float* Ub, unsigned* amax_bits, void* stream) {
     GN_REQUIRE(rows >= 0 && hidden > 0 && hidden % 4 == 0, "bn_bwd_apply_tables: bad shape");
     if (rows == 0) return GNNOME_OK;
     GN_REQUIRE(dy && x && scale && shift && a && c1 && c2 && mean && rstd && rdf && hf && rdb && hb && dx && Tf && Uf && Tb && Ub,
                "bn_bwd_apply_tables: null pointer");
     hipLaunchKernelGGL(k_bn_bwd_apply_tables, dim3(ew_grid(rows * (hidden / 4))), dim3(kEwThreads), 0, (hipStream_t)stream, dy, x, scale,
-                       shift, rows, hidden, a, c1, c2, mean, rstd, rdf, hf, rdb, hb, dx, Tf, Uf, Tb, Ub);
+                       shift, rows, hidden, a, c1, c2, mean, rstd, rdf, hf, rdb, hb, dx, Tf, Uf, Tb, Ub, amax_bits);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
@@ -727,8 +736,9 @@ __global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(WPE)
                                                               float* __restrict__ de, const void* __restrict__ xe,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ mean, float* __restrict__ sum_in,
-                                                              float* __restrict__ sum_out, float* __restrict__ part) {
+                                                              float* __restrict__ sum_out, float* __restrict__ part, unsigned* __restrict__ amax_bits) {
     constexpr int LPR = H / 4, G = 64 / LPR, WAVES = kEwThreads / 64;
+    float amax = 0.f;   // (of the node sums, for the consumers that scale them into fp16's range)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int group = lane / LPR, c = (lane % LPR) * 4;
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -850,7 +860,10 @@ __global__ __launch_bounds__(kEwThreads) __attribute__((amdgpu_waves_per_eu(WPE)
             *reinterpret_cast<f32x4*>(sum_in + node * H + c) = nf;
             *reinterpret_cast<f32x4*>(sum_out + node * H + c) = nb;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) amax = fmaxf(amax, fmaxf(fabsf(nf[k]), fabsf(nb[k])));
     }
+    if (amax_bits != nullptr) wave_amax_to(amax_bits, amax);
     column_fold<2>(acc, H, part);
 }
 }  // namespace gnnome
@@ -895,7 +908,7 @@ static int agg_bwd_fused_impl(const float* e, int64_t num_nodes, int64_t num_edg
                               const float* Ub, const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr, const int32_t* srt_src,
                               const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst, float* de, const void* xe, bool x16,
                               const float* scale, const float* shift, const float* mean, float* sum_in, float* sum_out, float* s1, float* s2,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              unsigned* amax_bits, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace gnnome;
     GN_REQUIRE(num_nodes >= 1 && num_edges >= 0, "agg_bwd_fused: needs at least one node");
     GN_REQUIRE(Tf && Uf && Tb && Ub && A2h && A3h && in_ptr && out_ptr && scale && shift && mean && sum_in && sum_out && s1 && s2 &&
@@ -925,15 +938,15 @@ static int agg_bwd_fused_impl(const float* e, int64_t num_nodes, int64_t num_edg
         if (tuning(kTuneGateExperiment) == 88)   /* A/B: four waves per SIMD, 2 / 4 items (the first form) */                        \
             hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX, 2, 4, 4>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, \
                                A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out, \
-                               (float*)workspace);                                                                                   \
+                               (float*)workspace, amax_bits);                                                                                   \
         else if (HH == 256)                                                                                                          \
             hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX, 5, 5, 2>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, \
                                A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out, \
-                               (float*)workspace);                                                                                   \
+                               (float*)workspace, amax_bits);                                                                                   \
         else                                                                                                                         \
             hipLaunchKernelGGL((k_agg_bwd_fused<HH, XX, 3, 4, 3>), dim3(grid), dim3(kEwThreads), 0, s, e, num_nodes, num_edges, Tf, Uf, Tb, Ub, \
                                A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de, xe, scale, shift, mean, sum_in, sum_out, \
-                               (float*)workspace);                                                                                   \
+                               (float*)workspace, amax_bits);                                                                                   \
     } while (0)
     switch (hidden) {
         case 64: if (x16) GN_ABF(64, true); else GN_ABF(64, false); break;
@@ -952,20 +965,20 @@ extern "C" int gnnome_agg_bwd_fused_f32(const float* e, int64_t num_nodes, int64
                                         const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
                                         const int32_t* in_ptr, const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
                                         const int32_t* out_dst, float* de, const float* xe, const float* scale, const float* shift,
-                                        const float* mean, float* sum_in, float* sum_out, float* s1, float* s2, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
+                                        const float* mean, float* sum_in, float* sum_out, float* s1, float* s2, unsigned* amax_bits,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
     return agg_bwd_fused_impl(e, num_nodes, num_edges, hidden, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de,
-                              xe, false, scale, shift, mean, sum_in, sum_out, s1, s2, workspace, workspace_bytes, stream);
+                              xe, false, scale, shift, mean, sum_in, sum_out, s1, s2, amax_bits, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gnnome_agg_bwd_fused_x16(const float* e, int64_t num_nodes, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
                                         const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node,
                                         const int32_t* in_ptr, const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
                                         const int32_t* out_dst, float* de, const uint16_t* xe, const float* scale, const float* shift,
-                                        const float* mean, float* sum_in, float* sum_out, float* s1, float* s2, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
+                                        const float* mean, float* sum_in, float* sum_out, float* s1, float* s2, unsigned* amax_bits,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
     return agg_bwd_fused_impl(e, num_nodes, num_edges, hidden, Tf, Uf, Tb, Ub, A2h, A3h, ld_node, in_ptr, srt_src, out_ptr, out_pos, out_dst, de,
-                              xe, true, scale, shift, mean, sum_in, sum_out, s1, s2, workspace, workspace_bytes, stream);
+                              xe, true, scale, shift, mean, sum_in, sum_out, s1, s2, amax_bits, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gnnome_agg_edge_bwd_stats_f32(const float* e, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
@@ -987,7 +1000,7 @@ extern "C" int gnnome_agg_edge_bwd_stats_x16(const float* e, int64_t num_edges, 
 }
 
 static int segment_sum2_impl(const void* X, bool x16, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
-                             int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream) {
+                             int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream, unsigned* amax_bits = nullptr) {
     using namespace gnnome;
     GN_REQUIRE(num_nodes >= 0, "segment_sum2: negative node count");
     if (num_nodes == 0) return GNNOME_OK;
@@ -997,7 +1010,7 @@ static int segment_sum2_impl(const void* X, bool x16, int width, const int32_t* 
     hipStream_t s = (hipStream_t)stream;
 #define GN_SS2(WW, XX)                                                                                                                    \
     hipLaunchKernelGGL((k_segment_sum2<WW, XX>), dim3(blocks), dim3(256), 0, s, X, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, \
-                       ld_out, (int)blocks)
+                       ld_out, (int)blocks, amax_bits)
     switch (width) {
         case 64: if (x16) GN_SS2(64, true); else GN_SS2(64, false); break;
         case 128: if (x16) GN_SS2(128, true); else GN_SS2(128, false); break;
@@ -1013,6 +1026,14 @@ static int segment_sum2_impl(const void* X, bool x16, int width, const int32_t* 
 extern "C" int gnnome_segment_sum2_f32(const float* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
                                        int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, void* stream) {
     return segment_sum2_impl(X, false, width, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, stream);
+}
+
+// ... raising amax_bits[0] (the bits of a non-negative float, NOT zeroed here: several producers share one slot) to max |out_in|, |out_out|
+extern "C" int gnnome_segment_sum2_amax_f32(const float* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
+                                            int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, unsigned* amax_bits,
+                                            void* stream) {
+    GN_REQUIRE(amax_bits != nullptr, "segment_sum2_amax: null amax_bits");
+    return segment_sum2_impl(X, false, width, in_ptr, out_ptr, out_pos, num_nodes, out_in, ld_in, out_out, ld_out, stream, amax_bits);
 }
 
 extern "C" int gnnome_segment_sum2_x16(const uint16_t* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,

@@ -226,12 +226,19 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial_h(WgradA a_op, int lda
 
     const int c4 = tid & 31, rr = tid >> 5;
     const bool a_in = i0 + 4 * c4 < Ka, b_in = j0 + 4 * c4 < Kb;
-    // ONE buffer of A (the launcher sends column-block operands to the bf16x6 kernel): both operands are addressed as a base that is the
+    // Both operands are addressed as a base that is the
     // same for the whole workgroup plus a 32-bit offset per lane (one register instead of a 64-bit pair per row - the kernel has
     // two accumulator sets and lives at the 256-register limit), and every request is unconditional: rows past the chunk's end repeat
     // its last row, columns past the operand its column 0, and both are zeroed when they are staged (the compiler cannot count loads
     // behind a branch and would wait for each as it is issued).
-    const float* a_base = a_op.blk[0] + (a_in ? i0 : 0);
+    const float* a_base = a_op.blk[0];
+    {   // column blocks in separate buffers: a tile lies inside ONE block (the launcher requires width % 128 == 0 then) - a uniform select
+        const int which = i0 / a_op.width;
+#pragma unroll
+        for (int k = 1; k < kWgBlocks; ++k)
+            if (which == k) a_base = a_op.blk[k];
+        a_base += i0 - which * a_op.width;
+    }
     const float* b_base = B + (b_in ? j0 : 0);
     const unsigned a_lane = (a_in ? 4u * c4 : 0u) + 4u * rr * (unsigned)lda, b_lane = (b_in ? 4u * c4 : 0u) + 4u * rr * (unsigned)ldb;
     const bool sums = colsum_part != nullptr && blockIdx.y == 0;
@@ -870,8 +877,9 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
         hipLaunchKernelGGL((k_wgrad_partial<false, 5>), grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
     else if (tuning(kTuneGateAblation) == 16)   // timing only: fp16x3 without a scale
         hipLaunchKernelGGL(k_wgrad_partial_h, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, (const unsigned*)nullptr, partial, colsum_part);
-    else if (amax_bits != nullptr && a_op.width >= Ka && tuning(kTuneArith) != 1 && tuning(kTuneGateAblation) != 17)
-        // fp16x3 with A scaled by the power of two that max |A| asks for (one buffer of A; gnnome_set_tuning(10, 1) or (1, 17): bf16x6)
+    else if (amax_bits != nullptr && (a_op.width >= Ka || a_op.width % kWgTile == 0) && tuning(kTuneArith) != 1 && tuning(kTuneGateAblation) != 17)
+        // fp16x3 with A scaled by the power of two that max |A| asks for (one buffer of A, or column blocks whose width is a whole number of
+        // tiles; gnnome_set_tuning(10, 1) or (1, 17): bf16x6)
         hipLaunchKernelGGL(k_wgrad_partial_h, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, amax_bits, partial, colsum_part);
     else
         hipLaunchKernelGGL(k_wgrad_partial<false>, grid, dim3(256), 0, s, a_op, lda, Ka, B, ldb, Kb, rows, rpc, partial, colsum_part);
@@ -927,6 +935,22 @@ extern "C" int gnnome_wgrad_blocks_f32(const float* const* A_blocks, int num_blo
     }
     a_op.width = block_width;
     return wgrad_impl(a_op, lda, num_blocks * block_width, B, ldb, Kb, rows, C, ldc, colsum, workspace, workspace_bytes, stream);
+}
+
+// gnnome_wgrad_blocks_f32 with max |A| over ALL blocks known on the device (one slot raised by the kernels that produced the blocks): fp16x3 with
+// that common scale where the 128 x 128 tile kernel runs and block_width is a multiple of 128; elsewhere amax_bits is ignored.
+extern "C" int gnnome_wgrad_blocks_scaled_f32(const float* const* A_blocks, int num_blocks, int block_width, int lda, const float* B, int ldb,
+                                              int Kb, int64_t rows, const unsigned* amax_bits, float* C, int ldc, float* colsum,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+    GN_REQUIRE(A_blocks && amax_bits && num_blocks >= 1 && num_blocks <= kWgBlocks && block_width > 0 && block_width % 4 == 0 && lda >= block_width,
+               "wgrad_blocks_scaled: 1..%d blocks of a width that is a multiple of 4, and the maximum's slot", kWgBlocks);
+    WgradA a_op = {};
+    for (int k = 0; k < num_blocks; ++k) {
+        GN_REQUIRE(rows == 0 || (A_blocks[k] && (uintptr_t)A_blocks[k] % 16 == 0), "wgrad_blocks_scaled: block %d null or not 16-byte aligned", k);
+        a_op.blk[k] = A_blocks[k];
+    }
+    a_op.width = block_width;
+    return wgrad_impl(a_op, lda, num_blocks * block_width, B, ldb, Kb, rows, C, ldc, colsum, workspace, workspace_bytes, stream, false, amax_bits);
 }
 
 extern "C" int gnnome_score_tail_bwd_f32(const float* z1, const float* dscore, const int32_t* srt_eid, int64_t num_edges,

@@ -735,7 +735,7 @@ def bn_bwd_apply(dy, x, scale, shift, a, c1, c2, mean, rstd, out=None):
     return dx
 
 
-def bn_bwd_apply_tables(dy, x, scale, shift, a, c1, c2, mean, rstd, rdf, hf, rdb, hb, out=None):
+def bn_bwd_apply_tables(dy, x, scale, shift, a, c1, c2, mean, rstd, rdf, hf, rdb, hb, out=None, amax=None):
     """bn_bwd_apply and the two mul23 calls that follow it for a layer's node BatchNorm, one launch: -> (dx, Tf, Uf, Tb, Ub) with
     Tf = dx*rdf, Uf = Tf*hf, Tb = dx*rdb, Ub = Tb*hb."""
     dx = torch.empty_like(x) if out is None else _dense(out, "bn_bwd_apply_tables.out")
@@ -747,7 +747,8 @@ def bn_bwd_apply_tables(dy, x, scale, shift, a, c1, c2, mean, rstd, rdf, hf, rdb
             raise ValueError(f"bn_bwd_apply_tables.{name}: shape {tuple(v.shape)} != {tuple(x.shape)}")
     _call("gnnome_bn_bwd_apply_tables_f32", x.device, _ptr(_dense(dy, "dy")), _ptr(_dense(x, "x")), _ptr(scale), _ptr(shift), x.shape[0],
           x.shape[1], _ptr(a), _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(_dense(rdf, "rdf")), _ptr(_dense(hf, "hf")),
-          _ptr(_dense(rdb, "rdb")), _ptr(_dense(hb, "hb")), _ptr(dx), _ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(t[3]))
+          _ptr(_dense(rdb, "rdb")), _ptr(_dense(hb, "hb")), _ptr(dx), _ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(t[3]),
+          _ptr(_amax_slot(amax, x.device, "bn_bwd_apply_tables")))   # amax: raised to max |dx|
     return dx, t[0], t[1], t[2], t[3]
 
 
@@ -800,7 +801,7 @@ def segment_sum(X, ptr, pos, num_nodes, out=None):
     return out
 
 
-def segment_sum2(X, views, num_nodes, out_in=None, out_out=None):
+def segment_sum2(X, views, num_nodes, out_in=None, out_out=None, amax=None):
     """(sum over in-edge rows, sum over out-edge rows) of X[E,W] per node, one launch; outputs may be column blocks of a
     wider table (row-strided)."""
     X, x16 = _act(X, "segment_sum2.X")
@@ -810,6 +811,10 @@ def segment_sum2(X, views, num_nodes, out_in=None, out_out=None):
     out_out = mk() if out_out is None else out_out
     out_in, ld_in = _rows(out_in, "segment_sum2.out_in")
     out_out, ld_out = _rows(out_out, "segment_sum2.out_out")
+    if amax is not None and not x16 and num_nodes > 0:   # (amax: raised to max |out_in|, |out_out|)
+        _call("gnnome_segment_sum2_amax_f32", X.device, _ptr(X), W, _ptr(views.in_ptr), _ptr(views.out_ptr), _ptr(views.out_pos), num_nodes,
+              _ptr(out_in), ld_in, _ptr(out_out), ld_out, _ptr(_amax_slot(amax, X.device, "segment_sum2")))
+        return out_in, out_out
     _call("gnnome_segment_sum2_x16" if x16 else "gnnome_segment_sum2_f32", X.device, _ptr(X), W, _ptr(views.in_ptr), _ptr(views.out_ptr), _ptr(views.out_pos), num_nodes,
           _ptr(out_in), ld_in, _ptr(out_out), ld_out)
     return out_in, out_out
@@ -852,9 +857,10 @@ def _block_table(blocks, name):
     return table, rows, width, lda
 
 
-def wgrad_blocks(blocks, B, colsum=True):
+def wgrad_blocks(blocks, B, colsum=True, amax=None):
     """(C, s): C[len(blocks)*width, Kb] = [blocks[0] | blocks[1] | ...]^T @ B without concatenating, and the column sums s of
-    the blocks (the bias gradients) from the same pass (None with colsum=False)."""
+    the blocks (the bias gradients) from the same pass (None with colsum=False).  amax: the slot the blocks' producers raised to the
+    largest |element| of all blocks (agg_bwd_fused / bn_bwd_apply_tables / segment_sum2 with amax=) - the product then runs as fp16x3."""
     table, rows, width, lda = _block_table(blocks, "wgrad_blocks.A")
     B, ldb = _rows(B, "wgrad_blocks.B")
     Ka, Kb, dev = len(blocks) * width, B.shape[1], B.device
@@ -863,6 +869,10 @@ def wgrad_blocks(blocks, B, colsum=True):
     need = ctypes.c_size_t(0)
     _lib.check(_lib.load().gnnome_wgrad_workspace_bytes(rows, Ka, Kb, ctypes.byref(need)), "wgrad_workspace_bytes")
     ws = torch.empty(max(int(need.value), 4), dtype=torch.uint8, device=dev)
+    if amax is not None and rows > 0 and width % 128 == 0:
+        _call("gnnome_wgrad_blocks_scaled_f32", dev, table, len(blocks), width, lda, _ptr(B), ldb, Kb, rows, _ptr(_amax_slot(amax, dev, "wgrad_blocks")),
+              _ptr(out), Kb, _ptr(sums), _ptr(ws), ws.numel())
+        return out, sums
     _call("gnnome_wgrad_blocks_f32", dev, table, len(blocks), width, lda, _ptr(B), ldb, Kb, rows, _ptr(out), Kb, _ptr(sums), _ptr(ws),
           ws.numel())
     return out, sums
@@ -958,7 +968,16 @@ def agg_edge_bwd_stats(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift,
     return de, s[0], s[1]
 
 
-def agg_bwd_fused(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift, mean, num_nodes):
+NODE_AMAX = True   # agg_bwd_fused / bn_bwd_apply_tables / segment_sum2 / wgrad_blocks take amax= (train.py asks before it builds the slot)
+
+
+def _amax_slot(amax, device, what):
+    if amax is not None and (amax.dtype != torch.int32 or amax.numel() != 1 or amax.device != device):
+        raise ValueError(f"{what}.amax: a one-element int32 tensor on the operands' device (the bits of a non-negative float)")
+    return amax
+
+
+def agg_bwd_fused(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift, mean, num_nodes, amax=None):
     """node_aggregate_raw(e, None, Tb, Tf, views, 2, num_nodes) and agg_edge_bwd_stats(...) in one launch (gnnome_agg_bwd_fused_f32: one
     read of e from HBM instead of two) -> (sum_in, sum_out, de, s1, s2); de is updated in place."""
     A2h, ldn = _rows(A2h, "agg_bwd_fused.A2h")
@@ -977,7 +996,7 @@ def agg_bwd_fused(e, Tf, Uf, Tb, Ub, A2h, A3h, views, de, xe, scale, shift, mean
     _call("gnnome_agg_bwd_fused_x16" if x16 else "gnnome_agg_bwd_fused_f32", dev, _ptr(_dense(e, "e")), num_nodes, e.shape[0], H, _ptr(Tf), _ptr(Uf),
           _ptr(Tb), _ptr(Ub), _ptr(A2h), _ptr(A3h), ldn, _ptr(views.in_ptr), _ptr(views.srt_src), _ptr(views.out_ptr), _ptr(views.out_pos),
           _ptr(views.out_dst), _ptr(_dense(de, "de")), _ptr(xe), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(sums[0]), _ptr(sums[1]), _ptr(s[0]),
-          _ptr(s[1]), _ptr(ws), ws.numel())
+          _ptr(s[1]), _ptr(_amax_slot(amax, dev, "agg_bwd_fused")), _ptr(ws), ws.numel())   # amax: RAISED to max |sum_in|, |sum_out| (never zeroed here)
     return sums[0], sums[1], de, s[0], s[1]
 
 

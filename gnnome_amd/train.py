@@ -141,6 +141,7 @@ def _switch(name):   # GNNOME_<NAME>=0 in the environment turns a switch off for
     return os.environ.get("GNNOME_" + name, "1") != "0"
 
 
+SCALED_NODE_WGRAD = _switch("SCALED_NODE_WGRAD")   # ... and the projection's [5H, H] weight gradient, on the five node gradients scaled by their common maximum
 SCALED_WGRAD = _switch("SCALED_WGRAD")   # B_3's weight gradient as fp16x3 on dxe scaled by its maximum (gnnome_wgrad_scaled_f32) instead of bf16x6
 FUSED_NODE_TABLES = _switch("FUSED_NODE_TABLES")   # bn_h's backward apply + the four node tables of the aggregation's backward as one launch (gnnome_bn_bwd_apply_tables_f32)
 FUSED_AGG_BWD = _switch("FUSED_AGG_BWD")   # the aggregation's node sums and per-edge backward as one launch (gnnome_agg_bwd_fused_f32; tools/train_ab.py switches it)
@@ -362,12 +363,19 @@ class _TrainStep(torch.autograd.Function):
                 _, g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = ops.ln_bwd(dh[:n_own], s["v"][:n_own], d(conv.bn_h.weight),
                                                                              d(conv.bn_h.bias), out=dv[:n_own], width=ln_width)
                 tables = None
+            amax_nodes = None   # one slot for max |.| over the five node gradients dv, sum_out, sum_in, dB1, dB2 (raised by the kernels that write them)
+            if s["sc_h"] is None:
+                pass
             elif n_local == n_own and FUSED_NODE_TABLES and hasattr(ops, "bn_bwd_apply_tables"):
+                if (SCALED_NODE_WGRAD and s["sc_e"] is not None and FUSED_AGG_BWD and hasattr(ops, "agg_bwd_fused") and getattr(ops, "NODE_AMAX", False)
+                        and H % 128 == 0 and s["xe"] is not None and s["xe"].dtype == torch.float32):
+                    amax_nodes = torch.zeros(1, dtype=torch.int32, device=dev)
+                kw = {"amax": amax_nodes} if amax_nodes is not None else {}
                 # bn_h's backward and the four node tables of the aggregation's backward (Tf, Uf, Tb, Ub) in one pass over the node rows
                 g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"], c1, c2 = _bn_bwd(sh, dh, s["v"], s["sc_h"], s["sh_h"], s["mean_h"], s["rstd_h"],
                                                                                sh.n_global, n_own, None, apply=False)
                 _, *tables = ops.bn_bwd_apply_tables(dh, s["v"], s["sc_h"], s["sh_h"], s["sc_h"], c1, c2, s["mean_h"], s["rstd_h"], s["rdf"],
-                                                     s["hf"], s["rdb"], s["hb"], out=dv)
+                                                     s["hf"], s["rdb"], s["hb"], out=dv, **kw)
             else:
                 g[pfx + "bn_h.weight"], g[pfx + "bn_h.bias"] = _bn_bwd(sh, dh[:n_own], s["v"][:n_own], s["sc_h"], s["sh_h"], s["mean_h"],
                                                                        s["rstd_h"], sh.n_global, n_own, dv[:n_own])
@@ -388,9 +396,11 @@ class _TrainStep(torch.autograd.Function):
             if fused:
                 # the node sums (dA3 / dA2 by role), de += ... and bn_e's backward statistics in ONE pass over the e' rows
                 sum_in, sum_out, _, s1_e, s2_e = ops.agg_bwd_fused(s["e_new"], Tf, Uf, Tb, Ub, blk(s["P"], "A2"), blk(s["P"], "A3"), views, de,
-                                                                   s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], n_local)
+                                                                   s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], n_local,
+                                                                   **({"amax": amax_nodes} if amax_nodes is not None else {}))
                 stats_e = (s1_e, s2_e)
             else:
+                amax_nodes = None   # (these sums come without their maximum)
                 sum_in, sum_out = ops.node_aggregate_raw(s["e_new"], None, Tb, Tf, views, 2, n_local)   # = dA3(role), dA2(role)
             if fused:
                 pass
@@ -428,8 +438,9 @@ class _TrainStep(torch.autograd.Function):
                 ops.linear(dxe, s["W3T"] if s["W3T"] is not None else d(conv.B_3.weight).t().contiguous(), None, out=de,
                            accumulate=True)   # d e_in = d e' + dxe W3
             if hasattr(ops, "segment_sum2"):   # both gathers' transposes in one launch (the out-edge pass then hits L2)
-                dB2, dB1 = ops.segment_sum2(dxe, views, n_local)
+                dB2, dB1 = ops.segment_sum2(dxe, views, n_local, **({"amax": amax_nodes} if amax_nodes is not None else {}))
             else:
+                amax_nodes = None
                 dB1 = ops.segment_sum(dxe, views.out_ptr, views.out_pos, n_local)
                 dB2 = ops.segment_sum(dxe, views.in_ptr, None, n_local)
             parts = [None] * 5
@@ -439,7 +450,8 @@ class _TrainStep(torch.autograd.Function):
             if hasattr(ops, "wgrad_blocks") and ops.can_use_blocks(parts):
                 # the five [N,H] gradients stay where their kernels left them: weight gradients, bias gradients (column sums of
                 # the same slabs) and dh += dP Wcat read them as column blocks
-                gWcat, gbcat = ops.wgrad_blocks(parts, s["h"])                # [5H, H], [5H]
+                # (amax_nodes: every block's producer raised it - the product runs as fp16x3 on the blocks scaled by their common maximum)
+                gWcat, gbcat = ops.wgrad_blocks(parts, s["h"], **({"amax": amax_nodes} if amax_nodes is not None else {}))   # [5H, H], [5H]
                 for k, name in enumerate(names):
                     g[pfx + name + ".bias"] = gbcat[k * H:(k + 1) * H]
                 dh = ops.linear_blocks(parts, WcatT, dh_in, accumulate=True)

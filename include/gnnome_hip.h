@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 13
+#define GNNOME_ABI_VERSION 14
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -337,7 +337,7 @@ int gnnome_bn_bwd_apply_f32(const float* dy, const float* x, const float* scale,
 int gnnome_bn_bwd_apply_tables_f32(const float* dy, const float* x, const float* scale, const float* shift, int64_t rows, int hidden,
                                    const float* a, const float* c1, const float* c2, const float* mean, const float* rstd,
                                    const float* rdf, const float* hf, const float* rdb, const float* hb, float* dx, float* Tf, float* Uf,
-                                   float* Tb, float* Ub, void* stream);
+                                   float* Tb, float* Ub, unsigned* amax_bits, void* stream);   /* amax_bits (NULL: skip): raised to max |dx| */
 
 /* LayerNorm variant (normalization='layer', gated_gcn_full.py:40-42,106,119,132) of the two groups above:
  *   out = relu(LN(x) * gamma + beta) + res, LN over the `hidden` entries of each row (biased variance, eps 1e-5);
@@ -379,6 +379,15 @@ int gnnome_wgrad_f32(const float* A, int lda, int Ka, const float* B, int ldb, i
  * (NaN otherwise, never a wrong finite value).  Operands that take the 256 x 256 kernel ignore amax_bits (bf16x6). */
 int gnnome_wgrad_scaled_f32(const float* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, const unsigned* amax_bits,
                             float* C, int ldc, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for the column-block form (gnnome_wgrad_blocks_f32) with ONE maximum over all blocks - the slot the blocks' producers raised
+ * (gnnome_bn_bwd_apply_tables_f32, gnnome_agg_bwd_fused_f32, gnnome_segment_sum2_amax_f32; the caller zeroes it once before them): fp16x3 with
+ * that common scale (block_width a multiple of 128); a block much smaller than the largest keeps an absolute error of 2^-49 max|A| |b| per term. */
+int gnnome_wgrad_blocks_scaled_f32(const float* const* A_blocks, int num_blocks, int block_width, int lda, const float* B, int ldb, int Kb,
+                                   int64_t rows, const unsigned* amax_bits, float* C, int ldc, float* colsum, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+/* gnnome_segment_sum2_f32 that also raises amax_bits[0] to max |out_in|, |out_out| (not zeroed here) */
+int gnnome_segment_sum2_amax_f32(const float* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
+                                 int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, unsigned* amax_bits, void* stream);
 
 /* The same with A given as num_blocks (1..8) column blocks of equal width in separate buffers - A_blocks is a HOST array of
  * device pointers, each [rows, block_width] with row stride lda - so that the five gradients of a layer's node projections
@@ -486,12 +495,14 @@ int gnnome_agg_edge_bwd_stats_f32(const float* e, int64_t num_edges, int hidden,
  * AND gnnome_agg_edge_bwd_stats_f32 (de updated in place, s1 / s2 of the result) - as two launches they stream e from HBM twice.
  * One wave per node over the destination-sorted views; num_nodes rows of Tf/Uf/Tb/Ub [., hidden] and A2h/A3h (row stride ld_node),
  * sum_in / sum_out [num_nodes, hidden] overwritten.  Equal to the two launches up to fp32 reassociation of the sums; every sum is
- * formed in an order that depends on the graph and the launch geometry only (same bits on every run).  workspace as gnnome_colsum2_f32. */
+ * formed in an order that depends on the graph and the launch geometry only (same bits on every run).  workspace as gnnome_colsum2_f32.
+ * amax_bits (NULL: skip): a slot holding the bits of a non-negative float, RAISED (atomicMax on the unsigned value, never zeroed here) to
+ * max |sum_in|, |sum_out| - see gnnome_wgrad_blocks_scaled_f32. */
 int gnnome_agg_bwd_fused_f32(const float* e, int64_t num_nodes, int64_t num_edges, int hidden, const float* Tf, const float* Uf,
                              const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
                              const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst, float* de,
                              const float* xe, const float* scale, const float* shift, const float* mean, float* sum_in, float* sum_out,
-                             float* s1, float* s2, void* workspace, size_t workspace_bytes, void* stream);
+                             float* s1, float* s2, unsigned* amax_bits, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The per-channel arithmetic of a train-mode BatchNorm1d call in one launch (gated_gcn_full.py:106,119,132 with
  * nn.BatchNorm1d's buffer semantics): from shifted column sums d1 = sum(x - center), d2 = sum((x - center)^2) over `rows`
@@ -607,7 +618,7 @@ int gnnome_agg_bwd_fused_x16(const float* e, int64_t num_nodes, int64_t num_edge
                              const float* Tb, const float* Ub, const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,
                              const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos, const int32_t* out_dst, float* de,
                              const uint16_t* xe, const float* scale, const float* shift, const float* mean, float* sum_in, float* sum_out,
-                             float* s1, float* s2, void* workspace, size_t workspace_bytes, void* stream);
+                             float* s1, float* s2, unsigned* amax_bits, void* workspace, size_t workspace_bytes, void* stream);
 int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows, int64_t rows_once, int hidden, const float* scale, const float* shift, const float* a,
                             const float* c1, const float* c2, const float* mean, const float* rstd, const float* W, int ldw,
                             uint16_t* dxe, void* stream);

@@ -622,6 +622,54 @@ def test_scaled_weight_gradient_is_fp32_faithful(rows, Ka, Kb, spread):
         ops.wgrad(A0, B, amax=torch.zeros(2, dtype=torch.int32, device=dev()))
 
 
+def test_node_gradient_producers_raise_one_maximum_and_the_block_product_uses_it():
+    """Round 5: bn_bwd_apply_tables, agg_bwd_fused and segment_sum2 raise ONE slot to max |.| of the five node gradients (atomicMax on float
+    bits: exactly the maximum, whatever the order), their outputs unchanged; wgrad_blocks(amax=) then forms [dv | sum_out | sum_in | dB1 | dB2]^T h
+    as fp16x3 on the blocks scaled by that common maximum - within 2e-7 of max sum |a||b| of the fp64 product, also when one block is 1e6 times
+    smaller than the largest, and the bias sums (column sums) are those of the bf16x6 kernel bit for bit."""
+    g = torch.Generator().manual_seed(5)
+    n, e, H = 3000, 30_000, 128
+    r = lambda *s: torch.randn(*s, generator=g).to(dev())  # noqa: E731
+    gr = make_graph(n, e, seed=9)
+    views = ops.GraphViews(gr["src"].to(dev()), gr["dst"].to(dev()), n)
+    slot = torch.zeros(1, dtype=torch.int32, device=dev())
+    # producer 1
+    dy, x, rdf, hf, rdb, hb = (r(n, H) for _ in range(6))
+    scale, shift, a, c1, c2, mean, rstd = ((torch.rand(H, generator=g) + 0.5).to(dev()) if k in (0, 6) else r(H) for k in range(7))
+    t0 = ops.bn_bwd_apply_tables(dy, x, scale, shift, a, c1, c2, mean, rstd, rdf, hf, rdb, hb)
+    t1 = ops.bn_bwd_apply_tables(dy, x, scale, shift, a, c1, c2, mean, rstd, rdf, hf, rdb, hb, amax=slot)
+    assert all(torch.equal(u, v) for u, v in zip(t0, t1)) and slot.item() == _bits(t1[0]).item()
+    # producer 2 (raises, never lowers)
+    ee, xe, de0, P = 2 * r(e, H), 3 * r(e, H), r(e, H), r(n, 2 * H)
+    Tf, Uf, Tb, Ub = 1e-3 * r(n, H), r(n, H), 1e-3 * r(n, H), r(n, H)
+    f0 = ops.agg_bwd_fused(ee, Tf, Uf, Tb, Ub, P[:, :H], P[:, H:], views, de0.clone(), xe, scale, shift, mean, n)
+    f1 = ops.agg_bwd_fused(ee, Tf, Uf, Tb, Ub, P[:, :H], P[:, H:], views, de0.clone(), xe, scale, shift, mean, n, amax=slot)
+    assert all(torch.equal(u, v) for u, v in zip(f0, f1))
+    want = max(t1[0].abs().max().item(), f1[0].abs().max().item(), f1[1].abs().max().item())
+    assert slot.view(torch.float32).item() == want
+    # producer 3
+    dxe = 40 * r(e, H)
+    s0 = ops.segment_sum2(dxe, views, n)
+    s1 = ops.segment_sum2(dxe, views, n, amax=slot)
+    assert all(torch.equal(u, v) for u, v in zip(s0, s1))
+    want = max(want, s1[0].abs().max().item(), s1[1].abs().max().item())
+    assert slot.view(torch.float32).item() == want
+    # the consumer: five blocks of very different size under ONE scale
+    h = 5 * r(n, H)
+    blocks = [t1[0], f1[1], f1[0], s1[1], s1[0]]
+    blocks[1] = (blocks[1] * 1e-6).contiguous()   # (a block far below the common maximum)
+    got, sums = ops.wgrad_blocks(blocks, h, amax=slot)
+    plain, sums0 = ops.wgrad_blocks(blocks, h)
+    assert torch.equal(sums, sums0)
+    for k, b in enumerate(blocks):
+        wk = b.double().t() @ h.double()
+        bound_all = max((bb.double().abs().t() @ h.double().abs()).max().item() for bb in blocks)
+        assert (got[k * H:(k + 1) * H].double() - wk).abs().max().item() <= 2e-7 * bound_all, k
+    assert (got - plain).abs().max().item() <= 4e-7 * bound_all
+    with pytest.raises(ValueError):
+        ops.segment_sum2(dxe, views, n, amax=torch.zeros(1, dtype=torch.float32, device=dev()))
+
+
 def test_dgrad_leaves_the_maximum_of_dxe():
     """gnnome_bn_bwd_dgrad_amax_f32: the same dxe and de as gnnome_bn_bwd_dgrad_f32, bit for bit, and amax = the bits of max |dxe| exactly
     (atomicMax on the unsigned bits of non-negative floats), also when the last tile is ragged and when rows_once cuts a tile."""
@@ -643,7 +691,7 @@ def test_dgrad_leaves_the_maximum_of_dxe():
         ops.bn_bwd_dgrad(de0.clone(), xe.to(torch.bfloat16), scale, shift, a, c1, c2, mean, rstd, Wt, amax=amax)
 
 
-@pytest.mark.parametrize("switch", ["FUSED_AGG_BWD", "FUSED_NODE_TABLES", "SCALED_WGRAD"])
+@pytest.mark.parametrize("switch", ["FUSED_AGG_BWD", "FUSED_NODE_TABLES", "SCALED_WGRAD", "SCALED_NODE_WGRAD"])
 def test_training_step_is_the_same_with_and_without_the_fused_backward_launches(switch):
     """train.FUSED_AGG_BWD / train.FUSED_NODE_TABLES: the whole step (8 layers, H = 128, 40k edges) with the one launch and with the launches it
     replaces - loss equal, every gradient within fp32 reassociation."""
