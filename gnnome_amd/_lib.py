@@ -67,6 +67,7 @@ SIGNATURES = {
     "gnnome_wgrad_blocks_f32": [_p, _i, _i, _i, _p, _i, _i, _l, _p, _i, _p, _p, _sz, _p],
     "gnnome_wgrad_blocks_scaled_f32": [_p, _i, _i, _i, _p, _i, _i, _l, _p, _p, _i, _p, _p, _sz, _p],
     "gnnome_linear_blocks_f32": [_p, _i, _i, _l, _i, _p, _i, _i, _p, _i, _i, _p],
+    "gnnome_linear_blocks_scaled_f32": [_p, _i, _i, _l, _i, _p, _i, _i, _p, _p, _i, _i, _p],
     "gnnome_score_tail_bwd_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_agg_edge_bwd_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "gnnome_encode_hidden_f32": [_p, _l, _i, _p, _p, _p, _i, _p, _p],

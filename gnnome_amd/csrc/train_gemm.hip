@@ -329,6 +329,142 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_partial_h(WgradA a_op, int lda
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The data gradient of the node projection as ONE fp16x3 product (round 5):  C[M, Nout] (+)= [A_0 | A_1 | ...] W^T  with the column blocks
+// of A (the five node gradients) in separate buffers and W[Nout, K] row-major, K = blocks x width.  As five residual GEMMs on the edge-tile
+// kernel (gnnome_linear_blocks_f32's choice at these shapes) C is read and written five times (768 MB per layer at configs[2]) and the
+// products are bf16x6; here a workgroup keeps a 128 x 128 tile of C in its accumulators over all of K (358 MB), both operands are k-contiguous,
+// so a 32-wide k slab is staged as two fp16 planes [row][k] without a transposition (80-byte rows: the wgrad kernels' conflict-free
+// geometry, and their fragment reads), A is scaled by the power of two its maximum asks for (one slot over all blocks: k_wgrad_partial_h's
+// header has the error model), three MFMAs per k step.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_dgrad_blocks_h(WgradA a_op, int lda, int K, const float* __restrict__ W, int ldw, int Nout,
+                                                           int64_t M, const unsigned* __restrict__ amax_bits, float* __restrict__ C, int ldc,
+                                                           int accumulate) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kWhPlane];
+    unsigned char* Ap = lds;
+    unsigned char* Bp = lds + 2 * kWhPlane;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t i0 = (int64_t)blockIdx.x * kWgTile;
+    const int j0 = blockIdx.y * kWgTile;
+    const int wi = wave & 1, wj = wave >> 1;
+    float a_scale = 1.f, a_unscale = 1.f;
+    if (amax_bits != nullptr) {
+        const unsigned bits = amax_bits[0];
+        const int ex = (int)((bits >> 23) & 0xFFu) - 127;
+        if (bits != 0u && ex < 128) {
+            const int k = max(-100, min(100, 13 - ex));
+            a_scale = __uint_as_float((unsigned)(k + 127) << 23);
+            a_unscale = __uint_as_float((unsigned)(127 - k) << 23);
+        }
+    }
+    f32x16 acc[2][2], acs[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = acs[a][b][r] = 0.f;
+    // a thread stages pieces f = tid + 256 i of a 128-row x 32-k slab: row f / 8, k quad f % 8 (16 bytes of a row); rows past the operand repeat
+    // its last row and are zeroed when staged - every request unconditional
+    const int kq = tid & 7, row0 = tid >> 3;   // rows row0 + 32 i
+    const int a_rows = (int)min((int64_t)kWgTile, M - i0), b_rows = min(kWgTile, Nout - j0);
+    unsigned a_off[4], b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_off[i] = (unsigned)min(row0 + 32 * i, a_rows - 1) * (unsigned)lda + 4u * kq;
+        b_off[i] = (unsigned)min(row0 + 32 * i, b_rows - 1) * (unsigned)ldw + 4u * kq;
+    }
+    const float* w_base = W + (int64_t)j0 * ldw;
+    f32x4 av[4], bv[4];
+    auto fetch = [&](int k0) {
+        const float* ab = a_op.blk[0];
+        const int which = k0 / a_op.width;   // (uniform: a slab lies inside one block, width % 32 == 0)
+#pragma unroll
+        for (int k = 1; k < kWgBlocks; ++k)
+            if (which == k) ab = a_op.blk[k];
+        ab += i0 * lda + (k0 - which * a_op.width);
+        const float* wb = w_base + k0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[i] = *reinterpret_cast<const f32x4*>(ab + a_off[i]);
+            bv[i] = *reinterpret_cast<const f32x4*>(wb + b_off[i]);
+        }
+    };
+    auto stage = [&](unsigned char* planes, const f32x4 (&v)[4], float scale, int rows_live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 p1, p2;
+            const f32x4 x = row0 + 32 * i < rows_live ? v[i] * scale : f32x4{0.f, 0.f, 0.f, 0.f};
+            wg_split4_h(x, p1, p2);
+            unsigned char* d = planes + (row0 + 32 * i) * kWgColBytes + 8 * kq;
+            *reinterpret_cast<uint2*>(d) = p1;
+            *reinterpret_cast<uint2*>(d + kWhPlane) = p2;
+        }
+    };
+    auto h8 = [](const uint4 v) { return __builtin_bit_cast(wg_h8, v); };
+    const unsigned char* ap = Ap + (64 * wi + (lane & 31)) * kWgColBytes + 16 * (lane >> 5);
+    const unsigned char* bp = Bp + (64 * wj + (lane & 31)) * kWgColBytes + 16 * (lane >> 5);
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += kWgRows) {
+        stage(Ap, av, a_scale, a_rows);
+        stage(Bp, bv, 1.f, b_rows);
+        __syncthreads();
+        fetch(min(k0 + kWgRows, K - kWgRows));   // (past the end: the last slab again, never used)
+#pragma unroll
+        for (int s = 0; s < kWgRows / 16; ++s) {
+            uint4 a1[2], a2[2], b1[2], b2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned char* pa = ap + 32 * h * kWgColBytes + 32 * s;
+                const unsigned char* pb = bp + 32 * h * kWgColBytes + 32 * s;
+                a1[h] = *reinterpret_cast<const uint4*>(pa);
+                a2[h] = *reinterpret_cast<const uint4*>(pa + kWhPlane);
+                b1[h] = *reinterpret_cast<const uint4*>(pb);
+                b2[h] = *reinterpret_cast<const uint4*>(pb + kWhPlane);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acs[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a2[a]), h8(b1[b]), acs[a][b], 0, 0, 0);
+                    acs[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a1[a]), h8(b2[b]), acs[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a1[a]), h8(b1[b]), acc[a][b], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    // the tile's 64 old values per lane are requested together (unconditionally: an element outside the tile repeats the tile's last row / column)
+    // before any is used - one trip to memory for the accumulate, not one per element
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = min(64 * wi + 32 * a + cd_row(r, lane), a_rows - 1), j = min(64 * wj + 32 * b + (lane & 31), b_rows - 1);
+                acc[a][b][r] = (acc[a][b][r] + acs[a][b][r] * (1.0f / 2048.f)) * a_unscale;
+                acs[a][b][r] = C[(i0 + i) * ldc + j0 + j];
+            }
+    if (!accumulate) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acs[a][b][r] = 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 64 * wi + 32 * a + cd_row(r, lane), j = 64 * wj + 32 * b + (lane & 31);
+                if (i < a_rows && j < b_rows) C[(i0 + i) * ldc + j0 + j] = acs[a][b][r] + acc[a][b][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The same product for operands that are whole multiples of 256 columns wide (H = 256: dW3 = dxe^T e over 2.5M+ rows, the
 // [5H, H] projection gradient): one workgroup = one 256 x 256 output tile, wave (wi, wj) a 128 x 128 quadrant as 4 x 4
 // accumulators (256 registers per lane: the accumulation half of the register file, one wave per SIMD).  Against the 128 x 128
@@ -951,6 +1087,31 @@ extern "C" int gnnome_wgrad_blocks_scaled_f32(const float* const* A_blocks, int 
     }
     a_op.width = block_width;
     return wgrad_impl(a_op, lda, num_blocks * block_width, B, ldb, Kb, rows, C, ldc, colsum, workspace, workspace_bytes, stream, false, amax_bits);
+}
+
+// C[M,Nout] (+)= [A_0 | A_1 | ...] W^T as ONE fp16x3 launch, the blocks scaled by their common maximum (amax_bits: the slot their producers raised)
+extern "C" int gnnome_linear_blocks_scaled_f32(const float* const* A_blocks, int num_blocks, int block_width, int64_t M, int lda, const float* W,
+                                               int ldw, int Nout, const unsigned* amax_bits, float* C, int ldc, int accumulate, void* stream) {
+    GN_REQUIRE(M >= 0 && Nout > 0, "linear_blocks_scaled: bad shape M=%lld Nout=%d", (long long)M, Nout);
+    if (M == 0) return GNNOME_OK;
+    GN_REQUIRE(A_blocks && amax_bits && num_blocks >= 1 && num_blocks <= kWgBlocks && block_width > 0 && block_width % kWgRows == 0,
+               "linear_blocks_scaled: 1..%d blocks of a width that is a multiple of %d, and the maximum's slot", kWgBlocks, kWgRows);
+    const int K = num_blocks * block_width;
+    GN_REQUIRE(W && C && lda >= block_width && ldw >= K && ldc >= Nout && lda % 4 == 0 && ldw % 4 == 0 && (uintptr_t)W % 16 == 0 &&
+                   (int64_t)kWgTile * lda < (1ll << 31) && (int64_t)kWgTile * ldw < (1ll << 31),
+               "linear_blocks_scaled: bad operands");
+    WgradA a_op = {};
+    for (int k = 0; k < num_blocks; ++k) {
+        GN_REQUIRE(A_blocks[k] && (uintptr_t)A_blocks[k] % 16 == 0, "linear_blocks_scaled: block %d null or not 16-byte aligned", k);
+        a_op.blk[k] = A_blocks[k];
+    }
+    a_op.width = block_width;
+    const int64_t mt = (M + kWgTile - 1) / kWgTile;
+    GN_REQUIRE(mt < (1ll << 31), "linear_blocks_scaled: too many row tiles");
+    hipLaunchKernelGGL(k_dgrad_blocks_h, dim3((unsigned)mt, (unsigned)((Nout + kWgTile - 1) / kWgTile)), dim3(256), 0, (hipStream_t)stream, a_op, lda, K, W,
+                       ldw, Nout, M, amax_bits, C, ldc, accumulate);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
 }
 
 extern "C" int gnnome_score_tail_bwd_f32(const float* z1, const float* dscore, const int32_t* srt_eid, int64_t num_edges,

@@ -878,12 +878,17 @@ def wgrad_blocks(blocks, B, colsum=True, amax=None):
     return out, sums
 
 
-def linear_blocks(blocks, W, out, accumulate=False):
-    """out[M,Nout] (+)= [blocks[0] | blocks[1] | ...] @ W.T without concatenating (W[Nout, len(blocks)*width])."""
+def linear_blocks(blocks, W, out, accumulate=False, amax=None):
+    """out[M,Nout] (+)= [blocks[0] | blocks[1] | ...] @ W.T without concatenating (W[Nout, len(blocks)*width]).  amax: the slot the blocks'
+    producers raised to their largest |element| - ONE fp16x3 launch on the scaled blocks (gnnome_linear_blocks_scaled_f32)."""
     table, M, width, lda = _block_table(blocks, "linear_blocks.A")
     W, ldw = _rows(W, "linear_blocks.W")
     out, ldc = _rows(out, "linear_blocks.out")
     assert W.shape[1] == len(blocks) * width and out.shape[0] == M
+    if amax is not None and M > 0 and width % 32 == 0:
+        _call("gnnome_linear_blocks_scaled_f32", out.device, table, len(blocks), width, M, lda, _ptr(W), ldw, W.shape[0],
+              _ptr(_amax_slot(amax, out.device, "linear_blocks")), _ptr(out), ldc, 1 if accumulate else 0)
+        return out
     _call("gnnome_linear_blocks_f32", out.device, table, len(blocks), width, M, lda, _ptr(W), ldw, W.shape[0], _ptr(out), ldc,
           1 if accumulate else 0)
     return out

@@ -141,6 +141,7 @@ def _switch(name):   # GNNOME_<NAME>=0 in the environment turns a switch off for
     return os.environ.get("GNNOME_" + name, "1") != "0"
 
 
+SCALED_NODE_DGRAD = _switch("SCALED_NODE_DGRAD")   # ... and dh += dP Wcat as one fp16x3 launch on the same scaled blocks (five bf16x6 residual GEMMs otherwise)
 SCALED_NODE_WGRAD = _switch("SCALED_NODE_WGRAD")   # ... and the projection's [5H, H] weight gradient, on the five node gradients scaled by their common maximum
 SCALED_WGRAD = _switch("SCALED_WGRAD")   # B_3's weight gradient as fp16x3 on dxe scaled by its maximum (gnnome_wgrad_scaled_f32) instead of bf16x6
 FUSED_NODE_TABLES = _switch("FUSED_NODE_TABLES")   # bn_h's backward apply + the four node tables of the aggregation's backward as one launch (gnnome_bn_bwd_apply_tables_f32)
@@ -368,7 +369,7 @@ class _TrainStep(torch.autograd.Function):
                 pass
             elif n_local == n_own and FUSED_NODE_TABLES and hasattr(ops, "bn_bwd_apply_tables"):
                 if (SCALED_NODE_WGRAD and s["sc_e"] is not None and FUSED_AGG_BWD and hasattr(ops, "agg_bwd_fused") and getattr(ops, "NODE_AMAX", False)
-                        and H % 128 == 0 and s["xe"] is not None and s["xe"].dtype == torch.float32):
+                        and H % 128 == 0 and (s["xe"].dtype if s["xe"] is not None else s["gate_path"][2]) == torch.float32):
                     amax_nodes = torch.zeros(1, dtype=torch.int32, device=dev)
                 kw = {"amax": amax_nodes} if amax_nodes is not None else {}
                 # bn_h's backward and the four node tables of the aggregation's backward (Tf, Uf, Tb, Ub) in one pass over the node rows
@@ -454,7 +455,7 @@ class _TrainStep(torch.autograd.Function):
                 gWcat, gbcat = ops.wgrad_blocks(parts, s["h"], **({"amax": amax_nodes} if amax_nodes is not None else {}))   # [5H, H], [5H]
                 for k, name in enumerate(names):
                     g[pfx + name + ".bias"] = gbcat[k * H:(k + 1) * H]
-                dh = ops.linear_blocks(parts, WcatT, dh_in, accumulate=True)
+                dh = ops.linear_blocks(parts, WcatT, dh_in, accumulate=True, **({"amax": amax_nodes} if amax_nodes is not None and SCALED_NODE_DGRAD else {}))
             else:
                 for k, name in enumerate(names):
                     g[pfx + name + ".bias"] = ops.colsum2(parts[k])[0]

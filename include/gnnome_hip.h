@@ -385,6 +385,11 @@ int gnnome_wgrad_scaled_f32(const float* A, int lda, int Ka, const float* B, int
 int gnnome_wgrad_blocks_scaled_f32(const float* const* A_blocks, int num_blocks, int block_width, int lda, const float* B, int ldb, int Kb,
                                    int64_t rows, const unsigned* amax_bits, float* C, int ldc, float* colsum, void* workspace,
                                    size_t workspace_bytes, void* stream);
+/* gnnome_linear_blocks_f32 as ONE fp16x3 launch with the blocks scaled by their common maximum (the same slot): a workgroup keeps a 128 x 128
+ * tile of C in its accumulators over all of K = num_blocks x block_width (block_width a multiple of 32), so C is read and written once - the
+ * data gradient dh += [dv | dA2 | dA3 | dB1 | dB2] Wcat of the node projection (gated_gcn_full.py:91-96 under autograd). */
+int gnnome_linear_blocks_scaled_f32(const float* const* A_blocks, int num_blocks, int block_width, int64_t M, int lda, const float* W, int ldw,
+                                    int Nout, const unsigned* amax_bits, float* C, int ldc, int accumulate, void* stream);
 /* gnnome_segment_sum2_f32 that also raises amax_bits[0] to max |out_in|, |out_out| (not zeroed here) */
 int gnnome_segment_sum2_amax_f32(const float* X, int width, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_pos,
                                  int64_t num_nodes, float* out_in, int ld_in, float* out_out, int ld_out, unsigned* amax_bits, void* stream);

@@ -666,6 +666,19 @@ def test_node_gradient_producers_raise_one_maximum_and_the_block_product_uses_it
         bound_all = max((bb.double().abs().t() @ h.double().abs()).max().item() for bb in blocks)
         assert (got[k * H:(k + 1) * H].double() - wk).abs().max().item() <= 2e-7 * bound_all, k
     assert (got - plain).abs().max().item() <= 4e-7 * bound_all
+    # the data gradient on the same blocks: out (+)= [blocks] W^T as one fp16x3 launch, at a ragged row count through the views below
+    W = (torch.randn(H, 5 * H, generator=g) / H ** 0.5).to(dev())
+    for rows in (n, 129, 1):
+        bl = [b[:rows] for b in blocks]
+        base = r(rows, H)
+        want = base.double() + sum(b.double() @ W[:, k * H:(k + 1) * H].double().t() for k, b in enumerate(bl))
+        bound = sum(b.double().abs() @ W[:, k * H:(k + 1) * H].double().abs().t() for k, b in enumerate(bl)).max().item()
+        got_acc = ops.linear_blocks(bl, W, base.clone(), accumulate=True, amax=slot)
+        plain_acc = ops.linear_blocks(bl, W, base.clone(), accumulate=True)
+        assert (got_acc.double() - want).abs().max().item() <= 2e-7 * bound + 1e-6 * base.abs().max().item(), rows
+        assert (got_acc - plain_acc).abs().max().item() <= 4e-7 * bound + 1e-6 * base.abs().max().item()
+        got_new = ops.linear_blocks(bl, W, torch.full_like(base, float("nan")), accumulate=False, amax=slot)
+        assert (got_new.double() - (want - base.double())).abs().max().item() <= 2e-7 * bound, rows
     with pytest.raises(ValueError):
         ops.segment_sum2(dxe, views, n, amax=torch.zeros(1, dtype=torch.float32, device=dev()))
 
@@ -691,7 +704,7 @@ def test_dgrad_leaves_the_maximum_of_dxe():
         ops.bn_bwd_dgrad(de0.clone(), xe.to(torch.bfloat16), scale, shift, a, c1, c2, mean, rstd, Wt, amax=amax)
 
 
-@pytest.mark.parametrize("switch", ["FUSED_AGG_BWD", "FUSED_NODE_TABLES", "SCALED_WGRAD", "SCALED_NODE_WGRAD"])
+@pytest.mark.parametrize("switch", ["FUSED_AGG_BWD", "FUSED_NODE_TABLES", "SCALED_WGRAD", "SCALED_NODE_WGRAD", "SCALED_NODE_DGRAD"])
 def test_training_step_is_the_same_with_and_without_the_fused_backward_launches(switch):
     """train.FUSED_AGG_BWD / train.FUSED_NODE_TABLES: the whole step (8 layers, H = 128, 40k edges) with the one launch and with the launches it
     replaces - loss equal, every gradient within fp32 reassociation."""
