@@ -683,6 +683,33 @@ def test_node_gradient_producers_raise_one_maximum_and_the_block_product_uses_it
         ops.segment_sum2(dxe, views, n, amax=torch.zeros(1, dtype=torch.float32, device=dev()))
 
 
+@pytest.mark.parametrize("M,width,nb,Nout", [(1000, 64, 3, 64), (257, 32, 5, 96), (5000, 256, 2, 256), (130, 128, 1, 128)])
+def test_scaled_block_products_at_other_shapes(M, width, nb, Nout):
+    """gnnome_linear_blocks_scaled_f32 / gnnome_wgrad_blocks_scaled_f32 away from the training step's 128s: narrow and wide blocks, an output
+    that is a column block of a wider table (row stride > Nout), row counts that end inside a tile - against fp64, and the untouched columns
+    of the wider table stay untouched."""
+    g = torch.Generator().manual_seed(M + width)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev())  # noqa: E731
+    blocks = [(10.0 ** (-k)) * r(M, width) for k in range(nb)]
+    amax = torch.stack([b.abs().max() for b in blocks]).max().reshape(1).float().view(torch.int32)
+    W = (r(Nout, nb * width) / (nb * width) ** 0.5).contiguous()
+    wide = torch.full((M, Nout + 32), 7.0, device=dev())
+    out = wide[:, 16:16 + Nout]
+    want = sum(b.double() @ W[:, k * width:(k + 1) * width].double().t() for k, b in enumerate(blocks))
+    bound = sum(b.double().abs() @ W[:, k * width:(k + 1) * width].double().abs().t() for k, b in enumerate(blocks)).max().item()
+    ops.linear_blocks(blocks, W, out, accumulate=False, amax=amax)
+    assert (out.double() - want).abs().max().item() <= 2e-7 * bound
+    assert (wide[:, :16] == 7.0).all() and (wide[:, 16 + Nout:] == 7.0).all()
+    ops.linear_blocks(blocks, W, out, accumulate=True, amax=amax)
+    assert (out.double() - 2 * want).abs().max().item() <= 4e-7 * bound
+    h = 3 * r(M, 64)
+    got, sums = ops.wgrad_blocks(blocks, h, amax=amax)       # (fp16x3 where the width is a whole number of 128-column tiles, bf16x6 elsewhere)
+    wk = torch.cat([b.double().t() @ h.double() for b in blocks], 0)
+    wb = max((b.double().abs().t() @ h.double().abs()).max().item() for b in blocks)
+    assert (got.double() - wk).abs().max().item() <= 2e-7 * wb
+    assert (sums.double() - torch.cat([b.double().sum(0) for b in blocks])).abs().max().item() <= 1e-5 * max(1.0, M ** 0.5)
+
+
 def test_dgrad_leaves_the_maximum_of_dxe():
     """gnnome_bn_bwd_dgrad_amax_f32: the same dxe and de as gnnome_bn_bwd_dgrad_f32, bit for bit, and amax = the bits of max |dxe| exactly
     (atomicMax on the unsigned bits of non-negative floats), also when the last tile is ragged and when rows_once cuts a tile."""
