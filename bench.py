@@ -115,6 +115,43 @@ class KernelTimer:
         return sum(s.elapsed_time(t) for s, t in ev) / max(len(ev), 1), len(ev)
 
 
+class ForwardEventTimer:
+    """KernelTimer's interface for a forward that is ONE library call (gnnome_model_forward_f32, the default since round 6): the HIP events go
+    around the last layer's edge-gate and aggregation launches INSIDE that call (gnnome_debug_forward_events), on the stream it launches on -
+    one pair per kernel and step, as before.  The events are created (and recorded once, which is what makes torch create them) before the
+    timed region."""
+
+    def __init__(self, lib, steps, layer, launches_per_step):
+        self.lib, self.layer, self.on, self.step = lib, layer, False, 0
+        self.pool = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+        for quad in self.pool:
+            for ev in quad:
+                ev.record()
+        torch.cuda.synchronize()
+        self.events = {"edge_gate": [], "node_aggregate": []}
+        self.calls = {"edge_gate": 0, "node_aggregate": 0}
+        self.per_step = launches_per_step
+
+    def before_step(self):
+        if not self.on or self.step >= len(self.pool):
+            self.lib.gnnome_debug_forward_events(None, None, None, None, -1)
+            return
+        q = self.pool[self.step]
+        self.lib.gnnome_debug_forward_events(*(ev.cuda_event for ev in q), self.layer)
+        self.events["edge_gate"].append((q[0], q[1]))
+        self.events["node_aggregate"].append((q[2], q[3]))
+        for k, v in self.per_step.items():
+            self.calls[k] += v
+        self.step += 1
+
+    def close(self):
+        self.lib.gnnome_debug_forward_events(None, None, None, None, -1)
+
+    def mean_ms(self, name):
+        ev = self.events[name]
+        return sum(s.elapsed_time(t) for s, t in ev) / max(len(ev), 1), len(ev)
+
+
 def _pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` (a substring of its name) from the committed PMC passes over one forward of `workload`
     (FETCH_SIZE / WRITE_SIZE cannot be read from inside this process; tools/pmc_forward.sh collects them per the guide - separate
@@ -733,32 +770,57 @@ def main():
     # whichever of the two holds the larger share of the measured step (the aggregation had overtaken the gate).
     dominant = [] if args.no_kernel_timers else ["edge_gate", "node_aggregate"]
     e_gate = e if world == 1 else plan.views.num_edges
-    with KernelTimer(ops, dominant, every=8) as kt:
+    from gnnome_amd import engine
+    one_call = world == 1 and engine.ONE_CALL_FORWARD and not args.hipgraph   # the forward is one library call: events inside it
+    if one_call and dominant:
+        from gnnome_amd import _lib as _glib
+        ref_layers = sum(1 for lw in engine.prepared_for(model, dev, engine.Prepared).layers if lw.ref)
+        fwd_timer = ForwardEventTimer(_glib.load(), args.steps, 7, {"edge_gate": 8 - ref_layers - (1 if ref_layers == 0 else 0), "node_aggregate": 8})
+    else:
+        fwd_timer = None
+    with KernelTimer(ops, [] if fwd_timer else dominant, every=8) as kt:
         for _ in range(args.warmup):
             step()
         barrier()
         kt.on = True
+        if fwd_timer:
+            fwd_timer.on = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
+            if fwd_timer:
+                fwd_timer.before_step()
             out = step()
         t_host = time.perf_counter() - t0
         barrier()
         elapsed = time.perf_counter() - t0
         kt.on = False
+    if fwd_timer:
+        fwd_timer.close()
+        kt = fwd_timer
+    # what a forward costs the HOST when the launch queue is empty (in the timed region above the host runs ahead until the queue is full and
+    # then waits for the GPU: host_enqueue_ms_per_step is the GPU's time there, not Python's)
+    torch.cuda.synchronize()
+    t0h = time.perf_counter()
+    for _ in range(10):
+        step()
+    host_unblocked_ms = (time.perf_counter() - t0h) / 10 * 1e3
+    barrier()
     # untimed diagnostic pass: every kernel family instrumented, for the per-kernel table only
     others = [] if args.no_kernel_timers or world > 1 else ["node_aggregate", "linear", "edge_score", "encode", "linear_ref", "edge_gate_ref",
                                                             "edge_gate_encode"] + (["edge_gate"] if args.workload == "ecoli" else [])
-    from gnnome_amd import engine
     chunks_timed = engine.PIPELINE_CHUNKS if (world == 1 and n >= engine.PIPELINE_MIN_NODES) else 1
     with KernelTimer(ops, others) as kd:
         kd.on = True
+        was_one_call = engine.ONE_CALL_FORWARD
         if others:
             engine.PIPELINE_CHUNKS = 1   # the per-kernel table wants every kernel alone on the chip, one launch per layer
+            engine.ONE_CALL_FORWARD = False   # ... and launched call by call, so that each can carry its own pair of events
         try:
             for _ in range(min(args.steps, 5)):
                 step()
         finally:
             engine.PIPELINE_CHUNKS = chunks_timed if chunks_timed > 1 else engine.PIPELINE_CHUNKS
+            engine.ONE_CALL_FORWARD = was_one_call
         barrier()
     timed = dominant
     if world > 1:
@@ -781,7 +843,9 @@ def main():
             "hbm_roofline_frac_whole_fwd": (b_fwd / (ms * 1e-3)) / (world * HBM_PEAK),
             "mfma_f32_frac_whole_fwd": (f_fwd / (ms * 1e-3)) / (world * MFMA_F32_PEAK),
             "algorithmic_bytes_fwd": b_fwd, "algorithmic_flops_fwd": f_fwd, "cold": cold, "timed_region_s": elapsed,
-            "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "so_sha16": so_sha16(),
+            "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_ms_per_forward_queue_empty": host_unblocked_ms,
+            "forward_entry": "gnnome_model_forward_f32 (one library call per forward)" if one_call else "per-kernel entries, call by call",
+            "so_sha16": so_sha16(),
             "streams": (f"2: every node projection after the first runs on a second HIP stream under the aggregation, which is cut into "
                         f"{chunks_timed} node ranges (engine.aggregate_then_project)") if chunks_timed > 1 else "1",
         }

@@ -26,6 +26,8 @@ SIGNATURES = {
     "gnnome_encode_f32": [_p, _l, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p],
     "gnnome_linear_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "gnnome_linear_acc_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
+    "gnnome_weight_planes_f16": [_p, _i, _i, _i, _p, _p],
+    "gnnome_linear_planes_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _i, _p],
     "gnnome_edge_gate_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p],
     "gnnome_edge_gate_encode_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
     "gnnome_linear_ref_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
@@ -37,6 +39,9 @@ SIGNATURES = {
     "gnnome_node_aggregate_stream_f32": [_p, _i, _l, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p,
                                          _p, _l, _p, _p],
     "gnnome_edge_score_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
+    "gnnome_debug_forward_events": [_p, _p, _p, _p, _i],
+    "gnnome_model_forward_workspace_bytes": [_l, _l, _i, _i, ctypes.POINTER(_sz)],
+    "gnnome_model_forward_f32": [_p, _p, _p, _p, _p, _p, _sz, _p],
     "gnnome_edge_gate_raw_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p],
     "gnnome_edge_gate_raw_stats_rows": [_i, ctypes.POINTER(_i)],
     "gnnome_edge_gate_raw_stats_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
@@ -101,7 +106,26 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
+
+
+# the parameter blocks of gnnome_model_forward_f32 (include/gnnome_hip.h), field for field
+class LayerParams(ctypes.Structure):
+    _fields_ = [(n, _p) for n in ("Wcat", "Wcat_planes", "bcat", "W3", "b3", "scale_e", "shift_e", "scale_h", "shift_h")] + [
+        ("norm_kind", ctypes.c_int32), ("reference_order", ctypes.c_int32)]
+
+
+class ModelParams(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int32) for n in ("hidden", "hidden_ne", "num_layers", "score_hidden", "node_features", "edge_features")]
+                + [(n, _p) for n in ("node_W1", "node_b1", "node_W2", "node_b2", "edge_W1", "edge_b1", "edge_W2", "edge_b2")]
+                + [("layers_host", ctypes.POINTER(LayerParams)), ("W_nodes", _p), ("W_nodes_planes", _p), ("b_nodes", _p), ("W1e", _p),
+                   ("ld_w1e", ctypes.c_int32), ("reserved", ctypes.c_int32), ("W2", _p), ("b2", _p), ("W3", _p), ("b3", _p)])
+
+
+class Views(ctypes.Structure):
+    _fields_ = ([("num_nodes", ctypes.c_int64), ("num_edges", ctypes.c_int64)]
+                + [(n, _p) for n in ("in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst", "node_gather")]
+                + [("transposed", ctypes.c_int32), ("reserved", ctypes.c_int32)])
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

@@ -28,13 +28,14 @@ class CapturedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = model(self.views, self.x, self.e)
-        from .engine import _state_key
-        self._key = _state_key(model, device)   # the recording holds the weights as PREPARED at capture time
+        from .engine import _StateProbe
+        self._probe = _StateProbe(model, device)   # the recording holds the weights as PREPARED at capture time
 
     def __call__(self, x=None, e=None):
-        """Replay; new features (same shapes, same graph) may be supplied.  Returns the static output tensor."""
-        from .engine import _state_key
-        if _state_key(self.model, self.device) != self._key:
+        """Replay; new features (same shapes, same graph) may be supplied.  Returns the static output tensor.  A replay is NOT range-checked
+        (engine.forward_in_range looked at the inputs the recording was made with): features beyond fp16x3's range (|x| >= 65504 somewhere in
+        the stack) come back as NaN rows, never as wrong finite values - record under `ops.bf16x6_arithmetic()` for such inputs."""
+        if not self._probe.unchanged(self.model, self.device):
             raise RuntimeError("the model's parameters or buffers changed since this forward was captured (the recording "
                                "replays the weights prepared at capture time): build a new CapturedForward")
         if x is not None:

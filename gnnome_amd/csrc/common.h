@@ -155,6 +155,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // aggregation kernels evaluate this E*H*2 times per layer
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// relu that keeps NaN a NaN (fmaxf(NaN, 0) = 0): a node row whose sums went non-finite - an fp16x3 operand beyond 65504 upstream - must stay loud
+// all the way to the logits, where engine.forward_in_range looks.  Same value as fmaxf(t, 0) for every t that is not NaN.
+__device__ __forceinline__ float relu_keep_nan(float t) { return t < 0.f ? 0.f : t; }
+
 // max |.| of a wave's values into amax_bits[0] (the bits of a non-negative float; unsigned order = float order): one atomicMax per wave, and
 // only when the value read first is smaller - a maximum does not depend on the order it is formed in, so results stay reproducible.
 __device__ __forceinline__ void wave_amax_to(unsigned* amax_bits, float v) {

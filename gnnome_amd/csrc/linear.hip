@@ -776,7 +776,7 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
         g.e_in = A; g.e_out = C; g.E = M; g.B1h = C; g.ldn = 256; g.W3 = W; g.ldw = ldw;
         return gate_pl256_launch(2, g, s);   // the plane form as a residual GEMM (edge_gate_pl256.hip)
     }
-    if (tuning(kTuneLinearVariant) == 0 && !accumulate && K == 256 && Nout % 128 == 0 && Nout / 128 <= 16 && lda % 4 == 0 && ldw % 4 == 0 && aligned_out &&
+    if ((tuning(kTuneLinearVariant) == 0 || tuning(kTuneLinearVariant) == 10) && !accumulate && K == 256 && Nout % 128 == 0 && Nout / 128 <= 16 && lda % 4 == 0 && ldw % 4 == 0 && aligned_out &&
         M >= 1 && (const void*)A != (const void*)C) {   // at every row count, as at K = 128: a row's bits do not depend on how the caller cuts the node range
         // K = 256 (the node projection and the scorer's node halves of configs[3] / [4]): the plane-form edge-tile kernel with W in
         // registers as a plain GEMM (edge_gate_pl256.hip mode 4); the tile kernel it replaces: 1.03 ms at N = 250k, Nout = 1280
@@ -784,7 +784,7 @@ static int linear_impl(const float* A, int64_t M, int K, int lda, const float* W
         g.e_in = A; g.e_out = C; g.E = M; g.ldn = lda; g.ld_out = ldc; g.W3 = W; g.ldw = ldw; g.scale = bias; g.num_cblocks = Nout / 128;
         return gate_pl256_launch(4, g, s);
     }
-    if ((tuning(kTuneLinearVariant) == 0 || tuning(kTuneLinearVariant) == 9) && !accumulate && K == 128 && Nout % 128 == 0 && Nout >= 256 && Nout / 128 <= 16 &&
+    if ((tuning(kTuneLinearVariant) == 0 || tuning(kTuneLinearVariant) == 9 || tuning(kTuneLinearVariant) == 10) && !accumulate && K == 128 && Nout % 128 == 0 && Nout >= 256 && Nout / 128 <= 16 &&
         lda % 4 == 0 && ldw % 4 == 0 && aligned_out && (const void*)A != (const void*)C &&
         M >= 1) {   // at every row count (12 us at 100 rows like the streaming kernel, level with k_linear_as from 400k): one kernel, so a
                     // row's bits do not depend on how the caller cuts the node range (engine.aggregate_then_project, dist.py)

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
         const f32x4 hi = *reinterpret_cast<const f32x4*>(h_in + node * ldh + c);
         f32x4 y;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) y[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f) + hi[k];
+        for (int k = 0; k < 4; ++k) y[k] = relu_keep_nan(v[k] * sc[k] + sh[k]) + hi[k];
         *reinterpret_cast<f32x4*>(h_out + node * H + c) = y;
     }
 }
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kAggThreads) void k_node_aggregate_pair(
     const f32x4 hi = *reinterpret_cast<const f32x4*>(h_in + node * ldh + c);
     f32x4 y;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) y[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f) + hi[k];
+    for (int k = 0; k < 4; ++k) y[k] = relu_keep_nan(v[k] * sc[k] + sh[k]) + hi[k];
     *reinterpret_cast<f32x4*>(h_out + node * H + c) = y;
   }
 }

@@ -360,8 +360,8 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
                         f32x4 yl, yh;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            yl[k] = fmaxf((R.tsl[k] + nbl[k] * __builtin_amdgcn_rcpf(dbl[k] + kAggEps)) * sc_l[k] + sh_l[k], 0.f) + R.hil[k];
-                            yh[k] = fmaxf((R.tsh[k] + nbh[k] * __builtin_amdgcn_rcpf(dbh[k] + kAggEps)) * sc_h[k] + sh_h[k], 0.f) + R.hih[k];
+                            yl[k] = relu_keep_nan((R.tsl[k] + nbl[k] * __builtin_amdgcn_rcpf(dbl[k] + kAggEps)) * sc_l[k] + sh_l[k]) + R.hil[k];
+                            yh[k] = relu_keep_nan((R.tsh[k] + nbh[k] * __builtin_amdgcn_rcpf(dbh[k] + kAggEps)) * sc_h[k] + sh_h[k]) + R.hih[k];
                         }
                         float* o = h_out + (int64_t)R.src * H + cl;
                         *reinterpret_cast<f32x4*>(o) = yl;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(512) void k_aggregate_stream(
                         nb = slot[0], db = slot[CH];
                         slot[0] = 0.f, slot[CH] = 0.f;
                     }
-                    h_out[(int64_t)node * H + cj] = fmaxf((t + nb * __builtin_amdgcn_rcpf(db + kAggEps)) * scj + shj, 0.f) + R.hnj;
+                    h_out[(int64_t)node * H + cj] = relu_keep_nan((t + nb * __builtin_amdgcn_rcpf(db + kAggEps)) * scj + shj) + R.hnj;
                 } else {
                     h_out[(int64_t)node * H + cj] = t;   // parked until the node's closing row, at least kLateDistance steps from here
                 }
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void k_stream_finish(const float* __restrict__
         const f32x4 hi = *reinterpret_cast<const f32x4*>(h_in + (int64_t)node * ldh + c);
         f32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = fmaxf(y[k] * sc[k] + sh[k], 0.f) + hi[k];
+        for (int k = 0; k < 4; ++k) o[k] = relu_keep_nan(y[k] * sc[k] + sh[k]) + hi[k];
         *reinterpret_cast<f32x4*>(h_out + (int64_t)node * H + c) = o;
     }
 }

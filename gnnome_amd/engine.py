@@ -24,7 +24,7 @@ from .graph import views_for
 
 
 class LayerWeights:
-    __slots__ = ("Wcat", "bcat", "W3", "b3", "norm", "scale_e", "shift_e", "scale_h", "shift_h", "ref", "gain_e")
+    __slots__ = ("Wcat", "bcat", "W3", "b3", "norm", "scale_e", "shift_e", "scale_h", "shift_h", "ref", "gain_e", "planes")
 
 
 # Which layers run in the reference's ORDER of evaluation (csrc/reference_order.hip) instead of on the bf16x6 matrix-core
@@ -86,6 +86,7 @@ class Prepared:
         amax = max((float(t.abs().max()) if t.numel() else 0.0) for t in weights) if weights else 0.0
         self.force_bf16x6 = not (amax < hip_ops_fp16_max())
         self.range_verified = self.range_failed = None
+        self.block = None   # ops.ModelBlock: these parameters as gnnome_model_forward_f32 takes them, built on first use
 
 
 def hip_ops_fp16_max():
@@ -180,6 +181,10 @@ def prepare_layer(conv, device, arithmetic=None):
     lw.gain_e = float(lw.scale_e.abs().max()) if lw.norm == NORM_AFFINE and lw.scale_e.numel() else 0.0
     can = hip_ops.reference_order_supported(hidden, lw.norm)
     lw.ref = can and (arithmetic == "reference" or (arithmetic == "auto" and lw.gain_e > REFERENCE_ORDER_GAIN))
+    # the projection's weights as fp16x3 planes, made once (ops.weight_planes -> gnnome_linear_planes_f32; round 6)
+    planes_ok = getattr(hip_ops, "planes_supported", None)
+    lw.planes = hip_ops.weight_planes(lw.Wcat) if (not lw.ref and planes_ok is not None and planes_ok(hidden, 5 * hidden)
+                                                   and lw.Wcat.is_cuda) else None
     if lw.ref:
         lw.bcat = dev(torch.cat([b(conv.A_1), b(conv.A_2), b(conv.A_3), b(conv.B_1), b(conv.B_2)], 0))
     else:
@@ -204,23 +209,53 @@ def prepare_predictor(pred, device):
     # node halves stacked into one [2*hs, H] projection: rows 0..hs-1 act on x[src], rows hs.. on x[dst] (+ b1)
     W_nodes = torch.cat([W1[:, :hidden], W1[:, hidden:2 * hidden]], 0).contiguous()
     b_nodes = torch.cat([torch.zeros_like(b1), b1])
+    # the node halves' projection on W_nodes' fp16x3 planes where ops.linear routes that shape there by itself (made once instead of per call)
+    planes_ok = getattr(hip_ops, "planes_supported", None)
+    planes = (hip_ops.weight_planes(W_nodes) if planes_ok is not None and W_nodes.is_cuda and planes_ok(hidden, 2 * hs) and (2 * hs) % 128 == 0
+              and (hidden == 256 or 2 * hs >= 256) else None)
     return {
+        "planes": planes,
         "hidden": hidden, "hs": hs, "model_hidden": width, "W_nodes": W_nodes, "b_nodes": dev(b_nodes), "W1_e": W1[:, 2 * hidden:],
         "W2": dev(_pad(pred.W2.weight.detach(), 32, hs)), "b2": dev(pred.W2.bias),
         "W3": dev(pred.W3.weight.reshape(-1)), "b3": dev(pred.W3.bias.reshape(-1)), "_W1": W1,
     }
 
 
-def _state_key(module, device):
-    items = [(id(t), t._version, str(t.device)) for t in list(module.parameters()) + list(module.buffers())]
-    return (str(device), getattr(module, "arithmetic", "auto"), tuple(items))
+class _StateProbe:
+    """Has anything `Prepared` was built from changed?  The question is asked on every forward, and walking module.parameters() + buffers()
+    (190 tensors behind generators) cost 0.26 ms of the 0.63 ms a forward spent on the host.  Kept instead: the flat list of (owning dict,
+    name, tensor, version, storage address) - an in-place update bumps the version (optimizer step, load_state_dict), `.to()` / `.data = `
+    moves the storage, a replaced Parameter is another object under the same name - and the sub-module counts (a layer added or removed)."""
+
+    __slots__ = ("device", "arithmetic", "slots", "modules")
+
+    def __init__(self, module, device):
+        self.device, self.arithmetic = str(device), getattr(module, "arithmetic", "auto")
+        self.slots, self.modules = [], []
+        for sub in module.modules():
+            self.modules.append((sub._modules, len(sub._modules)))
+            for table in (sub._parameters, sub._buffers):
+                for name, t in table.items():
+                    if t is not None:
+                        self.slots.append((table, name, t, t._version, t.data_ptr()))
+
+    def unchanged(self, module, device):
+        if str(device) != self.device or getattr(module, "arithmetic", "auto") != self.arithmetic:
+            return False
+        for table, count in self.modules:
+            if len(table) != count:
+                return False
+        for table, name, t, version, ptr in self.slots:
+            if table.get(name) is not t or t._version != version or t.data_ptr() != ptr:
+                return False
+        return True
 
 
 def prepared_for(module, device, build):
-    key = _state_key(module, device)
     cached = module.__dict__.get("_gnnome_prepared")
-    if cached is None or cached[0] != key:
-        cached = (key, build(module, device))
+    if cached is None or not cached[0].unchanged(module, device):
+        probe = _StateProbe(module, device)   # (before the build: a change during it is seen next time)
+        cached = (probe, build(module, device))
         module.__dict__["_gnnome_prepared"] = cached
     return cached[1]
 
@@ -269,7 +304,9 @@ def gate_update(ops, lw, views, e, B1, B2, scratch=None):
 
 def project(ops, lw, h, out=None):
     """P[rows,5H] = h Wcat^T + bcat: A1h|A2h|A3h|B1h|B2h (gated_gcn_full.py:91-96)."""
-    return (ops.linear_ref if lw.ref else ops.linear)(h, lw.Wcat, lw.bcat, out=out)
+    if lw.ref:
+        return ops.linear_ref(h, lw.Wcat, lw.bcat, out=out)
+    return ops.linear(h, lw.Wcat, lw.bcat, out=out, planes=lw.planes)
 
 
 def gate(ops, lw, views, e, B1, B2, raw_edges=None, scratch=None):
@@ -314,6 +351,8 @@ def aggregate_then_project(ops, lw, views, e, A1, A2, A3, h, then):
     return h_out, P_next
 
 
+import os as _os
+ONE_CALL_FORWARD = _os.environ.get("GNNOME_ONE_CALL_FORWARD", "1") != "0"   # run_stack's default path through gnnome_model_forward_f32 (0: call by call)
 PIPELINE_CHUNKS = 1   # off: measured slower, see aggregate_then_project
 PIPELINE_MIN_NODES = 1 << 15   # below this a launch is a few microseconds and the extra launches + events cost more than they hide
 
@@ -329,7 +368,9 @@ class _Projection:
 
 
 def layer_projection(ops, lw):
-    return _Projection(ops.linear_ref if lw.ref else ops.linear, lw.Wcat, lw.bcat)
+    if lw.ref:
+        return _Projection(ops.linear_ref, lw.Wcat, lw.bcat)
+    return _Projection(lambda rows, W, b, out=None: ops.linear(rows, W, b, out=out, planes=lw.planes), lw.Wcat, lw.bcat)
 
 
 def layer_step(ops, lw, views, h, e, n_out=None, raw_edges=None, scratch=None, P=None, then=None):
@@ -368,13 +409,13 @@ def encode_edges(ops, prep, views, e_raw):
 
 
 def predictor_projection(ops, pw):
-    return _Projection(ops.linear, pw["W_nodes"], pw["b_nodes"])
+    return _Projection(lambda rows, W, b, out=None: ops.linear(rows, W, b, out=out, planes=pw.get("planes")), pw["W_nodes"], pw["b_nodes"])
 
 
 def score_step(ops, pw, views, h, e, logits, n_edges=None, PQ=None):
     hs = pw["hs"]
     if PQ is None:
-        PQ = ops.linear(h, pw["W_nodes"], pw["b_nodes"])
+        PQ = ops.linear(h, pw["W_nodes"], pw["b_nodes"], planes=pw.get("planes"))
     Ps, Qd = PQ[:, :hs], PQ[:, hs:]
     if views.transposed:
         # x[src'] | x[dst'] = x[dst] | x[src]; b1 is added once either way
@@ -388,11 +429,20 @@ def run_stack(ops, prep, views, x, e_raw, exchange=None, n_own=None, n_score=Non
     sorted positions (both used by the destination-range partition, dist.py).  With PIPELINE_CHUNKS > 1 (off by
     default: measured slower) every node projection after the first runs under the preceding aggregation on a second
     stream (aggregate_then_project)."""
+    pipelined = (exchange is None and n_own is None and getattr(ops, "side_stream", None) is not None and PIPELINE_CHUNKS > 1
+                 and views.num_nodes >= PIPELINE_MIN_NODES)
+    one_call = getattr(ops, "model_forward", None)
+    if (ONE_CALL_FORWARD and one_call is not None and exchange is None and n_own is None and n_score is None and not pipelined
+            and not getattr(ops, "STREAM_AGGREGATE", False) and isinstance(views, ops.GraphViews) and x.is_cuda and x.is_contiguous()
+            and e_raw.is_contiguous()):
+        # the whole sequence below as ONE call into the library (gnnome_model_forward_f32: the same entries in the same order, same bits)
+        block = getattr(prep, "block", None)
+        if block is None:
+            block = prep.block = ops.ModelBlock(prep)
+        return one_call(block, views, x, e_raw, logits)
     h = encode_nodes(ops, views, x, prep.enc_node)
     e = encode_edges(ops, prep, views, e_raw)
     scratch = {}
-    pipelined = (exchange is None and n_own is None and getattr(ops, "side_stream", None) is not None and PIPELINE_CHUNKS > 1
-                 and h.shape[0] >= PIPELINE_MIN_NODES)
     P = None
     for i, lw in enumerate(prep.layers):
         if exchange is not None:

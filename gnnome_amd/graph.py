@@ -33,10 +33,11 @@ class _Entry:
     """What is cached per graph object: the views over the caller's numbering, the views over renumbered nodes, and what "auto"
     decided for this graph (None: not looked at yet).  Callers that ask for "input" (CapturedForward, the layer-level API, features.*)
     and a model that renumbers no longer evict each other."""
-    __slots__ = ("input", "renumbered", "auto", "order_ms")
+    __slots__ = ("input", "renumbered", "auto", "order_ms", "auto_calls")
 
     def __init__(self):
         self.input = self.renumbered = self.auto = self.order_ms = None
+        self.auto_calls = 0   # how often "auto" has been asked about this object: the order is looked for from the SECOND time on
 
 
 def _usable(hit, graph, device):
@@ -54,8 +55,9 @@ def views_for(graph, device, node_order="input"):
     node_order ("input" | "locality" | "auto"; `model.node_order`, default "auto" since round 5): "locality" builds the views over
     nodes renumbered by gnnome_amd.node_order.locality_order - for graphs whose ids do not follow the layout (graph_parser.py:174-181
     numbers reads in S-line order) and that are scored or trained on more than once: the order costs tens of forwards to compute;
-    "auto" does so only for cacheable graph objects of at least AUTO_MIN_NODES nodes whose mean edge span says the ids are shuffled
-    (one device reduction + one host sync per graph object, remembered), and keeps the renumbering only if it shortened the edges.
+    "auto" does so only for cacheable graph objects of at least AUTO_MIN_NODES nodes that are handed in a SECOND time and whose mean edge
+    span says the ids are shuffled (one device reduction + one host sync per graph object, remembered), and keeps the renumbering only if
+    it shortened the edges; the first call of an object runs in the caller's numbering.
     Callers never see the renumbering (GraphViews.node_perm)."""
     if node_order not in NODE_ORDERS:
         raise ValueError(f"node_order={node_order!r} not in {NODE_ORDERS}")
@@ -73,12 +75,21 @@ def views_for(graph, device, node_order="input"):
         except TypeError:  # not weak-referenceable
             entry = None
     if entry is not None:
+        if node_order == "auto":
+            entry.auto_calls += 1
+            if entry.auto is None and entry.auto_calls < 2:
+                # a graph object seen for the first time is scored in the caller's numbering: the reference's loops build a fresh object per
+                # epoch / per cluster (train.py:96,311-313,336) and inference.py:440 scores each graph once - the order costs tens of forwards
+                # and such objects never amortise it.  An object that comes back is worth the look.
+                node_order = "input"
         want = node_order if node_order != "auto" else entry.auto
         hit = entry.input if want == "input" else entry.renumbered if want == "locality" else None
         if _usable(hit, graph, device):
             if hit._bad is not None:   # a graph whose deferred range check failed stays refused on every later call
                 raise IndexError(hit._bad)
             return hit
+        if hit is not None:   # the object changed under its cached views (edge count, node count, device): what "auto" decided was about another graph
+            entry.input = entry.renumbered = entry.auto = entry.order_ms = None
     src, dst, n = edge_list(graph)
     src = src.to(device=device, dtype=torch.int32).contiguous()
     dst = dst.to(device=device, dtype=torch.int32).contiguous()
@@ -91,6 +102,11 @@ def views_for(graph, device, node_order="input"):
         else:
             perm, info = order.auto_order(cs, cd, n, AUTO_SPAN_FRACTION)
             order_ms = info.get("order_ms")
+    if node_order == "auto" and perm is None and entry is not None and _usable(entry.input, graph, device):
+        entry.auto, entry.order_ms = "input", order_ms   # decided: the caller's numbering stays - and so do the views the first call built
+        if entry.input._bad is not None:
+            raise IndexError(entry.input._bad)
+        return entry.input
     views = GraphViews(src, dst, n, validate="lazy", node_perm=perm)   # range check deferred: engine.model_forward / train_forward
     if entry is not None:
         if perm is None:

@@ -81,7 +81,7 @@ class GraphViews:
     """In-edge / out-edge orderings of one edge list (see include/gnnome_hip.h, "graph views")."""
 
     __slots__ = ("num_nodes", "num_edges", "in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst", "device",
-                 "transposed", "_range", "_bad", "node_perm", "node_gather", "_stream", "__weakref__")
+                 "transposed", "_range", "_bad", "node_perm", "node_gather", "_stream", "_c_block", "__weakref__")
 
     def __init__(self, src, dst, num_nodes, validate="now", node_perm=None):
         """node_perm (int64[N], optional): the views are built over RENUMBERED nodes, node_perm[caller's id] = internal id
@@ -108,7 +108,7 @@ class GraphViews:
                 self.check_range()
         self.num_nodes, self.num_edges, self.device, self.transposed = n, e, dev, False
         self.node_perm = self.node_gather = None
-        self._stream = None
+        self._stream = self._c_block = None
         if node_perm is not None:
             node_perm = node_perm.to(device=dev, dtype=torch.int64)
             if node_perm.numel() != n:
@@ -161,6 +161,7 @@ class GraphViews:
             if k != "__weakref__":
                 setattr(r, k, getattr(self, k))
         r.transposed = not self.transposed
+        r._c_block = None
         return r
 
 
@@ -273,8 +274,41 @@ def encode(x, W1, b1, W2, b2, gather=None, rows=None):
     return out
 
 
-def linear(A, W, bias, out=None, accumulate=False):
-    """out[M,Nout] = A @ W.T + bias on the fp32 matrix cores (accumulate: out += ...).  A, W, out may be row-strided."""
+PLANES_LINEAR = _os.environ.get("GNNOME_PLANES_LINEAR", "1") != "0"   # the round-6 node-projection kernel (csrc/node_project.hip); 0: round 5's routes
+
+
+def planes_supported(K, Nout):
+    """Shapes gnnome_linear_planes_f32 is built for (the node projections: K = H in {128, 256}, Nout = 5H or 2 hs)."""
+    return K in (128, 256) and Nout % (64 if K == 128 else 32) == 0 and 0 < Nout <= 1536
+
+
+def weight_planes(W):
+    """The two fp16 planes of W[Nout, K] in MFMA fragment order (gnnome_weight_planes_f16): what `linear(..., planes=)` multiplies by.
+    Made once per weight matrix - engine.Prepared keeps them beside Wcat; `linear` makes them per call when it is not given any."""
+    lib = _lib.load()
+    W, ldw = _rows(W, "weight_planes.W")
+    Nout, K = W.shape
+    planes = torch.empty(Nout * K * 2, dtype=torch.float16, device=W.device)
+    with _on(W.device):
+        _lib.check(lib.gnnome_weight_planes_f16(_ptr(W), ldw, Nout, K, _ptr(planes), _stream(W.device)), "weight_planes_f16")
+    return planes
+
+
+def _planes_route(A, lda, W, ldw, out, ldc, accumulate, given):
+    """Whether this product runs on gnnome_linear_planes_f32.  Without planes from the caller: exactly the shapes round 4 / 5 sent to the
+    fp16x3 edge-tile kernels (whole 128-column blocks: K = 128 with Nout >= 256, K = 256) - the node projections; a narrower product (the
+    scorer's node halves at H = 128, the backward's transposed products) keeps its bf16x6 kernel unless the caller hands in planes."""
+    K, Nout = A.shape[1], W.shape[0]
+    shape = planes_supported(K, Nout) and (given or (Nout % 128 == 0 and (K == 256 or Nout >= 256)))
+    return (PLANES_LINEAR and shape and not accumulate and _TUNING.get(10, 0) == 0 and _TUNING.get(2, 0) in (0, 9, 20) and A.shape[0] > 0
+            and lda % 4 == 0 and ldw % 4 == 0 and ldc % 4 == 0 and A.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
+            and out.data_ptr() % 16 == 0 and A.data_ptr() != out.data_ptr())
+
+
+def linear(A, W, bias, out=None, accumulate=False, planes=None):
+    """out[M,Nout] = A @ W.T + bias on the matrix cores, fp32-faithful (accumulate: out += ...).  A, W, out may be row-strided.
+    The node projections' shapes (planes_supported) run on gnnome_linear_planes_f32 from W's fp16x3 planes - `planes` if the
+    caller keeps them (weight_planes(W); they must belong to W), otherwise made here."""
     lib = _lib.load()
     A, lda = _rows(A, "linear.A")
     W, ldw = _rows(W, "linear.W")
@@ -283,10 +317,95 @@ def linear(A, W, bias, out=None, accumulate=False):
     if out is None:
         out = torch.empty((M, Nout), dtype=torch.float32, device=A.device)
     out, ldc = _rows(out, "linear.out")
+    if _planes_route(A, lda, W, ldw, out, ldc, accumulate, planes is not None):
+        if planes is None:
+            planes = weight_planes(W)
+        with _on(A.device):
+            _lib.check(lib.gnnome_linear_planes_f32(_ptr(A), M, K, lda, _ptr(planes), _ptr(bias), Nout, _ptr(out), ldc, _stream(A.device)),
+                       "linear_planes_f32")
+        return out
     with _on(A.device):
         fn = lib.gnnome_linear_acc_f32 if accumulate else lib.gnnome_linear_f32
         _lib.check(fn(_ptr(A), M, K, lda, _ptr(W), ldw, _ptr(bias), Nout, _ptr(out), ldc, _stream(A.device)), "linear_f32")
     return out
+
+
+def _dptr(t):
+    return t.data_ptr() if t is not None and t.numel() > 0 else None
+
+
+class ModelBlock:
+    """A model's prepared parameters as gnnome_model_forward_f32 takes them (gnnome_model_params + its host array of gnnome_layer_params).
+    Holds references to every tensor it points at."""
+
+    def __init__(self, prep):
+        pw = prep.predictor
+        self.keep = [prep.enc_node, prep.enc_edge, prep.layers, pw]
+        n = len(prep.layers)
+        self.layers = (_lib.LayerParams * max(n, 1))()
+        for lp, lw in zip(self.layers, prep.layers):
+            for name in ("Wcat", "bcat", "W3", "b3", "scale_e", "shift_e", "scale_h", "shift_h"):
+                t = getattr(lw, name)
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                    raise TypeError(f"model_forward: layer tensor {name} must be a contiguous CUDA float32 tensor")
+                setattr(lp, name, _dptr(t))
+            lp.Wcat_planes = _dptr(lw.planes)
+            lp.norm_kind, lp.reference_order = int(lw.norm), int(bool(lw.ref))
+        m = self.params = _lib.ModelParams()
+        m.hidden, m.num_layers, m.score_hidden = prep.hidden, n, pw["hs"]
+        (W1, b1, W2, b2), (V1, c1, V2, c2) = prep.enc_node, prep.enc_edge
+        m.hidden_ne, m.node_features, m.edge_features = W1.shape[0], W1.shape[1], V1.shape[1]
+        if V1.shape[0] != W1.shape[0]:
+            raise ValueError("model_forward: the two encoders share hidden_ne (models/full_graph.py:13-16)")
+        m.node_W1, m.node_b1, m.node_W2, m.node_b2 = (_dptr(t) for t in (W1, b1, W2, b2))
+        m.edge_W1, m.edge_b1, m.edge_W2, m.edge_b2 = (_dptr(t) for t in (V1, c1, V2, c2))
+        m.layers_host = ctypes.cast(self.layers, ctypes.POINTER(_lib.LayerParams))
+        W1e = pw["W1_e"]
+        if W1e.stride(1) != 1:
+            raise ValueError("model_forward: predictor W1's edge block must have contiguous rows")
+        m.W_nodes, m.W_nodes_planes, m.b_nodes = _dptr(pw["W_nodes"]), _dptr(pw.get("planes")), _dptr(pw["b_nodes"])
+        m.W1e, m.ld_w1e = _dptr(W1e), W1e.stride(0)
+        m.W2, m.b2, m.W3, m.b3 = (_dptr(pw[k]) for k in ("W2", "b2", "W3", "b3"))
+
+
+def _views_block(views):
+    blk = getattr(views, "_c_block", None)
+    if blk is None:
+        blk = _lib.Views()
+        blk.num_nodes, blk.num_edges = views.num_nodes, views.num_edges
+        for name in ("in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst"):
+            setattr(blk, name, _dptr(getattr(views, name)))
+        blk.node_gather = _dptr(getattr(views, "node_gather", None))
+        blk.transposed = int(bool(views.transposed))
+        try:
+            views._c_block = blk
+        except AttributeError:   # duck-typed views that do not take attributes: built per call
+            pass
+    return blk
+
+
+_WS_BYTES = {}
+
+
+def model_forward(block, views, x, e_raw, logits=None):
+    """models/full_graph.py:22-30 as ONE library call (gnnome_model_forward_f32): x[N, node_features], e_raw[E, edge_features] contiguous CUDA
+    float32 in the caller's numbering -> logits[E] in edge-id order.  `block` = ModelBlock(prepared parameters)."""
+    lib = _lib.load()
+    dev = x.device
+    m = block.params
+    key = (views.num_nodes, views.num_edges, m.hidden, m.score_hidden)
+    need = _WS_BYTES.get(key)
+    if need is None:
+        n = ctypes.c_size_t(0)
+        _lib.check(lib.gnnome_model_forward_workspace_bytes(views.num_nodes, views.num_edges, m.hidden, m.score_hidden, ctypes.byref(n)), "model_forward_workspace_bytes")
+        need = _WS_BYTES[key] = n.value
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)   # (torch's blocks are 512-byte aligned)
+    if logits is None:
+        logits = torch.empty(views.num_edges, dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.check(lib.gnnome_model_forward_f32(ctypes.byref(m), ctypes.byref(_views_block(views)), _ptr(x), _ptr(e_raw), _ptr(logits), _ptr(ws), need,
+                                                _stream(dev)), "model_forward_f32")
+    return logits
 
 
 def edge_gate(e, B1h, B2h, views, W3, norm_kind, scale, shift, out=None, num_edges=None):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 14
+#define GNNOME_ABI_VERSION 15
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -131,6 +131,18 @@ int gnnome_linear_f32(const float* A, int64_t M, int K, int lda, const float* W,
 /* C += A*W^T + bias: the residual form the backward uses (d e_in = d e' + dxe*W3; dh = dh_in + dP*Wcat). */
 int gnnome_linear_acc_f32(const float* A, int64_t M, int K, int lda, const float* W, int ldw, const float* bias,
                           int Nout, float* C, int ldc, void* stream);
+
+/* Round 6 - the node projection with PREPARED weights (gated_gcn_full.py:91-96 as one GEMM over the row-concatenated A_1 | A_2 | A_3 | B_1 | B_2;
+ * score_predictor.py:13-14's node halves): gnnome_weight_planes_f16 splits W[Nout, K] ONCE into the two fp16 planes of the fp16x3 arithmetic
+ * (see gnnome_linear_f32), laid out in MFMA fragment order as 16 KB chunks [Nout / 32][K / 128][8 k steps][2 planes][64 lanes][8 halves] =
+ * Nout * K * 4 bytes at `planes` (256-byte aligned); gnnome_linear_planes_f32 computes C[M, Nout] = A W^T + bias from them
+ * (csrc/node_project.hip): a wave keeps its 32 rows of A as planes in registers for every output column, the chunks of W arrive from L2 in an
+ * LDS ring by LDS-DMA, 16-byte row pieces leave straight from the accumulators.  K in {128, 256}, Nout % 32 == 0, Nout <= 2048; lda, ldc % 4 == 0,
+ * A, C 16-byte aligned, C must not alias A; bias may be NULL.  A row's bits depend on that row and W alone (not on M).  Same operand range as
+ * every fp16x3 product: an |element| >= 65504 makes its output row NaN. */
+int gnnome_weight_planes_f16(const float* W, int ldw, int Nout, int K, void* planes, void* stream);
+int gnnome_linear_planes_f32(const float* A, int64_t M, int K, int lda, const void* planes, const float* bias, int Nout, float* C,
+                             int ldc, void* stream);
 
 /* ---- fused edge gate ----------------------------------------------------------------------------
  * For every sorted position p:
@@ -261,6 +273,65 @@ int gnnome_edge_score_f32(const float* e, int64_t num_edges, int hidden, int hid
                           const int32_t* srt_dst, const int32_t* srt_eid, const float* W1e, int ldw1,
                           const float* W2, const float* b2, const float* W3, const float* b3, float* logits,
                           float* z1_out /* NULL, or [E,hs]: relu(z1) kept for the backward */, void* stream);
+
+/* ---- the whole eval forward as ONE call (round 6) ---------------------------------------------------
+ * models/full_graph.py:22-30 - `x = linear2_node(relu(linear1_node(x))); e = linear2_edge(relu(linear1_edge(e)));
+ * x, e = gnn(graph, x, e); scores = predictor(graph, x, e)` - i.e. what inference.py:440 calls once per graph, enqueued from C on one
+ * stream: encoders -> num_layers x (node projection, edge gate, gated aggregation + node update: layers/processor.py:16-19 over
+ * gated_gcn_full.py:84-142) -> score_predictor.py:12-24.  It calls the per-kernel entries above in exactly the order
+ * gnnome_amd/engine.py::run_stack calls them (same kernels, same bits; tests/test_model_forward_entry.py), so a caller that scores each graph
+ * once (where a hipGraph replay does not help) pays one host call instead of ~30.  No allocation, no host synchronisation, capturable.
+ *   gnnome_layer_params: one SymGatedGCN layer with eval semantics - Wcat = rows A_1 | A_2 | A_3 | B_1 | B_2 (gated_gcn_full.py:29-33,91-96),
+ *     bcat their biases (not reference_order: B_3's bias added to the B_2 block, it rides on the B2h rows), Wcat_planes =
+ *     gnnome_weight_planes_f16(Wcat) or NULL, W3 / b3 = B_3 (:34,97), norm_kind + scale / shift = bn_e and bn_h folded as the fused
+ *     kernels take them (:37-42,106,132); reference_order != 0: the layer's dense products in the reference's order of evaluation
+ *     (gnnome_linear_ref_f32 / gnnome_edge_gate_ref_f32)
+ *   gnnome_model_params: encoders (models/full_graph.py:13-16), layers (a HOST array), predictor with W1 split as the scorer takes it:
+ *     W_nodes [2 hs, H] = W1's x[src] block over its x[dst] block, b_nodes = [0 | b1], W1e [hs, H] = W1's e block (score_predictor.py:13)
+ *   gnnome_views: the arrays of gnnome_build_graph_views; node_gather: NULL, or the row of x each node of the views' numbering reads
+ *     (views over renumbered nodes); transposed != 0: the views describe dgl.reverse(g) (train.py:165) - src / dst roles swapped
+ *   workspace: gnnome_model_forward_workspace_bytes(...) bytes, 256-byte aligned; logits [E] in EDGE-ID order (what the model returns,
+ *     squeezed).  hidden in {64, 128, 256}, score_hidden in {32, 64, 128}: narrower models are zero-padded by the caller (engine.Prepared). */
+typedef struct gnnome_layer_params {
+    const float* Wcat;
+    const void* Wcat_planes;
+    const float* bcat;
+    const float* W3;
+    const float* b3;
+    const float* scale_e;
+    const float* shift_e;
+    const float* scale_h;
+    const float* shift_h;
+    int32_t norm_kind;
+    int32_t reference_order;
+} gnnome_layer_params;
+
+typedef struct gnnome_model_params {
+    int32_t hidden, hidden_ne, num_layers, score_hidden, node_features, edge_features;
+    const float *node_W1, *node_b1, *node_W2, *node_b2;   /* linear1_node [hidden_ne, node_features], linear2_node [hidden, hidden_ne] */
+    const float *edge_W1, *edge_b1, *edge_W2, *edge_b2;   /* linear1_edge, linear2_edge */
+    const gnnome_layer_params* layers_host;                /* [num_layers], host memory */
+    const float* W_nodes;
+    const void* W_nodes_planes;                            /* gnnome_weight_planes_f16(W_nodes) or NULL */
+    const float* b_nodes;
+    const float* W1e;
+    int32_t ld_w1e, reserved;
+    const float *W2, *b2, *W3, *b3;                        /* predictor.W2 [32, hs], W3 [32], biases */
+} gnnome_model_params;
+
+typedef struct gnnome_views {
+    int64_t num_nodes, num_edges;
+    const int32_t *in_ptr, *srt_src, *srt_dst, *srt_eid, *out_ptr, *out_pos, *out_dst;
+    const int32_t* node_gather;
+    int32_t transposed, reserved;
+} gnnome_views;
+
+/* Measurement only (bench.py's live `roofline`): four hipEvent_t (as void*) that every following gnnome_model_forward_f32 of the calling thread
+ * records on its stream around layer `layer`'s edge-gate launch (start, stop) and its aggregation launch (start, stop); NULLs / layer < 0: off. */
+int gnnome_debug_forward_events(void* gate_start, void* gate_stop, void* aggregate_start, void* aggregate_stop, int layer);
+int gnnome_model_forward_workspace_bytes(int64_t num_nodes, int64_t num_edges, int hidden, int score_hidden, size_t* bytes_host);
+int gnnome_model_forward_f32(const gnnome_model_params* params_host, const gnnome_views* views_host, const float* x, const float* e_raw,
+                             float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ================================================================================================
  * Training step (train.py:138-145 + :328-330: forward in train mode, BCE-with-logits, loss.backward()).

@@ -48,7 +48,7 @@ def encode(x, W1, b1, W2, b2, gather=None, rows=None):
     return torch.relu(x @ W1.t() + b1) @ W2.t() + b2
 
 
-def linear(A, W, bias, out=None, accumulate=False):
+def linear(A, W, bias, out=None, accumulate=False, planes=None):   # planes: the HIP backend's prepared form of W, ignored here
     y = A @ W.t()
     if bias is not None:
         y = y + bias

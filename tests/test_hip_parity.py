@@ -134,7 +134,7 @@ def test_linear(m, k, nout):
     A2 = torch.zeros(m, k)
     A2[torch.arange(m), torch.arange(m) % k] = 1.0
     got2 = ops.linear(A2.to(dev()), W.to(dev()), None)
-    if (k == 128 and nout % 128 == 0 and nout >= 256) or (k == 256 and nout % 128 == 0):   # the fp16x3 routes (edge_tile_f16.hip, k_edge_gate_pl<.., F16>): 1.0 * (w1 + w2 / 2048)
+    if (k == 128 and nout % 128 == 0 and nout >= 256) or (k == 256 and nout % 128 == 0):   # the fp16x3 route (node_project.hip): 1.0 * (w1 + w2 / 2048)
         assert torch.allclose(got2.cpu(), W.t()[torch.arange(m) % k], rtol=2.0 ** -21, atol=1e-9)   # is w to 2^-22, not bit for bit
     else:
         assert torch.equal(got2.cpu(), W.t()[torch.arange(m) % k])
@@ -144,8 +144,8 @@ def test_linear(m, k, nout):
     try:  # other kernels behind the same entry point: tile kernel (1), exact-fp32 weight-stationary (2), bf16x6 with LDS-staged A (3)
         ops.set_tuning(2, 5 if k == 128 else 4)   # the streaming kernel at any size
         stream = ops.linear(A.to(dev()), W.to(dev()), b.to(dev()))
-        for variant in (1, 2, 3, 7, 8, 9):   # 7 / 8: row-major 16-byte stores through an LDS tile / by in-register quad transposes
-            ops.set_tuning(2, variant)       # 9: at K = 128 the plane-form kernel (edge_gate_bf.hip mode 4) at any row count
+        for variant in (1, 2, 3, 7, 8, 10, 9):   # 7 / 8: row-major 16-byte stores through an LDS tile / by in-register quad transposes
+            ops.set_tuning(2, variant)       # 10: rounds 4-5's fp16x3 edge-tile kernels as the projection (edge_gate_bf.hip / edge_tile_f16.hip mode 4); 9: the default route by name
             _assert_close(ops.linear(A.to(dev()), W.to(dev()), b.to(dev())), want, scale=float(k) ** 0.5 * 4)
             if variant in (7, 8) and k in (64, 128) and nout % 64 == 0:   # the same arithmetic as the streaming kernel: the same bits
                 assert torch.equal(ops.linear(A.to(dev()), W.to(dev()), b.to(dev())), stream)

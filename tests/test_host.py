@@ -56,6 +56,22 @@ def test_argument_validation_without_a_gpu():
         _lib.check(rc, "edge_gate")
 
 
+def test_model_forward_entry_validates_its_arguments_without_a_gpu():
+    """gnnome_model_forward_f32 (the whole eval forward as one call, include/gnnome_hip.h): sizes and parameter blocks are checked before
+    anything is enqueued; the compute side is tests/test_model_forward_entry.py (-m gpu)."""
+    lib = _lib.load()
+    need = ctypes.c_size_t(0)
+    assert lib.gnnome_model_forward_workspace_bytes(1000, 10000, 128, 64, ctypes.byref(need)) == 0
+    assert need.value >= 4 * (1000 * 128 * 7 + 10000 * 128 + 1000 * 128)
+    assert lib.gnnome_model_forward_f32(None, None, None, None, None, None, 0, None) == -1
+    m, v = _lib.ModelParams(), _lib.Views()
+    m.hidden, m.score_hidden, m.num_layers = 100, 64, 0
+    assert lib.gnnome_model_forward_f32(ctypes.byref(m), ctypes.byref(v), None, None, None, None, 0, None) == -1 and b"hidden=100" in lib.gnnome_last_error()
+    m.hidden = 128
+    v.num_nodes, v.num_edges = 10, 10
+    assert lib.gnnome_model_forward_f32(ctypes.byref(m), ctypes.byref(v), None, None, None, None, 0, None) == -3 and b"workspace" in lib.gnnome_last_error()
+
+
 def test_module_contract_matches_shipped_weights(shipped_weights):
     m = gnnome_amd.models.SymGatedGCNModel(2, 2, 64, 16, 8, 64, "batch", dropout=0.2)
     assert list(m.state_dict().keys()) == list(shipped_weights.keys())

@@ -190,8 +190,11 @@ def test_auto_is_the_default_and_the_cache_keeps_both_numberings():
             assert info["span_after"] > 0.5 * info["span_before"]       # the order ran and was dropped: nothing to find
         G = obj(g)
         x, ef = degree_features(g["src"], g["dst"], n).to(dev()), g["e"].to(dev())
+        first = m(G, x, ef)
+        assert ggraph.auto_decision(G)[0] is None        # a graph object seen once runs in the caller's numbering (single-use objects never amortise the order)
         out = m(G, x, ef)
         assert ggraph.auto_decision(G)[0] == want
+        assert (torch.sigmoid(out) - torch.sigmoid(first)).abs().max().item() < 1e-5
         v_auto = ggraph.views_for(G, dev(), node_order="auto")
         assert (v_auto.node_perm is not None) == (want == "locality")
         v_in = ggraph.views_for(G, dev())                       # an "input" caller (CapturedForward, the layer-level API, features.*)
