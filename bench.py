@@ -858,6 +858,18 @@ def main():
             res["tuning"] = args.tuning   # not the shipped defaults
         if "scaling_reference" in extras:
             res["speedup_over_one_gpu_same_graph"] = extras["scaling_reference"]["ms_per_step"] / ms
+            if world > 1 and "exchange" in extras:
+                # DESIGN.md section 5's prediction next to what was measured, so that one SCALE record confirms or falsifies it by itself: rank 0's
+                # share of the edges at the one-GPU rate + the per-layer halo exchanges and the logits gather at 0.1 ms each (what a small RCCL
+                # collective over xGMI is ASSUMED to cost; measured alone: exchange.ms_per_exchange_alone)
+                t1, share, n_coll = extras["scaling_reference"]["ms_per_step"], plan.views.num_edges / e, 8 + 1
+                pred = t1 * share + n_coll * 0.1
+                res["prediction"] = {
+                    "model": "one-GPU ms x (rank 0's local edges / E) + (8 halo exchanges + 1 logits all_gather) x 0.1 ms, exchanges not overlapped",
+                    "one_gpu_ms": t1, "rank0_edge_share": share, "collectives_per_forward": n_coll, "assumed_ms_per_small_collective": 0.1,
+                    "predicted_ms": pred, "predicted_speedup": t1 / pred, "measured_ms": ms, "measured_over_predicted": ms / pred,
+                    "measured_ms_per_exchange_alone": extras["exchange"]["ms_per_exchange_alone"],
+                    "valid": "only over RCCL (exchange.rccl_ranks == n_gpus); a host-staged gloo run is a plumbing check"}
         if timed and kt.events[timed[0]]:
             gate_ms, gate_n = kt.mean_ms(timed[0])
             gate_flops = 2.0 * e_gate * hidden * hidden

@@ -103,6 +103,7 @@ SIGNATURES = {
     "gnnome_bfs_levels": [_p, _p, _l, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_hem_propose": [_p, _p, _p, _p, _p, _l, _i, _p, _p],
     "gnnome_kway_gains": [_p, _p, _p, _p, _l, _p, _p, _p],
+    "gnnome_greedy_growing_host": [_p, _p, _p, _p, _l, _i, _p],
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 

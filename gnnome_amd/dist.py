@@ -331,7 +331,7 @@ class HaloExchange:
     """h[n_own:] <- owners' rows, via one packed all_to_all_single (RCCL on GPUs, gloo in the CPU tests)."""
 
     def __init__(self, part, ops, group=None):
-        self.part, self.ops, self.group, self.work, self._keep = part, ops, group, None, None
+        self.part, self.ops, self.group, self.work, self._keep, self._bwd = part, ops, group, None, None, None
 
     def start(self, h):
         p = self.part
@@ -350,11 +350,28 @@ class HaloExchange:
         """Backward of start/finish: the halo rows of dh return to their owners, which add them to their own rows
         (one peer's block at a time: within a block the rows are distinct, so the sum order is fixed), then
         dh[n_own:] = 0."""
+        self.transpose_start(dh)
+        self.transpose_finish(dh)
+
+    def transpose_start(self, dh):
+        """First half of `transpose`: the halo rows leave (RCCL: asynchronously, on the collective's stream).  Nothing may WRITE dh until
+        transpose_finish; kernels that do not touch dh - the layer's weight gradients - run underneath."""
         p = self.part
         if _alone(p.world):
             return
         got = torch.empty((int(p.send_idx.numel()), dh.shape[1]), dtype=torch.float32, device=dh.device)
-        all_to_all_rows(got, dh[p.n_own:].contiguous(), p.send_counts, p.recv_counts, self.group)
+        sent = dh[p.n_own:].contiguous()   # (a view: dh is contiguous)
+        work = all_to_all_rows(got, sent, p.send_counts, p.recv_counts, self.group, async_op=True)
+        self._bwd = (work, got, sent)
+
+    def transpose_finish(self, dh):
+        p = self.part
+        if _alone(p.world) or getattr(self, "_bwd", None) is None:
+            return
+        work, got, _ = self._bwd
+        self._bwd = None
+        if work is not None:
+            work.wait()
         at = 0
         for cnt in p.send_counts:
             if cnt:
@@ -393,6 +410,12 @@ class PartitionShard:
 
     def halo_bwd(self, dh):
         self._xchg.transpose(dh)
+
+    def halo_bwd_start(self, dh):
+        self._xchg.transpose_start(dh)
+
+    def halo_bwd_finish(self, dh):
+        self._xchg.transpose_finish(dh)
 
     def combine_stats(self, mean, var, rows):
         if self.alone:

@@ -930,7 +930,12 @@ def segment_sum2(X, views, num_nodes, out_in=None, out_out=None, amax=None):
     out_out = mk() if out_out is None else out_out
     out_in, ld_in = _rows(out_in, "segment_sum2.out_in")
     out_out, ld_out = _rows(out_out, "segment_sum2.out_out")
-    if amax is not None and not x16 and num_nodes > 0:   # (amax: raised to max |out_in|, |out_out|)
+    if amax is not None and x16:
+        # a PRODUCER that cannot raise the slot must say so: a consumer (wgrad_blocks / linear_blocks with the same amax) would scale the
+        # blocks by a maximum that leaves these sums out - fp16x3 operands beyond 65504, NaN gradients.  The consumers' own
+        # fall-backs (a width they are not built for) are safe: unscaled bf16x6 needs no maximum.
+        raise TypeError("segment_sum2(amax=) is built for float32 rows: with bfloat16 rows pass amax=None (and keep the consumers on bf16x6)")
+    if amax is not None and num_nodes > 0:   # (amax: raised to max |out_in|, |out_out|)
         _call("gnnome_segment_sum2_amax_f32", X.device, _ptr(X), W, _ptr(views.in_ptr), _ptr(views.out_ptr), _ptr(views.out_pos), num_nodes,
               _ptr(out_in), ld_in, _ptr(out_out), ld_out, _ptr(_amax_slot(amax, X.device, "segment_sum2")))
         return out_in, out_out

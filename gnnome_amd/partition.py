@@ -126,6 +126,21 @@ class _HipKernels:
         return best_part, gain
 
 
+def _greedy_growing_host(ptr, adj, wgt, vwgt, k):
+    """_greedy_growing_py in the library (gnnome_greedy_growing_host: host memory in, host memory out, no launch)."""
+    import ctypes
+    lib = _lib.load()
+    p, a, w, vw = (t.detach().to("cpu", torch.int32).contiguous() for t in (ptr, adj, wgt, vwgt))
+    n = vw.numel()
+    label = torch.empty(n, dtype=torch.int32)
+    as_p = lambda t: ctypes.c_void_p(t.data_ptr() if t.numel() else None)  # noqa: E731
+    _lib.check(lib.gnnome_greedy_growing_host(as_p(p), as_p(a), as_p(w), as_p(vw), n, int(k), as_p(label)), "greedy_growing_host")
+    return label
+
+
+_HipKernels.greedy_growing = staticmethod(_greedy_growing_host)
+
+
 def _hem_level(ptr, adj, wgt, vwgt, max_vwgt, rounds=8, kernels=_HipKernels):
     """Heavy-edge matching by proposals and handshakes -> cmap int64[n] (coarse id of every vertex), nc."""
     n, dev = ptr.numel() - 1, ptr.device
@@ -158,8 +173,9 @@ def _contract(ptr, adj, wgt, vwgt, cmap, nc):
     return cptr.int(), (keys % nc).int().contiguous(), w.int().contiguous(), cvw.int()
 
 
-def _greedy_growing(ptr, adj, wgt, vwgt, k):
-    """The coarsest graph (a few thousand vertices) on the host, as METIS does it: k - 1 regions grown one after the other from the free
+def _greedy_growing_py(ptr, adj, wgt, vwgt, k):
+    """(The statement of gnnome_greedy_growing_host - csrc/partition.hip runs it in C++, same labels bit for bit; the checker backend of the CPU
+    tests runs this one.)  The coarsest graph (a few thousand vertices) on the host, as METIS does it: k - 1 regions grown one after the other from the free
     vertex with the smallest id, always taking the free vertex most heavily connected to the region (ties: the one that became a neighbour of
     the region first - breadth-first, compact regions; by smaller id a grid is cut into strips), until the region holds its share of the
     weight; the rest is the last part."""
@@ -206,10 +222,15 @@ def _cut_weight(ptr, adj, wgt, label):
 def _refine(ptr, adj, wgt, vwgt, label, k, max_pw, passes=12, kernels=_HipKernels):
     """Greedy k-way boundary refinement (Karypis & Kumar, JPDC 1998, section 4) as parallel passes: gains from the kernel, then per target part the
     candidates in order of decreasing gain as far as the part's weight allows; a pass moves vertices only towards higher (odd passes) or
-    lower (even passes) part ids, so two neighbours never swap; the labelling with the smallest cut seen is what is returned."""
+    lower (even passes) part ids, so two neighbours never swap; what is returned is the best labelling seen - feasible (no part above max_pw) before smaller cut."""
     n, dev = label.numel(), label.device
     vw = vwgt.long()
-    best_label, best_cut = label.clone(), _cut_weight(ptr, adj, wgt, label)
+    def excess(lab):   # weight above the limit in the heaviest part: 0 = the labelling is feasible (ufactor holds)
+        return max(0, int(torch.zeros(k, dtype=torch.int64, device=dev).scatter_add_(0, lab.long(), vw).max()) - max_pw)
+
+    # best = feasibility first, cut second (ADVICE r5: the smallest cut alone kept a greedy-growing overshoot that the balancing moves - negative
+    # gains out of an overweight part - had already repaired)
+    best_label, best_key = label.clone(), (excess(label), _cut_weight(ptr, adj, wgt, label))
     stale = 0
     for it in range(passes):
         best_part, gain = kernels.kway_gains(ptr, adj, wgt, label)
@@ -242,9 +263,9 @@ def _refine(ptr, adj, wgt, vwgt, label, k, max_pw, passes=12, kernels=_HipKernel
             continue
         label = label.clone()
         label[moved] = best_part[moved]
-        cut = _cut_weight(ptr, adj, wgt, label)
-        if cut < best_cut:
-            best_cut, best_label, stale = cut, label.clone(), 0
+        key = (excess(label), _cut_weight(ptr, adj, wgt, label))
+        if key < best_key:
+            best_key, best_label, stale = key, label.clone(), 0
         else:
             stale += 1
             if stale >= 3:
@@ -270,7 +291,7 @@ def multilevel_partition(src, dst, num_nodes, num_clusters, ufactor=1.03, kernel
         levels.append((ptr, adj, wgt, vwgt, cmap))
         ptr, adj, wgt, vwgt = _contract(ptr, adj, wgt, vwgt, cmap, nc)
     max_pw = int(ufactor * n / k) + 1
-    label = _greedy_growing(ptr, adj, wgt, vwgt, k).to(dev)
+    label = getattr(kernels, "greedy_growing", _greedy_growing_py)(ptr, adj, wgt, vwgt, k).to(dev)
     label = _refine(ptr, adj, wgt, vwgt, label, k, max_pw, kernels=kernels)
     for fptr, fadj, fwgt, fvw, cmap in reversed(levels):
         label = label[cmap].contiguous()
@@ -303,8 +324,49 @@ def _dgl_halo(src, dst, n, inner, hops):
     return torch.cat(nid), torch.cat(eids)
 
 
-def cluster_partition(graph, num_clusters, extra_cached_hops=1, device=None, method="multilevel", halo="dgl"):
-    """-> {part id: ClusterGraph}; see the module docstring.  method: "multilevel" | "region"; halo: "dgl" | "both"."""
+def _dgl_one_hop_parts(src, dst, n, label, k, device):
+    """_dgl_halo(..., hops=1) for every part at once: a part's edges are the in-edges of its inner nodes (ascending edge id), its nodes the inner
+    ones (ascending) followed by the outside sources of those edges (ascending).  Sorts over the whole graph, then slices."""
+    s_l, d_l, lab = src.long(), dst.long(), label.long()
+    part_e = lab[d_l]                                            # the part every edge belongs to
+    e_order = torch.argsort(part_e, stable=True)                 # edges by part, ascending id inside
+    e_ptr = torch.zeros(k + 1, dtype=torch.long, device=device)
+    e_ptr[1:] = torch.cumsum(torch.bincount(part_e, minlength=k), 0)
+    n_order = torch.argsort(lab, stable=True)                    # nodes by part, ascending id inside
+    n_ptr = torch.zeros(k + 1, dtype=torch.long, device=device)
+    n_ptr[1:] = torch.cumsum(torch.bincount(lab, minlength=k), 0)
+    rank = torch.empty(n, dtype=torch.long, device=device)       # a node's position among the inner nodes of its part
+    rank[n_order] = torch.arange(n, device=device) - n_ptr[lab[n_order]]
+    outside = lab[s_l] != part_e
+    keys = torch.unique(part_e[outside] * n + s_l[outside])      # (part, outside source), ascending
+    h_part, h_node = keys // n, keys % n
+    h_ptr = torch.zeros(k + 1, dtype=torch.long, device=device)
+    h_ptr[1:] = torch.cumsum(torch.bincount(h_part, minlength=k), 0)
+    n_inner = n_ptr[1:] - n_ptr[:-1]
+    pos = torch.searchsorted(keys, part_e * n + s_l)             # (meaningful where `outside`)
+    loc_src = torch.where(outside, n_inner[part_e] + pos - h_ptr[part_e], rank[s_l]).int()
+    loc_dst = rank[d_l].int()
+    e_lo, n_lo, h_lo = e_ptr.tolist(), n_ptr.tolist(), h_ptr.tolist()
+    parts = {}
+    for p in range(k):
+        ni = n_lo[p + 1] - n_lo[p]
+        if ni == 0:
+            continue
+        eid = e_order[e_lo[p]:e_lo[p + 1]]
+        nid = torch.cat([n_order[n_lo[p]:n_lo[p + 1]], h_node[h_lo[p]:h_lo[p + 1]]])
+        sub_src, sub_dst = loc_src[eid].contiguous(), loc_dst[eid].contiguous()
+        views = ops.GraphViews(sub_src, sub_dst, int(nid.numel()), validate=False)
+        sub = MaskedGraph(sub_src, sub_dst, int(nid.numel()), nid, eid, views)
+        inner = torch.zeros(int(nid.numel()), dtype=torch.bool, device=device)
+        inner[:ni] = True
+        parts[p] = ClusterGraph(sub, inner)
+    return parts
+
+
+def cluster_partition(graph, num_clusters, extra_cached_hops=1, device=None, method="multilevel", halo="dgl", one_pass=True):
+    """-> {part id: ClusterGraph}; see the module docstring.  method: "multilevel" | "region"; halo: "dgl" | "both".  one_pass: the reference's
+    own call (one hop, DGL's rule: train.py:334) cuts ALL parts out of the graph with a handful of sorts (_dgl_one_hop_parts) instead of one scan
+    of the whole graph per part (k = N / 2000 parts: hyperparameters.py:36) - same sub-graphs, same order of nodes and edges."""
     device = device or (graph.device if isinstance(graph, ops.GraphViews) else torch.device("cuda", torch.cuda.current_device()))
     src, dst, n = _edge_list_on(graph, device)
     if method == "multilevel":
@@ -317,6 +379,8 @@ def cluster_partition(graph, num_clusters, extra_cached_hops=1, device=None, met
         raise ValueError(f"halo={halo!r} not in ('dgl', 'both')")
     parts = {}
     s_l, d_l = src.long(), dst.long()
+    if halo == "dgl" and int(extra_cached_hops) == 1 and one_pass:
+        return _dgl_one_hop_parts(src, dst, n, label, int(num_clusters), device)
     for p in range(int(num_clusters)):
         inner = label == p
         if not bool(inner.any()):

@@ -50,6 +50,12 @@ class WholeGraph:
     def halo_bwd(self, dh):             # owners' dh rows += dh[n_own:], then dh[n_own:] = 0 (backward)
         pass
 
+    def halo_bwd_start(self, dh):       # the same in two halves: the rows leave ... (nothing may write dh in between)
+        pass
+
+    def halo_bwd_finish(self, dh):      # ... and are added where they belong
+        pass
+
     def combine_stats(self, mean, var, rows):   # per-rank (mean, biased var, row count) -> statistics of the union
         return mean, var
 
@@ -353,9 +359,17 @@ class _TrainStep(torch.autograd.Function):
         dh = ops.linear(dPQ, tail["W_nodes"].t().contiguous(), None)         # [n_local,H]
 
         # ---- layers, last to first (gated_gcn_full.py:82-142)
+        # the halo rows of dh travel back to their owners while the kernels that do not read dh run (round 6): the predictor's and, per layer, the
+        # weight gradients' - halo_bwd_start right after dh is complete, halo_bwd_finish where its owned rows are read next
+        split_halo = hasattr(sh, "halo_bwd_start")
+        if split_halo and saved:
+            sh.halo_bwd_start(dh)
         for li in range(len(saved) - 1, -1, -1):
             s, conv, pfx = saved[li], model.gnn.convs[li], f"gnn.convs.{li}."
-            sh.halo_bwd(dh)
+            if split_halo:
+                sh.halo_bwd_finish(dh)
+            else:
+                sh.halo_bwd(dh)
             if s["mask"] is not None:
                 dh[:n_own].copy_(ops.mul23(dh[:n_own], s["mask"], s["mask"])[0])
             # h' = relu(bn_h(v)) + h_in      (owned rows)
@@ -434,7 +448,6 @@ class _TrainStep(torch.autograd.Function):
                     dxe = torch.empty_like(de)
                     g[pfx + "bn_e.weight"], g[pfx + "bn_e.bias"] = _bn_bwd(sh, de, s["xe"], s["sc_e"], s["sh_e"], s["mean_e"], s["rstd_e"],
                                                                            sh.e_global, e_own, dxe, stats=stats_e)
-            g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"], amax=amax_dxe) if amax_dxe is not None else ops.wgrad(dxe, s["e"])
             if s["sc_e"] is None or W3t is not None:
                 ops.linear(dxe, s["W3T"] if s["W3T"] is not None else d(conv.B_3.weight).t().contiguous(), None, out=de,
                            accumulate=True)   # d e_in = d e' + dxe W3
@@ -448,20 +461,26 @@ class _TrainStep(torch.autograd.Function):
             parts[r["A1"]], parts[r["A2"]], parts[r["A3"]], parts[r["B1"]], parts[r["B2"]] = dv, sum_out, sum_in, dB1, dB2
             names = ("A_1", "A_2", "A_3", "B_1", "B_2")
             WcatT = s["WcatT"] if s["WcatT"] is not None else s["Wcat"].t().contiguous()
+            # dh first: its halo rows then travel (halo_bwd_start) under the weight gradients, which do not read it
             if hasattr(ops, "wgrad_blocks") and ops.can_use_blocks(parts):
                 # the five [N,H] gradients stay where their kernels left them: weight gradients, bias gradients (column sums of
                 # the same slabs) and dh += dP Wcat read them as column blocks
                 # (amax_nodes: every block's producer raised it - the product runs as fp16x3 on the blocks scaled by their common maximum)
+                dh = ops.linear_blocks(parts, WcatT, dh_in, accumulate=True, **({"amax": amax_nodes} if amax_nodes is not None and SCALED_NODE_DGRAD else {}))
+                if split_halo and li > 0:
+                    sh.halo_bwd_start(dh)
                 gWcat, gbcat = ops.wgrad_blocks(parts, s["h"], **({"amax": amax_nodes} if amax_nodes is not None else {}))   # [5H, H], [5H]
                 for k, name in enumerate(names):
                     g[pfx + name + ".bias"] = gbcat[k * H:(k + 1) * H]
-                dh = ops.linear_blocks(parts, WcatT, dh_in, accumulate=True, **({"amax": amax_nodes} if amax_nodes is not None and SCALED_NODE_DGRAD else {}))
             else:
+                dP = torch.cat(parts, 1)
+                dh = ops.linear(dP, WcatT, None, out=dh_in, accumulate=True)
+                if split_halo and li > 0:
+                    sh.halo_bwd_start(dh)
                 for k, name in enumerate(names):
                     g[pfx + name + ".bias"] = ops.colsum2(parts[k])[0]
-                dP = torch.cat(parts, 1)
                 gWcat = ops.wgrad(dP, s["h"])                                 # [5H, H]
-                dh = ops.linear(dP, WcatT, None, out=dh_in, accumulate=True)
+            g[pfx + "B_3.weight"] = ops.wgrad(dxe, s["e"], amax=amax_dxe) if amax_dxe is not None else ops.wgrad(dxe, s["e"])
             # every edge has exactly one destination: sum_p dxe[p] = sum_i dB2[i], no second pass over [E,H]
             g[pfx + "B_3.bias"] = g[pfx + ("B_1" if views.transposed else "B_2") + ".bias"].clone()
             for k, name in enumerate(names):

@@ -722,6 +722,12 @@ int gnnome_hem_propose(const int32_t* ptr, const int32_t* adj, const int32_t* wg
                        int64_t num_vertices, int max_vwgt, int32_t* proposal, void* stream);
 int gnnome_kway_gains(const int32_t* ptr, const int32_t* adj, const int32_t* wgt, const int32_t* label, int64_t num_vertices,
                       int32_t* best_part, int32_t* gain, void* stream);
+/* The coarsest level's initial partition (METIS's greedy graph growing), on the HOST: all pointers are host memory, nothing is launched.
+ * k - 1 regions grown one after the other from the free vertex with the smallest id, always taking the free vertex most heavily connected to the
+ * region (ties: the one that became its neighbour first), until the region holds (remaining weight) / (remaining parts); the rest is the last
+ * part.  label_host[v] in [0, num_parts).  (train.py:333: dgl.metis_partition -> METIS 5.1.0 InitKWayPartitioning; see csrc/partition.hip.) */
+int gnnome_greedy_growing_host(const int32_t* ptr_host, const int32_t* adj_host, const int32_t* wgt_host, const int32_t* vwgt_host,
+                               int64_t num_vertices, int num_parts, int32_t* label_host);
 
 #ifdef __cplusplus
 }

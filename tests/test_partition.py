@@ -75,12 +75,34 @@ def test_host_logic_of_the_multilevel_partition_on_the_checker_kernels():
     assert partition.edge_cut(g["src"], g["dst"], label) <= 1.15 * ref
 
 
+def test_greedy_growing_in_the_library_equals_its_python_statement():
+    """gnnome_greedy_growing_host (C++, host memory, no GPU needed) against partition._greedy_growing_py on weighted coarse-looking graphs: the
+    same labels, bit for bit - ties (equal connectivity) included, which is where a heap's order shows."""
+    from gnnome_amd import partition
+    rng = np.random.default_rng(4)
+    for n, deg, k in ((1, 0, 1), (50, 3, 4), (2000, 6, 16), (6000, 10, 97), (900, 4, 900)):
+        a = rng.integers(0, n, size=n * deg)
+        b = rng.integers(0, n, size=n * deg)
+        ptr, adj, wgt = partition.undirected_csr(torch.as_tensor(a, dtype=torch.int32), torch.as_tensor(b, dtype=torch.int32), n)
+        wgt = (wgt * torch.as_tensor(rng.integers(1, 4, size=wgt.numel()), dtype=torch.int32)).int()
+        # (symmetric weights are not needed by either form; equal weights everywhere would hide nothing either - ties are the point)
+        vwgt = torch.as_tensor(rng.integers(1, 5, size=n), dtype=torch.int32)
+        want = partition._greedy_growing_py(ptr, adj, wgt, vwgt, k)
+        got = partition._greedy_growing_host(ptr, adj, wgt, vwgt, k)
+        assert torch.equal(got, want), (n, deg, k)
+    src, dst, n = _grid(24)
+    ptr, adj, wgt = partition.undirected_csr(torch.as_tensor(src, dtype=torch.int32), torch.as_tensor(dst, dtype=torch.int32), n)
+    ones = torch.ones(n, dtype=torch.int32)
+    assert torch.equal(partition._greedy_growing_host(ptr, adj, wgt, ones, 9), partition._greedy_growing_py(ptr, adj, wgt, ones, 9))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,e,k", [("grid", 0, 0, 4), ("grid", 0, 0, 16), ("banded", 8000, 80000, 8), ("permuted", 8000, 80000, 8),
                                         ("banded", 20000, 200000, 20)])
 def test_multilevel_partition_against_the_oracle_scheme(kind, n, e, k):
-    """Balance within METIS's default tolerance, every part used, deterministic, and an edge cut no worse than 1.15 x the sequential
-    scheme's (best of three seeds is not taken: its median) - and far below region growing's where the ids carry no locality."""
+    """Balance within METIS's default tolerance, every part used, deterministic; the cut: optimal on grids, within 1.3 x the contiguous-range
+    cut on layout-ordered assembly graphs, below the sequential scheme's (median of three seeds) everywhere, a tenth of region growing's where
+    the ids carry no locality."""
     from gnnome_amd import partition
     dev = torch.device("cuda", 0)
     if kind == "grid":
@@ -98,12 +120,15 @@ def test_multilevel_partition_against_the_oracle_scheme(kind, n, e, k):
     ref = sorted(mo.edge_cut(src, dst, mo.partition(src.tolist(), dst.tolist(), n, k, seed=s)) for s in (1, 2, 3))[1]
     region = partition.edge_cut(ts, td, partition.grow_regions(ts, td, n, k))
     print(f"{kind} n={n} k={k}: cut {cut}, sequential scheme (median of 3 seeds) {ref}, region growing {region}")
-    assert cut <= 1.15 * ref + 8, (cut, ref)
+    # the bars that bind (the sequential restatement is a weak proxy - the device scheme cuts 2.7 x less on assembly graphs):
+    assert cut <= ref, (cut, ref)                                   # never worse than the sequential statement of the same published scheme
+    if kind == "grid":
+        assert cut == {4: 256, 16: 768}[k]                          # a 64 x 64 grid: THE optimum (two / six straight cuts, both directions)
     if kind == "permuted":
-        assert cut < 0.6 * region
+        assert cut < 0.1 * region                                   # ids without locality: region growing is lost, the matching is not
     if kind == "banded":
         ranges = torch.clamp(torch.arange(n, device=dev) * k // n, max=k - 1)
-        assert cut <= 1.6 * partition.edge_cut(ts, td, ranges)
+        assert cut <= 1.3 * partition.edge_cut(ts, td, ranges)      # layout-ordered reads: contiguous ranges are near-optimal
 
 
 @pytest.mark.gpu
@@ -140,6 +165,13 @@ def test_cluster_partition_follows_dgls_halo_rule_and_trains():
         assert torch.equal(nid[ss.cpu().long()], s_l[eid]) and torch.equal(nid[dd.cpu().long()], d_l[eid])
         total_edges += int(eid.numel())
     assert (owner >= 0).all() and total_edges == e          # with one hop every edge of the graph belongs to exactly one part
+    # all parts cut out in one pass (the default) = one scan of the graph per part (rounds 4-5), node for node and edge for edge
+    slow = partition.cluster_partition((gr["src"], gr["dst"], n), k, extra_cached_hops=1, device=dev, one_pass=False)
+    assert slow.keys() == parts.keys()
+    for p in parts:
+        a, b = parts[p], slow[p]
+        assert torch.equal(a.nid, b.nid) and torch.equal(a.eid, b.eid) and torch.equal(a.inner_node, b.inner_node)
+        assert all(torch.equal(x, y) for x, y in zip(a.edges(), b.edges()))
     # one training step on a cluster (get_bce_loss_partition, train.py:148-156)
     m = gnnome_amd.SymGatedGCNModel(2, 2, 64, 16, 2, 64, "batch").train()
     m.load_state_dict(random_state_dict(64, num_layers=2, seed=1))
