@@ -33,6 +33,8 @@ SIGNATURES = {
     "gnnome_linear_ref_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "gnnome_edge_gate_ref_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gnnome_node_aggregate_f32": [_p, _i, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
+    "gnnome_build_node_records": [_p, _p, _p, _p, _p, _l, _p, _p],
+    "gnnome_debug_node_records": [_p],
     "gnnome_node_aggregate_range_f32": [_p, _i, _l, _l, _l, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p],
     "gnnome_stream_schedule_sizes": [_l, _l, _i, ctypes.POINTER(_l), ctypes.POINTER(_sz)],
     "gnnome_build_stream_schedule": [_l, _l, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
@@ -84,6 +86,7 @@ SIGNATURES = {
     "gnnome_bn_bwd_dgrad_f32": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_bn_bwd_dgrad_amax_f32": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
     "gnnome_bn_bwd_dgrad_out_f32": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "gnnome_bn_bwd_dgrad_out_amax_f32": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
     "gnnome_bn_bwd_dgrad_x16": [_p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_bn_bwd_dgrad_out_x16": [_p, _p, _p, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "gnnome_agg_edge_bwd_stats_f32": [_p, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],

@@ -1210,7 +1210,16 @@ extern "C" int gnnome_bn_bwd_dgrad_x16(float* C, const uint16_t* X, int64_t rows
 // updated rows go to C_out != C_in (edge_gate_pl256.hip, mode 3).
 static int bn_bwd_dgrad_out_impl(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
                                  const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
-                                 const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream, bool x16);
+                                 const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream, bool x16,
+                                 unsigned* amax_bits = nullptr);
+// ... and max |dxe| left at amax_bits (round 6: gnnome_wgrad_scaled_f32 then runs B_3's [256, 256] weight gradient as fp16x3)
+extern "C" int gnnome_bn_bwd_dgrad_out_amax_f32(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
+                                                const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
+                                                const float* mean, const float* rstd, const float* W, int ldw, float* dxe, unsigned* amax_bits,
+                                                void* stream) {
+    GN_REQUIRE(amax_bits != nullptr, "bn_bwd_dgrad_out_amax: null amax_bits");
+    return bn_bwd_dgrad_out_impl(C_in, C_out, X, rows, rows_once, hidden, scale, shift, a, c1, c2, mean, rstd, W, ldw, dxe, stream, false, amax_bits);
+}
 extern "C" int gnnome_bn_bwd_dgrad_out_f32(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
                                            const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
                                            const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream) {
@@ -1224,9 +1233,11 @@ extern "C" int gnnome_bn_bwd_dgrad_out_x16(const float* C_in, float* C_out, cons
 }
 static int bn_bwd_dgrad_out_impl(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
                                  const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
-                                 const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream, bool x16) {
+                                 const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream, bool x16,
+                                 unsigned* amax_bits) {
     using namespace gnnome;
     GN_REQUIRE(rows >= 0 && hidden == 256, "bn_bwd_dgrad_out: hidden=%d (256 only; 64 / 128 update C in place: gnnome_bn_bwd_dgrad_f32)", hidden);
+    if (amax_bits != nullptr) GN_HIP(hipMemsetAsync(amax_bits, 0, sizeof(unsigned), (hipStream_t)stream));   // (before the rows == 0 return: an empty product has maximum 0)
     GN_REQUIRE(rows_once >= 0 && rows_once <= rows, "bn_bwd_dgrad_out: rows_once=%lld outside [0, rows]", (long long)rows_once);
     if (rows == 0) return GNNOME_OK;
     GN_REQUIRE(C_in && C_out && C_out != C_in && X && scale && shift && a && c1 && c2 && mean && rstd && W && dxe && dxe != C_out && dxe != C_in &&
@@ -1237,5 +1248,6 @@ static int bn_bwd_dgrad_out_impl(const float* C_in, float* C_out, const float* X
     GateBfArgs g = {};
     g.e_in = X; g.e_out = C_out; g.E = rows; g.B1h = C_in; g.ldn = hidden; g.W3 = W; g.ldw = ldw;
     g.bnb = GateBnBwd{a, c1, c2, mean, rstd, scale, shift, dxe, rows_once};
+    g.bnb.amax_bits = amax_bits;
     return gate_pl256_launch(3, g, (hipStream_t)stream, x16);
 }

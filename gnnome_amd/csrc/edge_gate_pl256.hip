@@ -90,6 +90,31 @@ __device__ __forceinline__ void split4(const f32x4 x, uint2& p1, uint2& p2, uint
 }
 __device__ __forceinline__ bf16x8_t as_bf8(const uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
+// fp16x3 planes (edge_tile_f16.hip's header): x1 = RN16(x), x2 = RN16((x - x1) 2048); and, for the one-accumulator form of mode 3, x1 2048
+typedef _Float16 pl_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 pl_h8 __attribute__((ext_vector_type(8)));
+typedef float pl_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pl_h8 as_h8(const uint4 v) { return __builtin_bit_cast(pl_h8, v); }
+__device__ __forceinline__ void split2h(const pl_f2 v, unsigned& p1, unsigned& p2, unsigned& p1x) {
+    const pl_h2 a = __builtin_convertvector(v, pl_h2);
+    const pl_f2 af = {(float)a[0], (float)a[1]};
+    const pl_f2 r = {__builtin_fmaf(af[0], -2048.f, v[0] * 2048.f), __builtin_fmaf(af[1], -2048.f, v[1] * 2048.f)};   // exact
+    p1 = __builtin_bit_cast(unsigned, a);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, pl_h2));
+    p1x = __builtin_bit_cast(unsigned, __builtin_convertvector(af * 2048.f, pl_h2));   // exact: |x| < 32 (the caller's scale), subnormal a1 included
+}
+__device__ __forceinline__ void split4h3(const f32x4 x, uint2& p1, uint2& p2, uint2& p1x) {
+    split2h(pl_f2{x[0], x[1]}, p1.x, p2.x, p1x.x);
+    split2h(pl_f2{x[2], x[3]}, p1.y, p2.y, p1x.y);
+}
+__device__ __forceinline__ void split8h(const f32x4 lo4, const f32x4 hi4, uint4& p1, uint4& p2) {
+    unsigned unused;
+    split2h(pl_f2{lo4[0], lo4[1]}, p1.x, p2.x, unused);
+    split2h(pl_f2{lo4[2], lo4[3]}, p1.y, p2.y, unused);
+    split2h(pl_f2{hi4[0], hi4[1]}, p1.z, p2.z, unused);
+    split2h(pl_f2{hi4[2], hi4[3]}, p1.w, p2.w, unused);
+}
+
 // MODE 0: e' = relu((e W3^T + B1h[src] + B2h[dst]) * scale + shift) + e    (gated_gcn_full.py:97,104-110)
 // MODE 1: xe = e W3^T + B1h[src] + B2h[dst] and its shifted column sums (training forward; a.scale = the centres, a.stats out)
 // MODE 2: C += A W^T (A = e_in, C = e_out = the rows at B1h; the backward's d e_in = d e' + dxe W3)
@@ -97,9 +122,16 @@ __device__ __forceinline__ bf16x8_t as_bf8(const uint4 v) { return __builtin_bit
 // MODE 4: C[M, 128 * num_cblocks] = A[M,256] W^T + bias (a.e_in = A with row stride a.ldn, a.e_out = C with row stride a.ld_out, a.scale = bias):
 //         the node projection [N,256] -> [N,1280] and the scorer's node halves at this width
 // X16 (MODE 3, round 4): the xe rows are read and the dxe rows written as bf16 (the product C += dxe W^T uses the unrounded dxe - common.h)
-template <int MODE, int PROBE = 0, bool X16 = false>   // PROBE (measurement only, wrong results): 1 = no MFMAs, 2 = no plane reads either
+// F16 (MODE 3, round 6): the product dxe W^T as fp16x3 in ONE accumulator.  dxe is a gradient computed right here, so its
+// scale cannot come from a maximum known beforehand: every load wave scales ITS sixteen rows of a tile by the power of two that brings their
+// largest |element| into [8, 16) and multiplies the rows of x by the inverse on the way out (rows of A scale rows of C).  Planes of A: a1,
+// a2 2^11 and a1 2^11 (exact: a1 < 16), of W: w1 and w2 2^11, so that 2^11 a w = (a1 2^11) w1 + a1 (w2 2^11) + (a2 2^11) w1 are three MFMAs
+// into the same accumulator - 48 per tile instead of bf16x6's 96, W in 128 registers instead of 192.  Same error bound as every fp16x3
+// product; W (weights) must lie in fp16's range.
+template <int MODE, int PROBE = 0, bool X16 = false, bool F16 = false>   // PROBE (measurement only, wrong results): 1 = no MFMAs, 2 = no plane reads either
 __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
     static_assert(!X16 || MODE == 3, "bf16 storage in this kernel: mode 3 only");
+    static_assert(!F16 || MODE == 3, "the one-accumulator fp16x3 form is built for mode 3");
     constexpr int H = 256, HC = 128, TM = 32, KS = H / 16, PLD = 2 * H + 16, PLANE = TM * PLD, SLOTB = 3 * PLANE, LDK = HC + 4, XT = TM * LDK;
     constexpr int NPF = 16, NPE = 8;   // pieces per lane: fetch mapping (whole rows), epilogue mapping (this workgroup's column half)
     __shared__ __attribute__((aligned(16))) unsigned char ring[2 * SLOTB];
@@ -158,7 +190,8 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
             const float* wp = a.W3 + (int64_t)col * a.ldw + 64 * (q >> 2) + 32 * half + 8 * (q & 3);
-            split8(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4), w1[q], w2[q], w3[q]);
+            if (F16) split8h(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4), w1[q], w2[q]);
+            else split8(*reinterpret_cast<const f32x4*>(wp), *reinterpret_cast<const f32x4*>(wp + 4), w1[q], w2[q], w3[q]);
         }
         auto crow = [](int r) { return (r & 3) + 8 * (r >> 2); };
         const int lane_x = 4 * half * LDK + 32 * wave + cl;   // accumulator element r sits in tile row 4 half + crow(r)
@@ -185,6 +218,15 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                 if (PROBE >= 1) {
                     acc[q & 15] += __uint_as_float(c1.x ^ c2.y ^ c3.z ^ w1[q].x ^ w2[q].y ^ w3[q].z);
                     c1 = n1, c2 = n2, c3 = n3;
+                    continue;
+                }
+                if (F16) {   // planes of A: c1 = a1, c2 = a2 2^11, c3 = a1 2^11; smallest terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c2), as_h8(w1[q]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c1), as_h8(w2[q]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(c3), as_h8(w1[q]), acc, 0, 0, 0);
+                    c1 = n1;
+                    c2 = n2;
+                    c3 = n3;
                     continue;
                 }
                 // smallest terms first
@@ -278,9 +320,12 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
         const float* Xs = xt + group * XT;
         f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = st1;   // MODE 1: this lane's running shifted sums of its four columns
         long long t_split = 0, t_done = 0, t_epi = 0, t_issue = 0, t0 = 0, t1 = 0;
+        float amax3 = 0.f;   // MODE 3: max |dxe| over the elements this lane writes out (round 6: for the fp16x3 weight gradient of B_3)
+        float un_pub = 1.f;  // F16: 2^-11 / (the scale of this wave's sixteen rows of the tile it published last)
         // split the rows in av (tile r) into the group's planes slot and publish them; MODE 3 first turns them into A = BatchNorm
         // backward of (dy = the old C rows, x = the xe rows) and writes this workgroup's column half of it out as dxe
         auto split_and_publish = [&](int r) {
+            float mrow = 0.f;   // F16: max |.| over this lane's pieces of the wave's sixteen rows
             if (MODE == 3) {
                 const f32x4 ka = *reinterpret_cast<const f32x4*>(norm_lds + 4 * c4f), k1 = *reinterpret_cast<const f32x4*>(norm_lds + H + 4 * c4f);
                 const f32x4 k2 = *reinterpret_cast<const f32x4*>(norm_lds + 2 * H + 4 * c4f), km = *reinterpret_cast<const f32x4*>(norm_lds + 3 * H + 4 * c4f);
@@ -301,13 +346,30 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                         t[j] = ka[j] * (gm - on * (k1[j] + (av[p][j] - km[j]) * kr[j] * k2[j]));
                     }
                     av[p] = t;
-                    if (mine && row < valid3) store4_as<X16>(a.bnb.a_out, aoff + (int64_t)row * H, t);
+                    if (F16) mrow = fmaxf(fmaxf(mrow, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
+                    if (mine && row < valid3) {
+                        store4_as<X16>(a.bnb.a_out, aoff + (int64_t)row * H, t);
+                        amax3 = fmaxf(fmaxf(amax3, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
+                    }
                 }
+            }
+            float row_scale = 1.f;
+            if (F16) {
+                float m = mrow;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                const unsigned bits = __float_as_uint(m);
+                const int ex = (int)((bits >> 23) & 0xFFu) - 127;
+                int k = 0;
+                if (bits != 0u && ex < 128) k = max(-100, min(100, 3 - ex));   // (all zero: any scale; inf / NaN: scale 1 and NaN rows, as it should be)
+                row_scale = __uint_as_float((unsigned)(k + 127) << 23);
+                un_pub = __uint_as_float((unsigned)(127 - k - 11) << 23);
             }
 #pragma unroll
             for (int p = 0; p < NPF; ++p) {
                 uint2 p1, p2, p3;
-                split4(av[p], p1, p2, p3);
+                if (F16) split4h3(av[p] * row_scale, p1, p2, p3);
+                else split4(av[p], p1, p2, p3);
                 unsigned char* d = S + (16 * r0f + p) * PLD + 8 * c4f;
                 *reinterpret_cast<uint2*>(d) = p1;
                 *reinterpret_cast<uint2*>(d + PLANE) = p2;
@@ -349,6 +411,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                                   (hi(u1.y) + hi(u2.y)) + hi(u3.y)};
                 }
             }
+            const float un_use = un_pub;   // F16: tile r's factor (this wave split its sixteen rows of tile r - the rows its epilogue lanes own)
             if (r + 2 < n) split_and_publish(r + 2);
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_split += t1 - t0; t0 = t1; }
             const int valid = tile_valid(r);
@@ -392,6 +455,9 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                             for (int j = 0; j < 4; ++j) y[j] = fmaxf((x[u][j] + g1[p][j]) * sc4[j] + sh4[j], 0.f) + ek[p][j];
                         } else if (MODE == 4) {
                             y = x[u] + sc4;
+                        } else if (F16) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) y[j] = __builtin_fmaf(x[u][j], un_use, g1[p][j]);
                         } else {
                             y = x[u] + g1[p];
                         }
@@ -421,6 +487,7 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
             }
             if (a.prof) { t1 = __builtin_readcyclecounter(); t_issue += t1 - t0; }
         }
+        if (MODE == 3 && a.bnb.amax_bits != nullptr) wave_amax_to(a.bnb.amax_bits, amax3);   // (one atomicMax per wave, only when larger)
         if (a.prof && wave == 4 && lane == 0) {   // the first load wave's phases, after the 256 compute-wave records
             long long* o = a.prof + (int64_t)(256 + blockIdx.x) * 8;
             o[0] = 0; o[1] = t_split; o[2] = t_done; o[3] = t_epi; o[4] = (n + 1) / 2; o[5] = t_issue;
@@ -448,7 +515,7 @@ int grid_pl256() {
     return g < 16 ? 16 : g;
 }
 
-template <int MODE, int PROBE = 0, bool X16 = false>
+template <int MODE, int PROBE = 0, bool X16 = false, bool F16 = false>
 int launch_pl256(const GateBfArgs& args, hipStream_t s) {
     GateBfArgs a = args;
     const int64_t tiles = (a.E + 31) / 32;
@@ -462,7 +529,7 @@ int launch_pl256(const GateBfArgs& args, hipStream_t s) {
     if (MODE == 1 && a.stats != nullptr) GN_HIP(hipMemsetAsync(a.stats, 0, sizeof(float) * (size_t)grid_pl256() * 4 * 2 * 256, s));   // idle waves / the other half
     if (PROBE == 0 && (MODE == 0 || MODE == 1 || MODE == 4) && tuning(kTuneArith) == 0)   // the shipped default: fp16x3 + LDS-DMA (edge_tile_f16.hip)
         return gate_f16_launch(MODE, a, grid_pl256(), s);
-    hipLaunchKernelGGL((k_edge_gate_pl256<MODE, PROBE, X16>), dim3(grid_pl256()), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((k_edge_gate_pl256<MODE, PROBE, X16, F16>), dim3(grid_pl256()), dim3(512), 0, s, a);
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
@@ -475,7 +542,7 @@ int launch_pl256(const GateBfArgs& args, hipStream_t s) {
 int gate_pl256_stats_rows() { return grid_pl256() * 4; }
 int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s, bool x16) {
     if (x16) {   // bf16 storage of xe / dxe at H = 256 (round 4)
-        if (mode == 3) return launch_pl256<3, 0, true>(a, s);
+        if (mode == 3) return tuning(kTuneArith) == 0 && tuning(kTuneGateExperiment) != 79 ? launch_pl256<3, 0, true, true>(a, s) : launch_pl256<3, 0, true>(a, s);
         GN_REQUIRE(mode == 1 && tuning(kTuneArith) == 0, "edge-tile kernel (H = 256): bf16 storage exists for modes 1 (fp16x3 kernel) and 3");
         GateBfArgs b = a;
         b.num_tiles = (int)((a.E + 31) / 32);
@@ -487,7 +554,8 @@ int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s, bool x16) {
     if (mode == 0) return launch_pl256<0>(a, s);
     if (mode == 1) return launch_pl256<1>(a, s);
     if (mode == 2) return launch_pl256<2>(a, s);
-    if (mode == 3) return launch_pl256<3>(a, s);
+    if (mode == 3)   // fp16x3 in one accumulator (round 6); gnnome_set_tuning(10, 1) or (4, 79): bf16x6
+        return tuning(kTuneArith) == 0 && tuning(kTuneGateExperiment) != 79 ? launch_pl256<3, 0, false, true>(a, s) : launch_pl256<3>(a, s);
     if (mode == 4) return launch_pl256<4>(a, s);
     set_error("edge-tile kernel (H = 256): mode %d is not built", mode);
     return GNNOME_EINVAL;

@@ -38,6 +38,7 @@ constexpr int kHubThreshold = 4096;   // items (in-edges + out-edges) above whic
 constexpr int kHubChunks = 128;       // chunks per hub = waves working on it
 constexpr int kHubCap = 64;           // hubs per call that get the split path
 constexpr int kHubMaxH = 256;
+constexpr int kRecItems = 20;         // neighbours per direction that fit a node's 64-word record (4 + 3 * 20)
 
 struct HubScratch {
     const void *key_in = nullptr, *key_out = nullptr;   // the CSR arrays the hub list was last built from
@@ -203,16 +204,23 @@ __device__ __forceinline__ void accumulate_items(const float* __restrict__ e, co
 // and inside the in-loop all row loads go out first, then the neighbour indices are awaited and the table rows gathered.
 // NOBR: the accumulation of a dead item (past the end of its list: its loads were clamped to a live one) is masked arithmetically
 // instead of being branched around - every live item still adds the same values in the same order (a dead one adds +0): same bits.
+// recv (round 6 experiment, kNodeRecord): this lane's word of the node's 256-byte record (k_build_node_records) - when the node's two lists fit
+// it (rec_small), the neighbour ids and out-edge positions come out of that ONE load by cross-lane reads instead of a second trip to memory.
 template <int H, int U = (H == 256 ? 8 : 4), bool NOBR = false, bool NTOUT = false>
 __device__ __forceinline__ void accumulate_items_split(const float* __restrict__ e, const float* __restrict__ A2h, const float* __restrict__ A3h,
                                                        int ldn, const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_pos,
                                                        const int32_t* __restrict__ out_dst, int ib, int din, int ob, int lo, int hi, int lane,
-                                                       int group, int c, f32x4& nf, f32x4& df, f32x4& nb, f32x4& db) {
+                                                       int group, int c, f32x4& nf, f32x4& df, f32x4& nb, f32x4& db, int recv = 0,
+                                                       bool rec_small = false) {
     constexpr int LPR = H / 4, G = 64 / LPR;
     for (int base = lo; base < hi; base += 64) {
         const int j = base + lane;   // lane l owns item base + l
         int my_p = 0, my_n = 0;
-        if (j < din) {
+        if (rec_small) {   // (wave-uniform; one batch: hi <= 2 * kRecItems)
+            const int jo = min(max(j - din, 0), kRecItems - 1);
+            my_n = __shfl(recv, j < din ? 4 + min(j, kRecItems - 1) : 4 + 2 * kRecItems + jo);
+            my_p = __shfl(recv, 4 + kRecItems + jo);
+        } else if (j < din) {
             my_n = srt_src[ib + j];
         } else if (j < hi) {
             my_p = out_pos[ob + j - din];
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(kAggThreads) void k_hub_partials(const float* __res
 // shares everything after the sums (two launches instead of a branch: the partial-sum loop cost the regular kernel 22
 // registers and a third of its occupancy).  U: items per lane group in flight, WPS: waves per SIMD asked of the register
 // allocator (0 = unconstrained).
-template <int H, int NORM, int MODE, bool HUBFIN = false, int U = (H == 256 ? 8 : 4), int WPS = 0, int SPLIT = 0>
+template <int H, int NORM, int MODE, bool HUBFIN = false, int U = (H == 256 ? 8 : 4), int WPS = 0, int SPLIT = 0, bool REC = false>
 __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggregate(
     const float* __restrict__ e, int64_t n_out, const float* __restrict__ A1h, const float* __restrict__ A2h,
     const float* __restrict__ A3h, int ldn, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src,
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
     const float* __restrict__ h_in, int ldh, float* __restrict__ h_out, const float* __restrict__ scale,
     const float* __restrict__ shift, int total_blocks, float* __restrict__ aux0, float* __restrict__ aux1,
     float* __restrict__ aux2, float* __restrict__ aux3, const int* __restrict__ hub_count, const int* __restrict__ hub_nodes,
-    const float* __restrict__ hub_partials, int64_t node0, int norm_width) {
+    const float* __restrict__ hub_partials, int64_t node0, int norm_width, const int32_t* __restrict__ records = nullptr) {
     constexpr int LPR = H / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t node;
@@ -363,8 +371,16 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
     if (node >= n_out) return;
     const int group = lane / LPR, c = (lane % LPR) * 4;
 
-    const int ib = in_ptr[node], din = in_ptr[node + 1] - ib;
-    const int ob = out_ptr[node], cnt = din + out_ptr[node + 1] - ob;
+    int ib, din, ob, cnt, recv = 0;
+    if (REC) {   // one 256-byte load: [ib, din, ob, dout, 20 in-neighbours, 20 out positions, 20 out-neighbours]
+        recv = records[node * 64 + lane];
+        ib = __builtin_amdgcn_readlane(recv, 0), din = __builtin_amdgcn_readlane(recv, 1);
+        ob = __builtin_amdgcn_readlane(recv, 2), cnt = din + __builtin_amdgcn_readlane(recv, 3);
+    } else {
+        ib = in_ptr[node], din = in_ptr[node + 1] - ib;
+        ob = out_ptr[node], cnt = din + out_ptr[node + 1] - ob;
+    }
+    const bool rec_small = REC && din <= kRecItems && cnt - din <= kRecItems;
     if (HUBFIN) {
         if (cnt <= kHubThreshold) return;   // a stale list entry: the regular launch has done this node
     } else if (cnt > kHubThreshold && hub_nodes != nullptr) {   // wave-uniform: is this node on the hub list?
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
         else if (SPLIT == 3)   // variant 8: the split loop without branches around dead items
             accumulate_items_split<H, U, true>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
         else if (SPLIT == 1)
-            accumulate_items_split<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
+            accumulate_items_split<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db, recv, rec_small);
         else
             accumulate_items<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
     }
@@ -582,6 +598,25 @@ __global__ __launch_bounds__(kAggThreads) void k_node_aggregate_pair(
   }
 }
 
+// A node's 256-byte record for the REC form of the aggregation (round 6 experiment): word 0 ib, 1 in-degree, 2 ob, 3 out-degree, then the first
+// kRecItems of srt_src[ib ..], out_pos[ob ..], out_dst[ob ..].  One thread per word.
+__global__ __launch_bounds__(256) void k_build_node_records(const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ srt_src,
+                                                            const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_pos,
+                                                            const int32_t* __restrict__ out_dst, int64_t n, int32_t* __restrict__ rec) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t node = t >> 6;
+    const int w = (int)(t & 63);
+    if (node >= n) return;
+    const int ib = in_ptr[node], din = in_ptr[node + 1] - ib, ob = out_ptr[node], dout = out_ptr[node + 1] - ob;
+    int v = 0;
+    if (w < 4) v = w == 0 ? ib : w == 1 ? din : w == 2 ? ob : dout;
+    else if (w < 4 + kRecItems) v = (w - 4) < din ? srt_src[ib + w - 4] : 0;
+    else if (w < 4 + 2 * kRecItems) v = (w - 4 - kRecItems) < dout ? out_pos[ob + w - 4 - kRecItems] : 0;
+    else v = (w - 4 - 2 * kRecItems) < dout ? out_dst[ob + w - 4 - 2 * kRecItems] : 0;
+    rec[t] = v;
+}
+static thread_local const int32_t* g_node_records = nullptr;   // gnnome_debug_node_records
+
 template <int H>
 static int launch_agg(const float* e, int64_t n_out, const float* A1h, const float* A2h, const float* A3h, int ldn,
                       const int32_t* in_ptr, const int32_t* ss, const int32_t* out_ptr, const int32_t* out_pos,
@@ -709,7 +744,14 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
                     GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks);
                 }
                 break;
-            default: GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks); break;
+            default:
+                if (g_node_records != nullptr && node_begin == 0 && node_end == n_out)
+                    hipLaunchKernelGGL((k_node_aggregate<H, GNNOME_NORM_AFFINE, 0, false, UD, 0, 1, true>), dim3((unsigned)blocks), dim3(kAggThreads), dyn, s, e, node_end,
+                                       A1h, A2h, A3h, ldn, in_ptr, ss, out_ptr, out_pos, od, h_in, ldh, h_out, scale, shift, (int)blocks, aux0, aux1, aux2, aux3,
+                                       hub_count, hub_nodes, hub_partials, node0, norm_width, g_node_records);
+                else
+                    GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks);
+                break;
         }
         if (hub_pass) GN_AGG_LAUNCH(GNNOME_NORM_AFFINE, 0, true, UD, 0, kFinGrid);
     } else {
@@ -723,6 +765,24 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
 }
 
 }  // namespace gnnome
+
+// Round 6 experiment: records[N][64] for the aggregation's REC form, and the switch that makes the following
+// gnnome_node_aggregate_f32 calls of this thread (inference form, BatchNorm, whole node range) read them.  NULL = off.
+extern "C" int gnnome_build_node_records(const int32_t* in_ptr, const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
+                                         const int32_t* out_dst, int64_t num_nodes, int32_t* records, void* stream) {
+    using namespace gnnome;
+    GN_REQUIRE(num_nodes >= 0 && num_nodes < (1ll << 25), "build_node_records: node count out of range");
+    if (num_nodes == 0) return GNNOME_OK;
+    GN_REQUIRE(in_ptr && out_ptr && records && (uintptr_t)records % 256 == 0, "build_node_records: null or misaligned pointer");
+    hipLaunchKernelGGL(k_build_node_records, dim3((unsigned)((num_nodes * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in_ptr, srt_src, out_ptr,
+                       out_pos, out_dst, num_nodes, records);
+    GN_LAUNCH_CHECK();
+    return GNNOME_OK;
+}
+extern "C" int gnnome_debug_node_records(const int32_t* records) {
+    gnnome::g_node_records = records;
+    return GNNOME_OK;
+}
 
 extern "C" int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num_nodes_out, const float* A1h,
                                          const float* A2h, const float* A3h, int ld_node, const int32_t* in_ptr,

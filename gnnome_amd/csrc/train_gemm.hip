@@ -482,11 +482,31 @@ constexpr int kW2Tile = 256, kW2Rows = 16;
 constexpr int kW2ColBytes = 2 * kW2Rows + 16;        // one column of one bf16 plane: 16 rows + 16 bytes of pad (48 B: conflict-free b128 reads)
 constexpr int kW2Plane = kW2Tile * kW2ColBytes;      // 12 KB; A and B, three planes each = 72 KB per buffer, two buffers
 
-template <int ABL = 0, bool X16 = false>   // ABL: measurement only (1 = no re-fetch, 2 = no MFMAs, 4 = no staging); X16: A stored as bf16 (round 4)
+// F16 (round 6; VERDICT r5 item 5 "fp16x3 for the H = 256 backward products ... needs a second accumulator set that does not fit beside 4 x 4
+// tiles"): fp16x3 in ONE accumulator set.  The two small products carry a factor 2^11 (the second planes are stored scaled, x2 = RN16((x - x1)
+// 2048), so that they are fp16 normals whenever x1 is); instead of keeping them apart and folding them in at the end, the LARGE product gets the
+// same factor: A's first plane is staged twice, a1 and a1 2^11 (exact: A is a gradient scaled into [8, 16) by the power of two its maximum asks
+// for - amax_bits, as in k_wgrad_partial_h - so a1 2^11 < 2^15), and
+//     2^11 a b  =  (a1 2^11) b1 + a1 (b2 2^11) + (a2 2^11) b1          (+ terms <= 3 * 2^-11 of the middle ones, dropped like everywhere)
+// are three MFMAs into the same accumulator, smallest first; the tile is multiplied by 2^-11 / scale on its way out.  Three planes of A, two of
+// B: half of bf16x6's matrix work, 5/6 of its staging.  B (activations) in fp16's range, like every fp16x3 operand.
+template <int ABL = 0, bool X16 = false, bool F16 = false>   // ABL: measurement only (1 = no re-fetch, 2 = no MFMAs, 4 = no staging); X16: A stored as bf16 (round 4)
 __global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int lda, int Ka, const float* __restrict__ B, int ldb, int Kb,
                                                              int64_t R, int64_t rows_per_chunk, float* __restrict__ partial,
-                                                             float* __restrict__ colsum_part, long long* prof) {
+                                                             float* __restrict__ colsum_part, long long* prof, const unsigned* __restrict__ amax_bits) {
+    static_assert(!(F16 && X16), "fp16x3 takes fp32 rows of A");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+    float a_scale = 1.f, out_scale = 1.f;   // F16: A times 2^k into [8, 16), k = 3 - floor(log2 amax); the tile times 2^-(k + 11)
+    if (F16) {
+        out_scale = 1.0f / 2048.f;
+        const unsigned bits = amax_bits != nullptr ? amax_bits[0] : 0u;
+        const int ex = (int)((bits >> 23) & 0xFFu) - 127;
+        if (bits != 0u && ex < 128) {   // (amax = 0: any scale; inf / NaN: scale 1 and a NaN result, as it should be)
+            const int k = max(-100, min(100, 3 - ex));
+            a_scale = __uint_as_float((unsigned)(k + 127) << 23);
+            out_scale = __uint_as_float((unsigned)(127 - k - 11) << 23);
+        }
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i0 = blockIdx.x * kW2Tile, j0 = blockIdx.y * kW2Tile;
     const int64_t r_begin = (int64_t)blockIdx.z * rows_per_chunk, r_end = min(R, r_begin + rows_per_chunk);
@@ -539,14 +559,28 @@ __global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int ld
             }
         }
     };
-    auto stage_col = [&](unsigned char* planes, const f32x4 (&v)[4], int j) {
+    auto stage_col = [&](unsigned char* planes, const f32x4 (&v)[4], int j, bool is_a) {
         uint2 p1, p2, p3;
-        tile_split4(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]}, p1, p2, p3);
         unsigned char* d = planes + (64 * j + c4) * kW2ColBytes + 8 * rr;
+        if (F16) {
+            const f32x4 x = f32x4{v[0][j], v[1][j], v[2][j], v[3][j]} * (is_a ? a_scale : 1.f);
+            wg_split4_h(x, p1, p2);
+            *reinterpret_cast<uint2*>(d) = p1;
+            *reinterpret_cast<uint2*>(d + kW2Plane) = p2;
+            if (is_a) {   // a1 2^11, exactly: the first plane as fp16 again, after the multiplication in fp32
+                const wg_h2 lo = __builtin_bit_cast(wg_h2, p1.x), hi = __builtin_bit_cast(wg_h2, p1.y);
+                const wg_f2 l2 = {(float)lo[0] * 2048.f, (float)lo[1] * 2048.f}, h2 = {(float)hi[0] * 2048.f, (float)hi[1] * 2048.f};
+                p3 = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(l2, wg_h2)), __builtin_bit_cast(unsigned, __builtin_convertvector(h2, wg_h2)));
+                *reinterpret_cast<uint2*>(d + 2 * kW2Plane) = p3;
+            }
+            return;
+        }
+        tile_split4(f32x4{v[0][j], v[1][j], v[2][j], v[3][j]}, p1, p2, p3);
         *reinterpret_cast<uint2*>(d) = p1;
         *reinterpret_cast<uint2*>(d + kW2Plane) = p2;
         *reinterpret_cast<uint2*>(d + 2 * kW2Plane) = p3;
     };
+    auto hf = [](const uint4 v) { return __builtin_bit_cast(wg_h8, v); };
     auto bf = [](const uint4 v) { return __builtin_bit_cast(tile_bf16x8, v); };
     // fragment a of this wave's half: slots 32 (4 w + a) + (lane & 31), rows 8 (lane >> 5) .. + 7
     const int frag_off_a = (128 * wi + (lane & 31)) * kW2ColBytes + 16 * (lane >> 5);
@@ -577,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int ld
             const unsigned char* pb = Bc + frag_off_b;
             bq[0][0] = *reinterpret_cast<const uint4*>(pb);
             bq[0][1] = *reinterpret_cast<const uint4*>(pb + kW2Plane);
-            bq[0][2] = *reinterpret_cast<const uint4*>(pb + 2 * kW2Plane);
+            if (!F16) bq[0][2] = *reinterpret_cast<const uint4*>(pb + 2 * kW2Plane);
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -585,7 +619,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int ld
                 const unsigned char* pb = Bc + frag_off_b + 32 * (b + 1) * kW2ColBytes;
                 bq[(b + 1) & 1][0] = *reinterpret_cast<const uint4*>(pb);
                 bq[(b + 1) & 1][1] = *reinterpret_cast<const uint4*>(pb + kW2Plane);
-                bq[(b + 1) & 1][2] = *reinterpret_cast<const uint4*>(pb + 2 * kW2Plane);
+                if (!F16) bq[(b + 1) & 1][2] = *reinterpret_cast<const uint4*>(pb + 2 * kW2Plane);
             }
             const uint4 b1 = bq[b & 1][0], b2 = bq[b & 1][1], b3 = bq[b & 1][2];
             // one row pair of the slab after next per column step: eight 1 KB requests at once block the wave at the CU's memory
@@ -593,12 +627,19 @@ __global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int ld
             // slab four or three ahead with one dword per line, so that these loads hit L2, made it slower: 5680 cycles.)
             if (!(ABL & 1)) fetch_row(r0 + 2 * kW2Rows, b, avF[b], bvF[b]);
             if (!(ABL & 4)) {
-                stage_col(An, avS, b);
-                stage_col(Bn, bvS, b);
+                stage_col(An, avS, b, true);
+                stage_col(Bn, bvS, b, false);
             }
             // the four accumulators of this column step take each term in turn: with ONE wave per SIMD a chain of dependent MFMAs would
             // leave the matrix pipe idle for the latency of each (measured: 67 cycles per MFMA instead of 32)
-            if (!(ABL & 2)) {
+            if (!(ABL & 2) && F16) {   // planes of A: a1 | a2 2^11 | a1 2^11; of B: b1 | b2 2^11
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf(a2[a]), hf(b1), acc[a][b], 0, 0, 0);   // smallest terms first
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf(a1[a]), hf(b2), acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf(a3[a]), hf(b1), acc[a][b], 0, 0, 0);
+            } else if (!(ABL & 2)) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a3[a]), bf(b1), acc[a][b], 0, 0, 0);   // smallest terms first
 #pragma unroll
@@ -625,8 +666,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int ld
     if (sums) cs += (av0[0] + av0[1]) + (av0[2] + av0[3]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        stage_col(lds2, av0, j);
-        stage_col(lds2 + 3 * kW2Plane, bv0, j);
+        stage_col(lds2, av0, j, true);
+        stage_col(lds2 + 3 * kW2Plane, bv0, j, false);
     }
     __syncthreads();
     const long long t_loop0 = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -652,7 +693,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad256_partial(WgradA a_op, int ld
                 // slot 32 f + m holds column 128 (f % 2) + 4 m + f / 2 of the tile; f = 4 w + a
                 const int fa = 4 * wi + a, fb = 4 * wj + b;
                 const int i = 128 * (fa & 1) + 4 * cd_row(r, lane) + (fa >> 1), j = 128 * (fb & 1) + 4 * (lane & 31) + (fb >> 1);
-                out[(int64_t)i * Kb + j] = acc[a][b][r];
+                out[(int64_t)i * Kb + j] = F16 ? acc[a][b][r] * out_scale : acc[a][b][r];
             }
     if (sums) {   // the four row groups of a column, added in a fixed order (the loop ended on a barrier)
         float* red = reinterpret_cast<float*>(lds2);
@@ -965,23 +1006,25 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
             return GNNOME_EWORKSPACE;
         }
         float* cpart = colsum ? partial + (size_t)ch * Ka * Kb : nullptr;
-#define GN_W256(ABLV) GN_W256X(ABLV, false)
-#define GN_W256X(ABLV, X16V)                                                                                                                 \
+#define GN_W256(ABLV) GN_W256X(ABLV, false, false)
+#define GN_W256X(ABLV, X16V, F16V)                                                                                                           \
     {                                                                                                                                       \
         /* the attribute is per device and per function: one flag per device ordinal (set once, outside any stream capture's first use) */  \
         static std::atomic<bool> attr_set[64];                                                                                              \
         int dev_ = 0;                                                                                                                       \
         GN_HIP(hipGetDevice(&dev_));                                                                                                        \
         if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_].load(std::memory_order_acquire)) {                                                    \
-            GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad256_partial<ABLV, X16V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+            GN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad256_partial<ABLV, X16V, F16V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        12 * kW2Plane));                                                                                     \
             if (dev_ >= 0 && dev_ < 64) attr_set[dev_].store(true, std::memory_order_release);                                              \
         }                                                                                                                                   \
-        hipLaunchKernelGGL((k_wgrad256_partial<ABLV, X16V>), dim3(Ka / kW2Tile, Kb / kW2Tile, (unsigned)ch), dim3(256), 12 * kW2Plane, s, a_op, lda, \
-                           Ka, B, ldb, Kb, rows, rp, partial, cpart, gate_profile_buffer());                                                \
+        hipLaunchKernelGGL((k_wgrad256_partial<ABLV, X16V, F16V>), dim3(Ka / kW2Tile, Kb / kW2Tile, (unsigned)ch), dim3(256), 12 * kW2Plane, s, a_op, lda, \
+                           Ka, B, ldb, Kb, rows, rp, partial, cpart, gate_profile_buffer(), amax_bits);                                     \
     }
         if (x16) {
-            GN_W256X(0, true);
+            GN_W256X(0, true, false);
+        } else if (amax_bits != nullptr && tuning(kTuneArith) != 1 && tuning(kTuneGateAblation) != 17) {
+            GN_W256X(0, false, true);   // max |A| known: fp16x3 in one accumulator set (gnnome_set_tuning(10, 1) or (1, 17): bf16x6)
         } else switch (tuning(kTuneGateAblation)) {
             case 1: GN_W256(1); break;
             case 2: GN_W256(2); break;
@@ -1030,7 +1073,8 @@ static int wgrad_impl(const WgradA& a_op, int lda, int Ka, const float* B, int l
 
 // The same product with max |A| known (amax_bits: the bits of a non-negative float on the device, as gnnome_bn_bwd_dgrad_amax_f32 leaves
 // them): where the 128 x 128 tile kernel runs it runs as fp16x3 with A scaled into fp16's range (k_wgrad_partial_h) - half the matrix work
-// of bf16x6 at a third of its error; elsewhere (256-wide operands) amax_bits is ignored.  B must lie in fp16's range (NaN rows otherwise).
+// of bf16x6 at a third of its error; 256-wide operands over many rows take the 256 x 256 tile kernel's one-accumulator fp16x3 form (round 6).
+// B must lie in fp16's range (NaN rows otherwise).
 extern "C" int gnnome_wgrad_scaled_f32(const float* A, int lda, int Ka, const float* B, int ldb, int Kb, int64_t rows, const unsigned* amax_bits,
                                        float* C, int ldc, void* workspace, size_t workspace_bytes, void* stream) {
     GN_REQUIRE(rows == 0 || (A && lda >= Ka && (uintptr_t)A % 16 == 0 && amax_bits), "wgrad_scaled: bad operands");

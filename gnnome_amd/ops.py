@@ -1048,8 +1048,8 @@ def can_fuse_bn_bwd_dgrad(de, W, xe=None):
 
 
 def can_dgrad_amax(de, xe):
-    """bn_bwd_dgrad can leave max |dxe| (amax=): hidden = 128, fp32 storage, the plane-form kernel."""
-    return de.shape[1] == 128 and de.shape[0] > 0 and xe.dtype == torch.float32 and _TUNING.get(0, 0) != 8
+    """bn_bwd_dgrad can leave max |dxe| (amax=): hidden = 128 (the plane-form kernel) or 256 (round 6), fp32 storage."""
+    return de.shape[1] in (128, 256) and de.shape[0] > 0 and xe.dtype == torch.float32 and _TUNING.get(0, 0) != 8
 
 
 def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None, amax=None):
@@ -1064,8 +1064,14 @@ def bn_bwd_dgrad(de, xe, scale, shift, a, c1, c2, mean, rstd, Wt, rows_once=None
         # two workgroups per row at this width: the kernel writes the updated rows to a fresh buffer, which then BECOMES de
         # (Tensor.set_: same tensor object, new storage - the caller's `de` is updated "in place" as at the other widths)
         out = torch.empty_like(de)
-        _call("gnnome_bn_bwd_dgrad_out_x16" if x16 else "gnnome_bn_bwd_dgrad_out_f32", de.device, _ptr(de), _ptr(out), _ptr(xe), de.shape[0], once, 256, _ptr(scale), _ptr(shift), _ptr(a),
-              _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))
+        if amax is not None:
+            if not can_dgrad_amax(de, xe) or amax.dtype != torch.int32 or amax.numel() != 1 or amax.device != de.device:
+                raise ValueError("bn_bwd_dgrad.amax: needs fp32 storage and a one-element int32 tensor on the same device")
+            _call("gnnome_bn_bwd_dgrad_out_amax_f32", de.device, _ptr(de), _ptr(out), _ptr(xe), de.shape[0], once, 256, _ptr(scale), _ptr(shift), _ptr(a),
+                  _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe), _ptr(amax))
+        else:
+            _call("gnnome_bn_bwd_dgrad_out_x16" if x16 else "gnnome_bn_bwd_dgrad_out_f32", de.device, _ptr(de), _ptr(out), _ptr(xe), de.shape[0], once, 256, _ptr(scale), _ptr(shift), _ptr(a),
+                  _ptr(c1), _ptr(c2), _ptr(mean), _ptr(rstd), _ptr(Wt), ldw, _ptr(dxe))
         if de._base is not None or de.storage_offset() != 0:   # a view of somebody else's storage: set_ would leave that storage unchanged
             de.copy_(out)
         else:

@@ -211,6 +211,13 @@ int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num_nodes_out,
                               const int32_t* out_dst, const float* h_in, int ld_h, float* h_out, int norm_kind,
                               const float* norm_scale, const float* norm_shift, void* stream);
 
+/* Measurement only (round 6, a measured negative / experiment - see NOTES.md): per-node 256-byte records [ib, in-degree, ob, out-degree, 20 x srt_src,
+ * 20 x out_pos, 20 x out_dst] (records[num_nodes][64], 256-byte aligned) and the switch that makes the calling thread's following
+ * gnnome_node_aggregate_f32 calls (BatchNorm, whole node range) take a node's pointers AND neighbour ids from ONE load.  NULL switches it off. */
+int gnnome_build_node_records(const int32_t* in_ptr, const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
+                              const int32_t* out_dst, int64_t num_nodes, int32_t* records, void* stream);
+int gnnome_debug_node_records(const int32_t* records);
+
 /* The same update for the nodes [node_begin, node_end) only - all pointers and num_nodes_out describe the WHOLE graph
  * exactly as for gnnome_node_aggregate_f32, rows outside the range are not touched.  Lets a caller cut one aggregation
  * (gated_gcn_full.py:111-137) into consecutive launches and start the NEXT layer's node projection (:91-96) on the rows
@@ -555,6 +562,11 @@ int gnnome_bn_bwd_dgrad_amax_f32(float* C, const float* X, int64_t rows, int64_t
 int gnnome_bn_bwd_dgrad_out_f32(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
                                 const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
                                 const float* mean, const float* rstd, const float* W, int ldw, float* dxe, void* stream);
+/* ... and max |dxe| left at amax_bits[0] as the bits of a non-negative float (zeroed first), as gnnome_bn_bwd_dgrad_amax_f32 does at hidden = 128:
+ * gnnome_wgrad_scaled_f32(dxe, e, amax_bits) then runs B_3's weight gradient as fp16x3 (round 6). */
+int gnnome_bn_bwd_dgrad_out_amax_f32(const float* C_in, float* C_out, const float* X, int64_t rows, int64_t rows_once, int hidden,
+                                     const float* scale, const float* shift, const float* a, const float* c1, const float* c2,
+                                     const float* mean, const float* rstd, const float* W, int ldw, float* dxe, unsigned* amax_bits, void* stream);
 
 /* gnnome_agg_edge_bwd_f32 with the BatchNorm-backward statistics of its result gathered in the same pass:
  *   de[p,:] += s(1-s)(...)   as above, then   s1[c] = sum_p de[p,c] m,  s2[c] = sum_p de[p,c] m (xe[p,c] - mean[c]),

@@ -598,7 +598,9 @@ def _bits(x):
 
 
 @pytest.mark.parametrize("rows,Ka,Kb,spread", [(50_001, 128, 128, 1e-3), (7000, 64, 128, 1e-9), (31, 128, 64, 1.0), (200_000, 128, 128, 1e-6),
-                                               (4097, 256, 128, 1e-4)])
+                                               (4097, 256, 128, 1e-4),
+                                               # round 6: whole 256-column tiles over >= 16384 rows - the 256 x 256 kernel's one-accumulator fp16x3
+                                               (40_003, 256, 256, 1e-3), (16_384, 512, 256, 1e-8), (100_000, 256, 256, 1.0)])
 def test_scaled_weight_gradient_is_fp32_faithful(rows, Ka, Kb, spread):
     """gnnome_wgrad_scaled_f32 (round 5): A^T B as fp16x3 with the GRADIENT operand scaled by the power of two its maximum asks for.  Against
     the fp64 product: within 2e-7 of max sum |a||b| (bf16x6's own contract) for operands whose magnitudes span `spread` .. 1 times a tiny
@@ -713,8 +715,16 @@ def test_scaled_block_products_at_other_shapes(M, width, nb, Nout):
 def test_dgrad_leaves_the_maximum_of_dxe():
     """gnnome_bn_bwd_dgrad_amax_f32: the same dxe and de as gnnome_bn_bwd_dgrad_f32, bit for bit, and amax = the bits of max |dxe| exactly
     (atomicMax on the unsigned bits of non-negative floats), also when the last tile is ragged and when rows_once cuts a tile."""
+    _dgrad_amax_case(128)
+
+
+def test_dgrad_leaves_the_maximum_of_dxe_at_256():
+    """gnnome_bn_bwd_dgrad_out_amax_f32 (round 6): the H = 256 form of the same contract."""
+    _dgrad_amax_case(256)
+
+
+def _dgrad_amax_case(H):
     g = torch.Generator().manual_seed(11)
-    H = 128
     r = lambda *s: torch.randn(*s, generator=g).to(dev())  # noqa: E731
     for e, once in ((50_001, None), (33, 20), (128, 0)):
         de0, xe = 1e-3 * r(e, H), 3 * r(e, H)
