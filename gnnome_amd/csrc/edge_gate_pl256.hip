@@ -542,7 +542,7 @@ int launch_pl256(const GateBfArgs& args, hipStream_t s) {
 int gate_pl256_stats_rows() { return grid_pl256() * 4; }
 int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s, bool x16) {
     if (x16) {   // bf16 storage of xe / dxe at H = 256 (round 4)
-        if (mode == 3) return tuning(kTuneArith) == 0 && tuning(kTuneGateExperiment) != 79 ? launch_pl256<3, 0, true, true>(a, s) : launch_pl256<3, 0, true>(a, s);
+        if (mode == 3) return tuning(kTuneArith) == 0 && tuning(kTuneGateExperiment) != 80 ? launch_pl256<3, 0, true, true>(a, s) : launch_pl256<3, 0, true>(a, s);
         GN_REQUIRE(mode == 1 && tuning(kTuneArith) == 0, "edge-tile kernel (H = 256): bf16 storage exists for modes 1 (fp16x3 kernel) and 3");
         GateBfArgs b = a;
         b.num_tiles = (int)((a.E + 31) / 32);
@@ -554,8 +554,8 @@ int gate_pl256_launch(int mode, const GateBfArgs& a, hipStream_t s, bool x16) {
     if (mode == 0) return launch_pl256<0>(a, s);
     if (mode == 1) return launch_pl256<1>(a, s);
     if (mode == 2) return launch_pl256<2>(a, s);
-    if (mode == 3)   // fp16x3 in one accumulator (round 6); gnnome_set_tuning(10, 1) or (4, 79): bf16x6
-        return tuning(kTuneArith) == 0 && tuning(kTuneGateExperiment) != 79 ? launch_pl256<3, 0, false, true>(a, s) : launch_pl256<3>(a, s);
+    if (mode == 3)   // fp16x3 in one accumulator (round 6); gnnome_set_tuning(10, 1) or (4, 80): bf16x6
+        return tuning(kTuneArith) == 0 && tuning(kTuneGateExperiment) != 80 ? launch_pl256<3, 0, false, true>(a, s) : launch_pl256<3>(a, s);
     if (mode == 4) return launch_pl256<4>(a, s);
     set_error("edge-tile kernel (H = 256): mode %d is not built", mode);
     return GNNOME_EINVAL;

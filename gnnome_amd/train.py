@@ -20,6 +20,13 @@ Backward = the transposes, in reverse: scorer tail, node projections (dgrad / wg
 (two-pass, per-channel sums over all rows), the per-edge gradient of both gated aggregations, segment sums for
 the gathers.  Everything runs in libgnnome_hip.so; torch holds the memory, does [H]-sized vector arithmetic on
 BatchNorm statistics and concatenates/slices views.
+
+DOMAIN.  The forward's dense products and, since rounds 5-6, the backward's weight / data gradients at H >= 128 run as fp16x3: the
+gradient operand is scaled by the power of two its maximum asks for (any magnitude from 1e-30 to 1e30 is fine), the OTHER operand - the
+activations e, h and the weights - must lie inside fp16's range, |x| < 65504.  Beyond it the affected gradients are NaN (never wrong finite
+values): `loss.backward()` then leaves non-finite `.grad`s, which `torch.nn.utils.clip_grad_norm_(..., error_if_nonfinite=True)` or a look at the
+loss catches.  Inference re-runs such a forward as bf16x6 by itself (engine.forward_in_range); a training step does not - select fp32's range
+for it with `GNNOME_SCALED_WGRAD=0 GNNOME_SCALED_NODE_WGRAD=0 GNNOME_SCALED_NODE_DGRAD=0` + `ops.bf16x6_arithmetic()` (gnnome_set_tuning(10, 1)).
 """
 import torch
 
