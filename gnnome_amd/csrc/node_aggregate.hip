@@ -206,7 +206,7 @@ __device__ __forceinline__ void accumulate_items(const float* __restrict__ e, co
 // instead of being branched around - every live item still adds the same values in the same order (a dead one adds +0): same bits.
 // recv (round 6 experiment, kNodeRecord): this lane's word of the node's 256-byte record (k_build_node_records) - when the node's two lists fit
 // it (rec_small), the neighbour ids and out-edge positions come out of that ONE load by cross-lane reads instead of a second trip to memory.
-template <int H, int U = (H == 256 ? 8 : 4), bool NOBR = false, bool NTOUT = false>
+template <int H, int U = (H == 256 ? 8 : 4), bool NOBR = false, bool NTOUT = false, bool TBLFIX = false>
 __device__ __forceinline__ void accumulate_items_split(const float* __restrict__ e, const float* __restrict__ A2h, const float* __restrict__ A3h,
                                                        int ldn, const int32_t* __restrict__ srt_src, const int32_t* __restrict__ out_pos,
                                                        const int32_t* __restrict__ out_dst, int ib, int din, int ob, int lo, int hi, int lane,
@@ -240,7 +240,7 @@ __device__ __forceinline__ void accumulate_items_split(const float* __restrict__
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int item = j0 + u * G + group;
-                const int nn = __shfl(my_n, live[u] ? item : 0);
+                const int nn = TBLFIX ? (ib & 1023) : __shfl(my_n, live[u] ? item : 0);   // TBLFIX (measurement only, wrong results): one table row per node
                 a[u] = *reinterpret_cast<const f32x4*>(A2h + (int64_t)nn * ldn + c);
             }
 #pragma unroll
@@ -268,7 +268,7 @@ __device__ __forceinline__ void accumulate_items_split(const float* __restrict__
                 const int item = j0 + u * G + group;
                 live[u] = item >= m_in && item < m;
                 const int it = live[u] ? item : m_in;   // (m_in < m here: a valid out-item)
-                const int p = __shfl(my_p, it), nn = __shfl(my_n, it);
+                const int p = __shfl(my_p, it), nn = TBLFIX ? (ib & 1023) : __shfl(my_n, it);
                 // NTOUT (variant 14): the out-edge pass is an e' row's LAST use in this launch - read past the L2's replacement order, so that the
                 // rows the in-edge passes have just brought in (and whose out-edge use is still to come) stay
                 x[u] = NTOUT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e + (int64_t)p * H + c))
@@ -410,6 +410,8 @@ __global__ __launch_bounds__(kAggThreads, (WPS > 0 ? WPS : 1)) void k_node_aggre
             accumulate_items_split<H, U>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, 0, ob, 0, cnt - din, lane, group, c, nf, df, nb, db);
         else if (SPLIT == 4)   // variant 14: nontemporal out-edge loads of e'
             accumulate_items_split<H, U, false, true>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
+        else if (SPLIT == 5)   // variant 15, MEASUREMENT ONLY (wrong results): every table row of a node replaced by one L1-resident row - the kernel without its gathers' L1 misses
+            accumulate_items_split<H, U, false, false, true>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
         else if (SPLIT == 3)   // variant 8: the split loop without branches around dead items
             accumulate_items_split<H, U, true>(e, A2h, A3h, ldn, srt_src, out_pos, out_dst, ib, din, ob, 0, cnt, lane, group, c, nf, df, nb, db);
         else if (SPLIT == 1)
@@ -713,6 +715,7 @@ static int launch_agg(const float* e, int64_t n_out, const float* A1h, const flo
             case 7: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 2); break;   // measurement only: out-edges alone
             case 8: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 3); break;   // no branches around dead items
             case 14: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 4); break;  // nontemporal out-edge loads of e' 
+            case 15: GN_AGG_LAUNCH_S(GNNOME_NORM_AFFINE, 0, false, UD, 0, blocks, 5); break;  // measurement only: no table-row misses
             case 11:   // ... walked as contiguous chunks by persistent workgroups (4 per CU)
             case 12:   // ... with nontemporal e loads
             case 13:   // the same, 8 workgroups per CU

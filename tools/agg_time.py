@@ -26,7 +26,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "once":   # a few launches of the defaul
     torch.cuda.synchronize()
     sys.exit(0)
 VARIANTS = {0: "default (U=4 at H<=128, 8 at 256)", 1: "U=4, 8 waves/SIMD", 2: "U=2, 8 waves/SIMD", 3: "U=1", 4: "U=8", 5: "U=2", 6: "U=4, single item loop (in-edge rows requested after the index wait; the round-1 form)",
-            9: "two nodes per wave, U=4 (k_node_aggregate_pair, round 4)", 10: "two nodes per wave, U=2", 11: "two nodes per wave, persistent contiguous chunks, 4 WG/CU", 12: "... + nontemporal e loads", 13: "... 8 WG/CU", 14: "default + nontemporal out-edge loads of e' (round 5)"}
+            9: "two nodes per wave, U=4 (k_node_aggregate_pair, round 4)", 10: "two nodes per wave, U=2", 11: "two nodes per wave, persistent contiguous chunks, 4 WG/CU", 12: "... + nontemporal e loads", 13: "... 8 WG/CU", 14: "default + nontemporal out-edge loads of e' (round 5)", 15: "MEASUREMENT ONLY: one L1-resident table row per node (no gather misses; round 6)", 7: "MEASUREMENT ONLY: out-edges alone"}
 if len(sys.argv) > 3:   # a subset: python tools/agg_time.py 128 variants 0,14
     VARIANTS = {int(v): VARIANTS[int(v)] for v in sys.argv[3].split(",")}
 if len(sys.argv) > 2 and sys.argv[2] == "variants":   # items in flight per lane group against occupancy (gnnome_set_tuning key 7)
