@@ -152,6 +152,22 @@ class ForwardEventTimer:
         return sum(s.elapsed_time(t) for s, t in ev) / max(len(ev), 1), len(ev)
 
 
+def _mfma_util(workload_key):
+    """Matrix-core utilisation per kernel from the committed PMC pass over this workload (tools/pmc_mfma.sh -> profiles/<tag>_mfma_busy.json:
+    SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE x SIMDs, per the guide's PMC section; north_star: "MFMA utilisation ... against CDNA4 peak").
+    Quoted only when the file was collected on THIS build of the library."""
+    prof = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(prof), reverse=True):
+        if name.endswith("_mfma_busy.json"):
+            with open(os.path.join(prof, name)) as f:
+                d = json.load(f)
+            if d.get("so_sha16") != so_sha16() or workload_key not in d.get("workloads", {}):
+                continue
+            return {"source": "profiles/" + name, "definition": d.get("mfma_util"),
+                    "kernels": {r["kernel"]: round(r["mfma_util"], 4) for r in d["workloads"][workload_key]}}
+    return None
+
+
 def _pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` (a substring of its name) from the committed PMC passes over one forward of `workload`
     (FETCH_SIZE / WRITE_SIZE cannot be read from inside this process; tools/pmc_forward.sh collects them per the guide - separate
@@ -960,6 +976,10 @@ def main():
                  "frac": (e * hidden * 4.0 + 3 * e * 4.0) / (sc_ms * 1e-3) / HBM_PEAK},
                 {"kernel": "k_encode (node + edge)", "bound": "hbm", "avg_launch_ms": en_ms, "launches": en_n},
             ]
+        if world == 1 and args.workload in ("c2", "c4shard"):
+            mu = _mfma_util(f"{args.workload}_infer")
+            if mu:
+                res["mfma_util"] = mu
         if timed and others and kd.events["edge_gate_ref"]:
             # layers that run in the reference's ORDER of evaluation (fp32 VALU, csrc/reference_order.hip) next to the bf16x6
             # matrix-core kernels they stand in for, same shapes, same pass

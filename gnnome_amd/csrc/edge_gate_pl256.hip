@@ -348,7 +348,11 @@ __global__ __launch_bounds__(512) void k_edge_gate_pl256(GateBfArgs a) {
                     av[p] = t;
                     if (F16) mrow = fmaxf(fmaxf(mrow, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
                     if (mine && row < valid3) {
-                        store4_as<X16>(a.bnb.a_out, aoff + (int64_t)row * H, t);
+                        // (the offset is made opaque so that the sixteen row addresses are formed here, one at a time: hoisted out of the loop they were
+                        // spilled, and every reload came with an s_waitcnt vmcnt(0) in front of its store - the stores of a tile went out one by one)
+                        int roff = row * H;
+                        asm volatile("" : "+v"(roff));
+                        store4_as<X16>(a.bnb.a_out, aoff + (int64_t)roff, t);
                         amax3 = fmaxf(fmaxf(amax3, fmaxf(fabsf(t[0]), fabsf(t[1]))), fmaxf(fabsf(t[2]), fabsf(t[3])));
                     }
                 }
