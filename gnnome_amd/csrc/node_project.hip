@@ -104,6 +104,8 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, h8_t& p1,
     }
 }
 
+}  // namespace (the helpers above stay private to this file; the kernels carry plain gnnome:: names for the profilers' tables)
+
 // Which output column of its 32-column block the MFMA's row index i = 8 a + 4 h + t stands for: 16 h + 4 a + t.  With W as the A operand, lane
 // (j, h) of the result holds i = 8 q + 4 h + t in accumulator 4 q + t; after the 4 x 4 transpose among the four lanes of a quad (epilogue) lane
 // (4 g + a, h) holds i = 8 a + 4 h + t of node row 4 g + r in slot r - and with this numbering that is columns 16 h + 4 a .. + 3: the four lanes
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_node_project(const float* __restrict
 }
 
 template <int K, int PROBE>
-int launch_project(const float* A, int64_t M, int lda, const void* planes, const float* bias, int Nout, float* C, int ldc, hipStream_t s) {
+static int launch_project(const float* A, int64_t M, int lda, const void* planes, const float* bias, int Nout, float* C, int ldc, hipStream_t s) {
     constexpr int BPG = K == 128 ? 2 : 1;
     const int64_t tiles = (M + 127) / 128, units = tiles * (Nout / (32 * BPG));
     const int64_t slots = 2 * persistent_grid();   // workgroups that are resident together: two per CU
@@ -341,8 +343,6 @@ int launch_project(const float* A, int64_t M, int lda, const void* planes, const
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
-
-}  // namespace
 
 bool project_supported(int K, int Nout) { return (K == 128 || K == 256) && Nout > 0 && Nout % (K == 128 ? 64 : 32) == 0 && Nout <= kMaxNout; }
 
