@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py - edges/sec of one full SymGatedGCNModel forward (encoders + 8 layers + scorer).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|10m|parity64|c4shard|c4|c5|c5shard|c5quarter] [--kind banded|uniform]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|10m|parity64|c4shard|c4|c5|c5shard|c5quarter|c4quarter] [--kind banded|uniform]
                     [--mode infer|train]
 
 One "step" = one `model(graph, x, e)` on a synthetic assembly graph already resident in HBM (graph views prebuilt, as a
@@ -34,6 +34,7 @@ WORKLOADS = {
     "parity64": (100_000, 1_000_000, 64),
     "c4shard": (250_000, 2_500_000, 256),      # one GPU's eighth of configs[3]
     "c4": (2_000_000, 20_000_000, 256),        # BASELINE.json configs[3] (8 GPUs; 20.5 GB of edge state: fits one GPU as well)
+    "c4quarter": (500_000, 5_000_000, 256),    # a quarter of configs[3]: `--gpus 8 --one-gpu-gloo` plumbing runs at H = 256
     "c5": (5_000_000, 50_000_000, 256),        # BASELINE.json configs[4] (8-GPU training step)
     "c5shard": (625_000, 6_250_000, 256),      # one GPU's eighth of configs[4]: what a rank of the 8-GPU training step holds
     "c5quarter": (1_250_000, 12_500_000, 256), # a quarter of configs[4] (two ranks' shares: `--gpus 2 --one-gpu-gloo --mode train`)
