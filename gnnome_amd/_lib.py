@@ -28,6 +28,7 @@ SIGNATURES = {
     "gnnome_linear_acc_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "gnnome_weight_planes_f16": [_p, _i, _i, _i, _p, _p],
     "gnnome_linear_planes_f32": [_p, _l, _i, _i, _p, _p, _i, _p, _i, _p],
+    "gnnome_linear_planes_route": [_l, _i, _i, _i],
     "gnnome_edge_gate_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p],
     "gnnome_edge_gate_encode_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
     "gnnome_linear_ref_f32": [_p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p],
@@ -110,7 +111,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 # the parameter blocks of gnnome_model_forward_f32 (include/gnnome_hip.h), field for field

@@ -34,11 +34,6 @@ Workspace layout(int64_t n, int64_t e, int hidden, int hs) {
     return w;
 }
 
-bool planes_route(int K, int Nout) {   // gnnome_amd.ops._planes_route
-    const int v = tuning(kTuneLinearVariant);
-    return tuning(kTuneArith) == 0 && (v == 0 || v == 9 || v == 20) && (K == 128 || K == 256) && Nout % (K == 128 ? 64 : 32) == 0 && Nout <= 1536;
-}
-
 // gnnome_debug_forward_events: HIP events the NEXT forwards record around one layer's gate and aggregation launches (bench.py's live roofline)
 struct ForwardEvents {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -52,7 +47,7 @@ int mark(int which, int layer, void* stream) {
 }
 
 int project(const float* A, int64_t M, int K, const float* W, const void* planes, const float* bias, int Nout, float* C, void* stream) {
-    if (M > 0 && planes != nullptr && planes_route(K, Nout)) return gnnome_linear_planes_f32(A, M, K, K, planes, bias, Nout, C, Nout, stream);
+    if (planes != nullptr && gnnome_linear_planes_route(M, K, Nout, 1)) return gnnome_linear_planes_f32(A, M, K, K, planes, bias, Nout, C, Nout, stream);
     return gnnome_linear_f32(A, M, K, K, W, K, bias, Nout, C, Nout, stream);
 }
 

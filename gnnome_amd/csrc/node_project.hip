@@ -31,6 +31,8 @@
 // issues its 8 pieces of granule n + 1 (between the MFMAs) and then 4 row-piece stores per column block, ALWAYS 4 (rows past M are clamped on
 // the way in and store the clamped row's own bits again): what is younger than granule n's DMA when it is needed is exactly the stores of
 // iteration n - 1, so `s_waitcnt vmcnt(4 * blocks per granule)` waits for the granule and for nothing issued after it.
+#include <cstdlib>
+
 #include "common.h"
 
 #pragma clang diagnostic ignored "-Winline-asm"
@@ -388,4 +390,16 @@ extern "C" int gnnome_linear_planes_f32(const float* A, int64_t M, int K, int ld
                "linear_planes: bad stride / alignment");
     GN_REQUIRE((const void*)A != (const void*)C, "linear_planes: C must not alias A");
     return project_launch(A, M, K, lda, planes, bias, Nout, C, ldc, (hipStream_t)stream);
+}
+
+// The one rule that sends a product to the kernel above (include/gnnome_hip.h): shapes, the caller's planes, the tuning switches, the A/B environment switch.
+extern "C" int gnnome_linear_planes_route(int64_t M, int K, int Nout, int given_planes) {
+    using namespace gnnome;
+    static const bool enabled = [] {
+        const char* v = getenv("GNNOME_PLANES_LINEAR");
+        return !(v != nullptr && v[0] == '0' && v[1] == '\0');
+    }();
+    const int variant = tuning(kTuneLinearVariant);
+    if (!enabled || M <= 0 || tuning(kTuneArith) != 0 || !(variant == 0 || variant == 9 || variant == 20) || !project_supported(K, Nout)) return 0;
+    return (given_planes || (Nout % 128 == 0 && (K == 256 || Nout >= 256))) ? 1 : 0;
 }

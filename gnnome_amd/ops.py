@@ -274,9 +274,6 @@ def encode(x, W1, b1, W2, b2, gather=None, rows=None):
     return out
 
 
-PLANES_LINEAR = _os.environ.get("GNNOME_PLANES_LINEAR", "1") != "0"   # the round-6 node-projection kernel (csrc/node_project.hip); 0: round 5's routes
-
-
 def planes_supported(K, Nout):
     """Shapes gnnome_linear_planes_f32 is built for (the node projections: K = H in {128, 256}, Nout = 5H or 2 hs)."""
     return K in (128, 256) and Nout % (64 if K == 128 else 32) == 0 and 0 < Nout <= 1536
@@ -295,14 +292,12 @@ def weight_planes(W):
 
 
 def _planes_route(A, lda, W, ldw, out, ldc, accumulate, given):
-    """Whether this product runs on gnnome_linear_planes_f32.  Without planes from the caller: exactly the shapes round 4 / 5 sent to the
-    fp16x3 edge-tile kernels (whole 128-column blocks: K = 128 with Nout >= 256, K = 256) - the node projections; a narrower product (the
-    scorer's node halves at H = 128, the backward's transposed products) keeps its bf16x6 kernel unless the caller hands in planes."""
-    K, Nout = A.shape[1], W.shape[0]
-    shape = planes_supported(K, Nout) and (given or (Nout % 128 == 0 and (K == 256 or Nout >= 256)))
-    return (PLANES_LINEAR and shape and not accumulate and _TUNING.get(10, 0) == 0 and _TUNING.get(2, 0) in (0, 9, 20) and A.shape[0] > 0
-            and lda % 4 == 0 and ldw % 4 == 0 and ldc % 4 == 0 and A.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
-            and out.data_ptr() % 16 == 0 and A.data_ptr() != out.data_ptr())
+    """Whether this product runs on gnnome_linear_planes_f32: the library's own rule (gnnome_linear_planes_route - shapes, tuning switches,
+    GNNOME_PLANES_LINEAR=0; without planes from the caller exactly the shapes round 4 / 5 sent to the fp16x3 edge-tile kernels, so a narrower
+    product keeps its bf16x6 kernel unless the caller hands in planes) and, here, what the kernel asks of its pointers."""
+    return (not accumulate and lda % 4 == 0 and ldw % 4 == 0 and ldc % 4 == 0 and A.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
+            and out.data_ptr() % 16 == 0 and A.data_ptr() != out.data_ptr()
+            and _lib.load().gnnome_linear_planes_route(A.shape[0], A.shape[1], W.shape[0], 1 if given else 0) == 1)
 
 
 def linear(A, W, bias, out=None, accumulate=False, planes=None):

@@ -51,3 +51,69 @@ def test_operators_run_the_hip_kernels():
     h_new = torch.ops.gnnome_hip.node_aggregate(e_new, A1, A2, A3, in_ptr, ss, out_ptr, out_pos, out_dst, h.to(dev), sc.to(dev), sh.to(dev), 0)
     want_h = cpu_ops.node_aggregate(want_e, Pd[:, :H], Pd[:, H:2 * H], Pd[:, 2 * H:3 * H], cv, h.double(), 0, sc.double(), sh.double())
     assert (h_new.cpu().double() - want_h).abs().max() < 1e-3
+
+
+def test_operators_are_compiled_kernels_not_python():
+    """The CUDA (= HIP) and Meta kernels are registered from csrc/torch_ext.cpp, and the extension is bound to the library the ctypes side loaded."""
+    for n in ("build_graph_views", "encode", "linear", "linear_ref", "edge_gate", "node_aggregate", "edge_score"):
+        dump = torch._C._dispatch_dump(f"gnnome_hip::{n}")
+        assert "CUDA: registered at" in dump and "Meta: registered at" in dump and "torch_ext.cpp" in dump and "PythonModule" not in dump, dump
+    from gnnome_amd import _lib
+    assert torch.ops.gnnome_hip.abi_version() == _lib.ABI_VERSION
+
+
+@pytest.mark.gpu
+def test_operators_equal_the_ctypes_path_and_follow_the_current_stream():
+    """Same C entries underneath: bit-equal to gnnome_amd.ops; strided column blocks are taken as they are; the launch goes to the caller's stream."""
+    from gnnome_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(1)
+    n, e, H, hs = 500, 4000, 128, 64
+    src, dst = torch.randint(0, n, (e,), generator=g).int().to(dev), torch.randint(0, n, (e,), generator=g).int().to(dev)
+    views = ops.GraphViews(src, dst, n)
+    got = torch.ops.gnnome_hip.build_graph_views(src.long(), dst, n)   # any integer dtype comes in
+    for a, b in zip(got, (views.in_ptr, views.srt_src, views.srt_dst, views.srt_eid, views.out_ptr, views.out_pos, views.out_dst)):
+        assert torch.equal(a, b)
+    with pytest.raises(IndexError):
+        torch.ops.gnnome_hip.build_graph_views(src, dst, n - 50)
+    h, ee = torch.randn(n, H, generator=g).to(dev), (3 * torch.randn(e, H, generator=g)).to(dev)
+    Wc, bc = (torch.randn(5 * H, H, generator=g) / H ** 0.5).to(dev), torch.randn(5 * H, generator=g).to(dev)
+    W3 = (torch.randn(H, H, generator=g) / H ** 0.5).to(dev)
+    sc, sh = (0.5 + torch.rand(H, generator=g)).to(dev), torch.randn(H, generator=g).to(dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        P = torch.ops.gnnome_hip.linear(h, Wc, bc)
+        A1, A2, A3, B1, B2 = (P[:, i * H:(i + 1) * H] for i in range(5))
+        e_new = torch.ops.gnnome_hip.edge_gate(ee, B1, B2, views.srt_src, views.srt_dst, W3, sc, sh)
+        h_new = torch.ops.gnnome_hip.node_aggregate(e_new, A1, A2, A3, views.in_ptr, views.srt_src, views.out_ptr, views.out_pos, views.out_dst, h, sc, sh)
+    torch.cuda.current_stream().wait_stream(side)
+    P2 = ops.linear(h, Wc, bc)
+    assert torch.equal(P, P2)
+    e2 = ops.edge_gate(ee.clone(), P2[:, 3 * H:4 * H], P2[:, 4 * H:], views, W3, 0, sc, sh)
+    assert torch.equal(e_new, e2)
+    assert torch.equal(h_new, ops.node_aggregate(e2, P2[:, :H], P2[:, H:2 * H], P2[:, 2 * H:3 * H], views, h, 0, sc, sh))
+    assert torch.equal(torch.ops.gnnome_hip.linear_ref(h, Wc, bc), ops.linear_ref(h, Wc, bc))
+    assert torch.equal(torch.ops.gnnome_hip.linear(h, Wc[:64], None), ops.linear(h, Wc[:64], None))     # a shape outside the planes route
+    # encoder with and without the gather; the scorer
+    x = torch.randn(e, 2, generator=g).to(dev)
+    W1, b1 = torch.randn(16, 2, generator=g).to(dev), torch.randn(16, generator=g).to(dev)
+    W2, b2 = (torch.randn(H, 16, generator=g) / 4).to(dev), torch.randn(H, generator=g).to(dev)
+    assert torch.equal(torch.ops.gnnome_hip.encode(x, W1, b1, W2, b2), ops.encode(x, W1, b1, W2, b2))
+    assert torch.equal(torch.ops.gnnome_hip.encode(x, W1, b1, W2, b2, views.srt_eid), ops.encode(x, W1, b1, W2, b2, gather=views.srt_eid, rows=e))
+    PQ = torch.randn(n, 2 * hs, generator=g).to(dev)
+    W1e = (torch.randn(hs, H, generator=g) / H ** 0.5).to(dev)
+    V2, c2 = (torch.randn(32, hs, generator=g) / 8).to(dev), torch.randn(32, generator=g).to(dev)
+    V3, c3 = torch.randn(32, generator=g).to(dev), torch.randn(1, generator=g).to(dev)
+    got = torch.ops.gnnome_hip.edge_score(e_new, PQ[:, :hs], PQ[:, hs:], views.srt_src, views.srt_dst, views.srt_eid, W1e, V2, c2, V3, c3)
+    want = ops.edge_score(e_new, PQ[:, :hs], PQ[:, hs:], views, W1e, V2, c2, V3, c3, torch.empty(e, device=dev))
+    assert torch.equal(got, want)
+    # what the operators refuse: the wrong dtype, a transposed matrix, tables of different projections
+    with pytest.raises(RuntimeError):
+        torch.ops.gnnome_hip.linear(h.double(), Wc, bc)
+    with pytest.raises(RuntimeError):
+        torch.ops.gnnome_hip.linear(h, Wc.t().contiguous().t(), bc)
+    with pytest.raises(RuntimeError):
+        torch.ops.gnnome_hip.edge_gate(ee, B1, B2.contiguous(), views.srt_src, views.srt_dst, W3, sc, sh)
+    with pytest.raises(RuntimeError):
+        torch.ops.gnnome_hip.edge_gate(ee, B1, B2, views.srt_src.long(), views.srt_dst, W3, sc, sh)
