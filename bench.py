@@ -891,6 +891,8 @@ def main():
             gate_ms, gate_n = kt.mean_ms(timed[0])
             gate_flops = 2.0 * e_gate * hidden * hidden
             gate_bytes = 2.0 * e_gate * hidden * 4 + 2 * e_gate * 4   # read e, write e', read src/dst (B_layer's edge part)
+            # the kernel's own operands touched once: + the two node tables it gathers from (B1h, B2h) and W3 - the same two figures the aggregation's record carries
+            gate_operand_bytes = gate_bytes + 2.0 * (n if world == 1 else plan.n_local) * hidden * 4 + hidden * hidden * 4.0
             # round 4: the forward's dense products run as fp16x3 (two fp16 planes per fp32 operand, three f16 MFMAs per K = 16 step - csrc/edge_tile_f16.hip)
             # unless --tuning 10=1 asks for round 3's bf16x6 (six); H = 64 still runs bf16x6
             terms = 6.0 if (hidden == 64 or "10=1" in (args.tuning or "").replace(" ", "")) else 3.0
@@ -903,7 +905,7 @@ def main():
                     "bound": "hbm", "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK,
                     "traffic": _pmc_traffic(args.workload, "k_edge_gate_pl<false, 0," if hidden == 128 else "k_edge_gate_bf") if (world == 1 and args.kind == "banded") else None,
-                    "avg_launch_ms": gate_ms, "launches": gate_n, "algorithmic_bytes_per_launch": gate_bytes,
+                    "avg_launch_ms": gate_ms, "launches": gate_n, "algorithmic_bytes_per_launch": gate_bytes, "operand_bytes_per_launch": gate_operand_bytes,
                     "fp32_equivalent_flops_per_launch": gate_flops, "fp32_equivalent_tflops": gate_flops / (gate_ms * 1e-3) / 1e12,
                     "mfma_16bit_frac": terms * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK, "arithmetic": arith,
                 }
@@ -915,7 +917,7 @@ def main():
                     "bound": "hbm", "achieved": gate_bytes / (gate_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK,
                     "traffic": _pmc_traffic(args.workload, "k_edge_tile_f16<0") if (world == 1 and args.kind == "banded") else None,
-                    "avg_launch_ms": gate_ms, "launches": gate_n, "algorithmic_bytes_per_launch": gate_bytes,
+                    "avg_launch_ms": gate_ms, "launches": gate_n, "algorithmic_bytes_per_launch": gate_bytes, "operand_bytes_per_launch": gate_operand_bytes,
                     "fp32_equivalent_tflops": gate_flops / (gate_ms * 1e-3) / 1e12,
                     "mfma_16bit_frac": terms * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK, "arithmetic": arith,
                     "bf16x6_equivalent_mfma_frac": 6.0 * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK,
@@ -929,7 +931,7 @@ def main():
                     "frac": 6.0 * gate_flops / (gate_ms * 1e-3) / MFMA_BF16_PEAK, "traffic": None,
                     "avg_launch_ms": gate_ms, "launches": gate_n, "bf16_flops_per_launch": 6.0 * gate_flops,
                     "fp32_equivalent_tflops": gate_flops / (gate_ms * 1e-3) / 1e12,
-                    "algorithmic_bytes_per_launch": gate_bytes, "hbm_frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK, "arithmetic": arith,
+                    "algorithmic_bytes_per_launch": gate_bytes, "operand_bytes_per_launch": gate_operand_bytes, "hbm_frac": gate_bytes / (gate_ms * 1e-3) / HBM_PEAK, "arithmetic": arith,
                 }
             if world > 1:
                 res["roofline"]["note"] = f"rank 0's launches: {e_gate} local edges (its node range's in- and out-edges)"
