@@ -19,6 +19,9 @@ for w in c2 c4shard; do
   python tools/pmc_forward_json.py $O/pmc_fwd_$w $O/${TAG}_forward_pmc_$w.json $w > /dev/null; cp $O/${TAG}_forward_pmc_$w.json profiles/; rm -rf $O/pmc_fwd_$w
 done
 bash tools/pmc_forward.sh $O/pmc_train c2 train > $O/${TAG}_train_hbm_traffic_c2.md 2>&1; python tools/pmc_forward_json.py $O/pmc_train $O/${TAG}_train_pmc_c2.json c2-train > /dev/null; rm -rf $O/pmc_train
+# MFMA-busy counters of this build BEFORE the bench lines: bench.py quotes them as `mfma_util` when the stamp matches the library it runs
+bash tools/pmc_mfma.sh $O/pmc_mfma > $O/pmc_mfma.log 2>&1; python tools/pmc_mfma_to_json.py $O/pmc_mfma $O/${TAG}_mfma_busy.json > $O/${TAG}_mfma_busy.txt 2>&1
+cp $O/${TAG}_mfma_busy.json profiles/; rm -rf $O/pmc_mfma; tail -12 $O/${TAG}_mfma_busy.txt
 timeout 900 python bench.py > $O/${TAG}_bench_c2.json 2> $O/bench_c2.err; tail -c 400 $O/${TAG}_bench_c2.json
 for w in 10m parity64 c4shard; do timeout 400 python bench.py --workload $w --no-cpu-baseline --no-extras > $O/${TAG}_bench_$w.json 2>/dev/null; done
 # the whole configs[3] graph and the configs[4] graph (inference) on ONE GPU: H = 256, 20M / 50M edges
@@ -35,6 +38,11 @@ timeout 400 python bench.py --workload c4shard --mode train --steps 5 --warmup 2
 timeout 400 python bench.py --workload ecoli > $O/${TAG}_bench_ecoli.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_ecoli -o r -- python bench.py --workload ecoli --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timers --no-extras > /dev/null 2> $O/prof_ecoli.err
 python tools/rocpd_summary.py "$(find $O/prof_ecoli -name '*.db' | head -1)" > $O/${TAG}_ecoli.kernel_stats.md 2>&1; rm -rf $O/prof_ecoli
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_c4t -o r -- python bench.py --workload c4shard --mode train --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-extras > /dev/null 2> $O/prof_c4t.err
+python tools/rocpd_summary.py "$(find $O/prof_c4t -name '*.db' | head -1)" > $O/${TAG}_c4shard_train.kernel_stats.md 2>&1; rm -rf $O/prof_c4t
+for w in c2 10m c4quarter; do timeout 300 python bench.py --gpus 8 --one-gpu-gloo --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_n8_plumbing_$w.json 2>/dev/null; done
+timeout 300 python bench.py --gpus 8 --one-gpu-gloo --mode train --workload c2 --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_n8_plumbing_train_c2.json 2>/dev/null
+timeout 300 python bench.py --gpus 8 --one-gpu-gloo --mode train --workload c4quarter --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_n8_plumbing_train_c4quarter.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c4 -o r -- python bench.py --workload c4shard --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-extras > /dev/null 2> $O/prof_c4.err
 python tools/rocpd_summary.py "$(find $O/prof_c4 -name '*.db' | head -1)" > $O/${TAG}_c4shard_infer.kernel_stats.md 2>&1; rm -rf $O/prof_c4
 timeout 200 python tools/gate_phase_profile.py --hidden 256 --edges 2500000 2>&1 | grep -v amdgpu.ids > $O/${TAG}_gate256_phases.txt
