@@ -477,7 +477,7 @@ def run_partitioned(ops, prep, part, x_local, e_local, group=None, reduce_result
     pw = prep.predictor
     hs = pw["hs"]
     xchg.finish()
-    PQ = ops.linear(h, pw["W_nodes"], pw["b_nodes"])
+    PQ = ops.linear(h, pw["W_nodes"], pw["b_nodes"], planes=pw.get("planes"))
     score_views = _ScoreViews(views, part.srt_geid)
     if _alone(part.world) or not reduce_result:
         # scatter straight to GLOBAL edge ids: a GraphViews-like shim whose srt_eid is the global map
@@ -534,7 +534,7 @@ class CapturedPartitionedForward:
         def score():
             pw = prep.predictor
             hs = pw["hs"]
-            PQ = ops.linear(state["h"], pw["W_nodes"], pw["b_nodes"])
+            PQ = ops.linear(state["h"], pw["W_nodes"], pw["b_nodes"], planes=pw.get("planes"))
             sv = _ScoreViews(views, part.srt_geid)
             if alone:
                 self.piece = torch.empty(part.num_edges_global, dtype=torch.float32, device=dev)

@@ -209,10 +209,11 @@ def prepare_predictor(pred, device):
     # node halves stacked into one [2*hs, H] projection: rows 0..hs-1 act on x[src], rows hs.. on x[dst] (+ b1)
     W_nodes = torch.cat([W1[:, :hidden], W1[:, hidden:2 * hidden]], 0).contiguous()
     b_nodes = torch.cat([torch.zeros_like(b1), b1])
-    # the node halves' projection on W_nodes' fp16x3 planes where ops.linear routes that shape there by itself (made once instead of per call)
+    # the node halves' projection on W_nodes' fp16x3 planes (made once) from 128 output columns on: at H = 128, hs = 64 26.5 against 35 us on the
+    # bf16x6 kernel ops.linear picks for that shape by itself, and 9.6e-7 against 4.2e-6 from an fp64 product; at 2 hs = 64 the bf16x6 kernel is
+    # level (20 against 21.5 us) and stays (tools/score_nodes_time.py)
     planes_ok = getattr(hip_ops, "planes_supported", None)
-    planes = (hip_ops.weight_planes(W_nodes) if planes_ok is not None and W_nodes.is_cuda and planes_ok(hidden, 2 * hs) and (2 * hs) % 128 == 0
-              and (hidden == 256 or 2 * hs >= 256) else None)
+    planes = (hip_ops.weight_planes(W_nodes) if planes_ok is not None and W_nodes.is_cuda and planes_ok(hidden, 2 * hs) and 2 * hs >= 128 else None)
     return {
         "planes": planes,
         "hidden": hidden, "hs": hs, "model_hidden": width, "W_nodes": W_nodes, "b_nodes": dev(b_nodes), "W1_e": W1[:, 2 * hidden:],
