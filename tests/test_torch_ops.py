@@ -4,7 +4,13 @@ import pytest
 import torch
 
 import cpu_ops
-import gnnome_amd.torch_ops  # noqa: F401  (registers the operators)
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _operators():
+    """Load the compiled extension (gnnome_amd/lib/libgnnome_torch.so) when the first test of this module runs - a missing or stale build fails
+    these tests, not the collection of the whole suite."""
+    import gnnome_amd.torch_ops  # noqa: F401
 
 
 def test_operators_are_registered_with_schemas_and_trace_on_meta():
