@@ -56,7 +56,9 @@ int rows_ld(const Tensor& t, const char* name) {
     f32(t, name);
     TORCH_CHECK(t.dim() == 2 && (t.size(1) <= 1 || t.stride(1) == 1), name, ": expected a 2-D tensor with contiguous rows, got sizes ", t.sizes(),
                 " strides ", t.strides());
-    return (int)(t.size(0) > 1 ? t.stride(0) : std::max<int64_t>(t.stride(0), t.size(1)));
+    const int64_t ld = t.size(0) > 1 ? t.stride(0) : std::max<int64_t>(t.stride(0), t.size(1));
+    TORCH_CHECK(ld >= t.size(1) && ld <= INT32_MAX, name, ": row stride ", ld, " outside what the C ABI takes (an int, >= the row's width)");
+    return (int)ld;
 }
 
 bool aligned16(const Tensor& t) { return reinterpret_cast<uintptr_t>(t.const_data_ptr()) % 16 == 0; }
