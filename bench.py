@@ -861,7 +861,7 @@ def main():
             "mfma_f32_frac_whole_fwd": (f_fwd / (ms * 1e-3)) / (world * MFMA_F32_PEAK),
             "algorithmic_bytes_fwd": b_fwd, "algorithmic_flops_fwd": f_fwd, "cold": cold, "timed_region_s": elapsed,
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_ms_per_forward_queue_empty": host_unblocked_ms,
-            "forward_entry": "gnnome_model_forward_f32 (one library call per forward)" if one_call else "per-kernel entries, call by call",
+            "forward_entry": ("gnnome_model_forward_buffers_f32 (one library call per forward, buffers allocated one by one)" if ops.FORWARD_BUFFERS != "block" else "gnnome_model_forward_f32 (one library call per forward, one workspace block)") if one_call else "per-kernel entries, call by call",
             "so_sha16": so_sha16(),
             "streams": (f"2: every node projection after the first runs on a second HIP stream under the aggregation, which is cut into "
                         f"{chunks_timed} node ranges (engine.aggregate_then_project)") if chunks_timed > 1 else "1",

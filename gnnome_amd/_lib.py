@@ -45,6 +45,7 @@ SIGNATURES = {
     "gnnome_debug_forward_events": [_p, _p, _p, _p, _i],
     "gnnome_model_forward_workspace_bytes": [_l, _l, _i, _i, ctypes.POINTER(_sz)],
     "gnnome_model_forward_f32": [_p, _p, _p, _p, _p, _p, _sz, _p],
+    "gnnome_model_forward_buffers_f32": [_p, _p, _p, _p, _p, _p, _p],
     "gnnome_edge_gate_raw_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p],
     "gnnome_edge_gate_raw_stats_rows": [_i, ctypes.POINTER(_i)],
     "gnnome_edge_gate_raw_stats_f32": [_p, _p, _l, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p],
@@ -111,7 +112,7 @@ SIGNATURES = {
     "gnnome_edge_loss_f32": [_p, _p, _p, _l, _p, ctypes.c_float, ctypes.c_float, _p, _p, _p, _p, _p, _sz, _p],
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 # the parameter blocks of gnnome_model_forward_f32 (include/gnnome_hip.h), field for field
@@ -131,6 +132,12 @@ class Views(ctypes.Structure):
     _fields_ = ([("num_nodes", ctypes.c_int64), ("num_edges", ctypes.c_int64)]
                 + [(n, _p) for n in ("in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst", "node_gather")]
                 + [("transposed", ctypes.c_int32), ("reserved", ctypes.c_int32)])
+
+
+class ForwardBuffers(ctypes.Structure):
+    _fields_ = [("h", _p * 2), ("P", _p), ("e", _p * 2), ("PQ", _p)]
+
+
 NORM_AFFINE = 0
 NORM_LAYER = 1
 

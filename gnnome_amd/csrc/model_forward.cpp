@@ -77,16 +77,29 @@ extern "C" int gnnome_model_forward_workspace_bytes(int64_t num_nodes, int64_t n
         if (rc__ != GNNOME_OK) return rc__; \
     } while (0)
 
+namespace gnnome {
+namespace {
+int forward_on(const gnnome_model_params* m, const gnnome_views* g, const float* x, const float* e_raw, float* logits, float* const h[2], float* P,
+               float* const eb[2], float* PQ, void* stream);
+}  // namespace
+}  // namespace gnnome
+
+static int check_model(const gnnome_model_params* m, const gnnome_views* g) {
+    using namespace gnnome;
+    GN_REQUIRE(m && g, "model_forward: null parameter block");
+    const int H = m->hidden, hs = m->score_hidden, L = m->num_layers;
+    GN_REQUIRE(g->num_nodes >= 0 && g->num_edges >= 0 && L >= 0 && (L == 0 || m->layers_host != nullptr), "model_forward: bad sizes");
+    GN_REQUIRE(H == 64 || H == 128 || H == 256, "model_forward: hidden=%d (the kernels are built for 64 / 128 / 256; pad narrower models)", H);
+    GN_REQUIRE(hs == 32 || hs == 64 || hs == 128, "model_forward: score_hidden=%d (built for 32 / 64 / 128)", hs);
+    return GNNOME_OK;
+}
+
 extern "C" int gnnome_model_forward_f32(const gnnome_model_params* m, const gnnome_views* g, const float* x, const float* e_raw, float* logits,
                                         void* workspace, size_t workspace_bytes, void* stream) {
     using namespace gnnome;
-    GN_REQUIRE(m && g, "model_forward: null parameter block");
+    GN_TRY(check_model(m, g));
     const int64_t N = g->num_nodes, E = g->num_edges;
-    const int H = m->hidden, hs = m->score_hidden, L = m->num_layers;
-    GN_REQUIRE(N >= 0 && E >= 0 && L >= 0 && (L == 0 || m->layers_host != nullptr), "model_forward: bad sizes");
-    GN_REQUIRE(H == 64 || H == 128 || H == 256, "model_forward: hidden=%d (the kernels are built for 64 / 128 / 256; pad narrower models)", H);
-    GN_REQUIRE(hs == 32 || hs == 64 || hs == 128, "model_forward: score_hidden=%d (built for 32 / 64 / 128)", hs);
-    const Workspace ws = layout(N, E, H, hs);
+    const Workspace ws = layout(N, E, m->hidden, m->score_hidden);
     if (workspace_bytes < ws.total) {
         set_error("model_forward: workspace of %zu bytes, %zu needed", workspace_bytes, ws.total);
         return GNNOME_EWORKSPACE;
@@ -95,9 +108,35 @@ extern "C" int gnnome_model_forward_f32(const gnnome_model_params* m, const gnno
     GN_REQUIRE(E == 0 || logits != nullptr, "model_forward: null logits");
     char* base = static_cast<char*>(workspace);
     float* h[2] = {reinterpret_cast<float*>(base + ws.h[0]), reinterpret_cast<float*>(base + ws.h[1])};
-    float* P = reinterpret_cast<float*>(base + ws.P);
     float* eb[2] = {reinterpret_cast<float*>(base + ws.e[0]), reinterpret_cast<float*>(base + ws.e[1])};
-    float* PQ = reinterpret_cast<float*>(base + ws.PQ);
+    return forward_on(m, g, x, e_raw, logits, h, reinterpret_cast<float*>(base + ws.P), eb, reinterpret_cast<float*>(base + ws.PQ), stream);
+}
+
+// The same forward on buffers the caller allocated ONE BY ONE (round 6).  Where the driver places a buffer in HBM is worth 3 % of configs[1]'s forward, and
+// one block holding everything comes out on the slow side of that more often than five blocks of their own do (4.24 against 4.10 ms on the same box, the
+// kernels being the same: NOTES round 6, profiles/r06_placement_*.txt) - gnnome_amd.ops.model_forward hands over torch allocations.
+extern "C" int gnnome_model_forward_buffers_f32(const gnnome_model_params* m, const gnnome_views* g, const float* x, const float* e_raw, float* logits,
+                                                const gnnome_forward_buffers* b, void* stream) {
+    using namespace gnnome;
+    GN_TRY(check_model(m, g));
+    GN_REQUIRE(b != nullptr, "model_forward_buffers: null buffer block");
+    const int64_t N = g->num_nodes, E = g->num_edges;
+    GN_REQUIRE(E == 0 || logits != nullptr, "model_forward_buffers: null logits");
+    GN_REQUIRE(N == 0 || (b->h[0] && b->h[1] && b->P && b->PQ && b->h[0] != b->h[1]), "model_forward_buffers: node buffers h[0], h[1], P, PQ");
+    GN_REQUIRE(E == 0 || (b->e[0] && (m->hidden != 256 || (b->e[1] && b->e[1] != b->e[0]))), "model_forward_buffers: edge buffers e[0] (and e[1] at hidden = 256)");
+    for (const void* p : {(const void*)b->h[0], (const void*)b->h[1], (const void*)b->P, (const void*)b->e[0], (const void*)b->e[1], (const void*)b->PQ})
+        GN_REQUIRE((uintptr_t)p % 16 == 0, "model_forward_buffers: buffers must be 16-byte aligned");
+    float* h[2] = {b->h[0], b->h[1]};
+    float* eb[2] = {b->e[0], m->hidden == 256 ? b->e[1] : b->e[0]};
+    return forward_on(m, g, x, e_raw, logits, h, b->P, eb, b->PQ, stream);
+}
+
+namespace gnnome {
+namespace {
+int forward_on(const gnnome_model_params* m, const gnnome_views* g, const float* x, const float* e_raw, float* logits, float* const h[2], float* P,
+               float* const eb[2], float* PQ, void* stream) {
+    const int64_t N = g->num_nodes, E = g->num_edges;
+    const int H = m->hidden, hs = m->score_hidden, L = m->num_layers;
 
     // models/full_graph.py:26 - the node encoder, rows in the views' numbering
     GN_TRY(gnnome_encode_f32(x, N, m->node_features, g->node_gather, m->node_W1, m->node_b1, m->hidden_ne, m->node_W2, m->node_b2, H, h[0], stream));
@@ -158,3 +197,5 @@ extern "C" int gnnome_model_forward_f32(const gnnome_model_params* m, const gnno
     return gnnome_edge_score_f32(e, E, H, hs, Ps, Qd, 2 * hs, g->srt_src, g->srt_dst, g->srt_eid, m->W1e, m->ld_w1e, m->W2, m->b2, m->W3, m->b3, logits,
                                  nullptr, stream);
 }
+}  // namespace
+}  // namespace gnnome

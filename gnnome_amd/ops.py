@@ -382,24 +382,45 @@ def _views_block(views):
 _WS_BYTES = {}
 
 
+# Where the forward's buffers lie in HBM (round 6).  The same build on the same box runs configs[1]'s forward at one of three levels - 4.06-4.11,
+# 4.16-4.22 or 4.24-4.26 ms - and the level is a property of the BLOCKS the driver handed out: it does not move while a block is reused
+# (tools/placement_probe.py "same"), it changes when the forward gets a fresh block ("hold"), it depends neither on the buffers' offsets inside a
+# block nor on virtual addresses, blocks of >= 1 GiB all land on one level, and ONE block holding h, P, e and PQ comes out slow far more often than
+# the same buffers as allocations of their own (4.24 against 4.10 ms on one box, `tools/ab_one_call.sh`; profiles/r06_placement_*.txt).  So the one-call
+# forward takes its buffers one by one (gnnome_model_forward_buffers_f32); "block" = one workspace (gnnome_model_forward_f32), for A/B runs.
+FORWARD_BUFFERS = _os.environ.get("GNNOME_FORWARD_BUFFERS", "separate")
+
+
 def model_forward(block, views, x, e_raw, logits=None):
-    """models/full_graph.py:22-30 as ONE library call (gnnome_model_forward_f32): x[N, node_features], e_raw[E, edge_features] contiguous CUDA
+    """models/full_graph.py:22-30 as ONE library call (gnnome_model_forward_buffers_f32): x[N, node_features], e_raw[E, edge_features] contiguous CUDA
     float32 in the caller's numbering -> logits[E] in edge-id order.  `block` = ModelBlock(prepared parameters)."""
     lib = _lib.load()
     dev = x.device
     m = block.params
-    key = (views.num_nodes, views.num_edges, m.hidden, m.score_hidden)
-    need = _WS_BYTES.get(key)
-    if need is None:
-        n = ctypes.c_size_t(0)
-        _lib.check(lib.gnnome_model_forward_workspace_bytes(views.num_nodes, views.num_edges, m.hidden, m.score_hidden, ctypes.byref(n)), "model_forward_workspace_bytes")
-        need = _WS_BYTES[key] = n.value
-    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)   # (torch's blocks are 512-byte aligned)
+    n, e, H, hs = views.num_nodes, views.num_edges, m.hidden, m.score_hidden
     if logits is None:
-        logits = torch.empty(views.num_edges, dtype=torch.float32, device=dev)
+        logits = torch.empty(e, dtype=torch.float32, device=dev)
+    if FORWARD_BUFFERS == "block":
+        key = (n, e, H, hs)
+        need = _WS_BYTES.get(key)
+        if need is None:
+            nb = ctypes.c_size_t(0)
+            _lib.check(lib.gnnome_model_forward_workspace_bytes(n, e, H, hs, ctypes.byref(nb)), "model_forward_workspace_bytes")
+            need = _WS_BYTES[key] = nb.value
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)   # (torch's blocks are 512-byte aligned)
+        with _on(dev):
+            _lib.check(lib.gnnome_model_forward_f32(ctypes.byref(m), ctypes.byref(_views_block(views)), _ptr(x), _ptr(e_raw), _ptr(logits), _ptr(ws), need,
+                                                    _stream(dev)), "model_forward_f32")
+        return logits
+    mk = lambda rows, cols: torch.empty((max(rows, 1), cols), dtype=torch.float32, device=dev)  # noqa: E731  (stream-ordered: freed when this returns)
+    h0, h1, P, PQ, e0 = mk(n, H), mk(n, H), mk(n, 5 * H), mk(n, 2 * hs), mk(e, H)
+    e1 = mk(e, H) if H == 256 else None
+    bufs = _lib.ForwardBuffers()
+    bufs.h[0], bufs.h[1], bufs.P, bufs.PQ = h0.data_ptr(), h1.data_ptr(), P.data_ptr(), PQ.data_ptr()
+    bufs.e[0], bufs.e[1] = e0.data_ptr(), (e1.data_ptr() if e1 is not None else None)
     with _on(dev):
-        _lib.check(lib.gnnome_model_forward_f32(ctypes.byref(m), ctypes.byref(_views_block(views)), _ptr(x), _ptr(e_raw), _ptr(logits), _ptr(ws), need,
-                                                _stream(dev)), "model_forward_f32")
+        _lib.check(lib.gnnome_model_forward_buffers_f32(ctypes.byref(m), ctypes.byref(_views_block(views)), _ptr(x), _ptr(e_raw), _ptr(logits),
+                                                        ctypes.byref(bufs), _stream(dev)), "model_forward_buffers_f32")
     return logits
 
 

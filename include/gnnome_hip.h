@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GNNOME_ABI_VERSION 16
+#define GNNOME_ABI_VERSION 17
 
 #define GNNOME_OK 0
 #define GNNOME_EINVAL (-1)    /* bad argument (null pointer, unsupported width, bad stride)      */
@@ -345,6 +345,18 @@ int gnnome_debug_forward_events(void* gate_start, void* gate_stop, void* aggrega
 int gnnome_model_forward_workspace_bytes(int64_t num_nodes, int64_t num_edges, int hidden, int score_hidden, size_t* bytes_host);
 int gnnome_model_forward_f32(const gnnome_model_params* params_host, const gnnome_views* views_host, const float* x, const float* e_raw,
                              float* logits, void* workspace, size_t workspace_bytes, void* stream);
+/* The same forward on buffers the caller allocated one by one instead of one workspace block (round 6): where the driver places a buffer in HBM is
+ * worth ~3 % of the forward at configs[1], and separate allocations come out on the fast side more often than one block holding everything
+ * (NOTES.md round 6).  h[0], h[1] [N, hidden]; P [N, 5 hidden]; e[0] [E, hidden], and e[1] (another [E, hidden], used at hidden = 256 only, may be NULL
+ * otherwise); PQ [N, 2 score_hidden]; all 16-byte aligned, distinct, contents undefined on entry and on return. */
+typedef struct gnnome_forward_buffers {
+    float* h[2];
+    float* P;
+    float* e[2];
+    float* PQ;
+} gnnome_forward_buffers;
+int gnnome_model_forward_buffers_f32(const gnnome_model_params* params_host, const gnnome_views* views_host, const float* x, const float* e_raw,
+                                     float* logits, const gnnome_forward_buffers* buffers_host, void* stream);
 
 /* ================================================================================================
  * Training step (train.py:138-145 + :328-330: forward in train mode, BCE-with-logits, loss.backward()).

@@ -104,3 +104,26 @@ def test_one_call_follows_the_bf16x6_switch_and_the_range_fallback():
     assert torch.equal(a, b)
     fp16 = model((g["src"], g["dst"], n), x, ed)
     assert not torch.equal(a, fp16) and (torch.sigmoid(a) - torch.sigmoid(fp16)).abs().max() < 1e-4
+
+
+
+def test_separate_buffers_and_one_block_give_the_same_bits():
+    """gnnome_model_forward_buffers_f32 (the default since round 6: buffers allocated one by one) against gnnome_model_forward_f32 on one workspace block."""
+    old = ops.FORWARD_BUFFERS
+    try:
+        for hidden, hs in ((128, 64), (256, 64), (64, 32)):
+            n, e = 4000, 41000
+            g = make_graph(n, e, seed=hidden)
+            model = _model(hidden, hs, "batch")
+            x = torch.randn(n, 2, generator=torch.Generator().manual_seed(5)).to(dev())
+            views = views_for((g["src"], g["dst"], n), dev())
+            ops.FORWARD_BUFFERS = "separate"
+            a = model(views, x, g["e"].to(dev())).clone()
+            ops.FORWARD_BUFFERS = "block"
+            b = model(views, x, g["e"].to(dev()))
+            assert torch.equal(a, b)
+        ops.FORWARD_BUFFERS = "separate"
+        empty = model((torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int32), 6), torch.randn(6, 2).to(dev()), torch.zeros(0, 2).to(dev()))
+        assert empty.shape == (0, 1)
+    finally:
+        ops.FORWARD_BUFFERS = old
