@@ -1,10 +1,10 @@
-// gnnome_model_forward_f32: models/full_graph.py:22-30 as one host call (round 6).
+// gnnome_model_forward_f32 / gnnome_model_forward_buffers_f32: models/full_graph.py:22-30 as one host call (round 6).
 //
 // A sequencer over the library's own per-kernel entries, in the order gnnome_amd/engine.py::run_stack calls them: it adds no kernel and no
-// arithmetic, it removes ~30 interpreter round trips (0.63 ms of host time per forward at configs[1]; at the size of the reference's E. coli
-// example the forward was 0.78 ms of which 0.65 host).  Every decision run_stack takes per layer is taken here the same way: the
+// arithmetic, it removes ~30 interpreter round trips (host time per forward with an empty launch queue 0.15 against 0.48 ms; a forward that
+// keeps the GPU busy was never waiting for them).  Every decision run_stack takes per layer is taken here the same way: the
 // reference-order kernels per layer, the edge encoder folded into layer 0's gate, the two [E,H] buffers taking turns at H = 256, the
-// projection on the weights' fp16x3 planes.
+// projection on the weights' fp16x3 planes.  The buffers come as one workspace block or one by one (placement in HBM: DESIGN.md section 4).
 #include "common.h"
 
 namespace gnnome {
