@@ -153,6 +153,17 @@ class ForwardEventTimer:
         return sum(s.elapsed_time(t) for s, t in ev) / max(len(ev), 1), len(ev)
 
 
+def _placement_record(ops):
+    """What gnnome_amd.ops._placed_buffers did for this run's forward: the candidates' forward times, per buffer group ("Placement")."""
+    placed = [st for st in getattr(ops, "_PLACED", {}).values() if st.bufs is not None and st.log]
+    if not placed:
+        return {"tuned": False, "note": "buffers as the allocator handed them out (GNNOME_TUNE_PLACEMENT=0, a workspace block, or shapes whose placement does not vary)"}
+    log = placed[-1].log
+    return {"tuned": True, "start_ms": round(log[0][1], 4), "kept_ms": round(min(t for _, t in log), 4),
+            "candidates_ms": [("+".join(g) if not isinstance(g, str) else g, round(t, 4)) for g, t in log[1:]],
+            "note": "forward time with each candidate allocation of a buffer group, all else fixed; the fastest is kept for (device, stream, shapes) - same kernels, same bits"}
+
+
 def _mfma_util(workload_key):
     """Matrix-core utilisation per kernel from the committed PMC pass over this workload (tools/pmc_mfma.sh -> profiles/<tag>_mfma_busy.json:
     SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE x SIMDs, per the guide's PMC section; north_star: "MFMA utilisation ... against CDNA4 peak").
@@ -861,6 +872,7 @@ def main():
             "mfma_f32_frac_whole_fwd": (f_fwd / (ms * 1e-3)) / (world * MFMA_F32_PEAK),
             "algorithmic_bytes_fwd": b_fwd, "algorithmic_flops_fwd": f_fwd, "cold": cold, "timed_region_s": elapsed,
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_ms_per_forward_queue_empty": host_unblocked_ms,
+            "placement": _placement_record(ops) if one_call else None,
             "forward_entry": ("gnnome_model_forward_buffers_f32 (one library call per forward, buffers allocated one by one)" if ops.FORWARD_BUFFERS != "block" else "gnnome_model_forward_f32 (one library call per forward, one workspace block)") if one_call else "per-kernel entries, call by call",
             "so_sha16": so_sha16(),
             "streams": (f"2: every node projection after the first runs on a second HIP stream under the aggregation, which is cut into "

@@ -412,16 +412,99 @@ def model_forward(block, views, x, e_raw, logits=None):
             _lib.check(lib.gnnome_model_forward_f32(ctypes.byref(m), ctypes.byref(_views_block(views)), _ptr(x), _ptr(e_raw), _ptr(logits), _ptr(ws), need,
                                                     _stream(dev)), "model_forward_f32")
         return logits
-    mk = lambda rows, cols: torch.empty((max(rows, 1), cols), dtype=torch.float32, device=dev)  # noqa: E731  (stream-ordered: freed when this returns)
-    h0, h1, P, PQ, e0 = mk(n, H), mk(n, H), mk(n, 5 * H), mk(n, 2 * hs), mk(e, H)
-    e1 = mk(e, H) if H == 256 else None
-    bufs = _lib.ForwardBuffers()
-    bufs.h[0], bufs.h[1], bufs.P, bufs.PQ = h0.data_ptr(), h1.data_ptr(), P.data_ptr(), PQ.data_ptr()
-    bufs.e[0], bufs.e[1] = e0.data_ptr(), (e1.data_ptr() if e1 is not None else None)
+    shapes = {"h0": (n, H), "h1": (n, H), "P": (n, 5 * H), "PQ": (n, 2 * hs), "e0": (e, H)}
+    if H == 256:
+        shapes["e1"] = (e, H)
+    vb = _views_block(views)
+
+    def run(t):
+        bufs = _lib.ForwardBuffers()
+        bufs.h[0], bufs.h[1], bufs.P, bufs.PQ = t["h0"].data_ptr(), t["h1"].data_ptr(), t["P"].data_ptr(), t["PQ"].data_ptr()
+        bufs.e[0], bufs.e[1] = t["e0"].data_ptr(), (t["e1"].data_ptr() if "e1" in t else None)
+        _lib.check(lib.gnnome_model_forward_buffers_f32(ctypes.byref(m), ctypes.byref(vb), _ptr(x), _ptr(e_raw), _ptr(logits), ctypes.byref(bufs),
+                                                        _stream(dev)), "model_forward_buffers_f32")
+
     with _on(dev):
-        _lib.check(lib.gnnome_model_forward_buffers_f32(ctypes.byref(m), ctypes.byref(_views_block(views)), _ptr(x), _ptr(e_raw), _ptr(logits),
-                                                        ctypes.byref(bufs), _stream(dev)), "model_forward_buffers_f32")
+        run(_placed_buffers(dev, shapes, run))
     return logits
+
+
+# Placement of the forward's buffers (see FORWARD_BUFFERS above): a forward that is asked for again and again with the same shapes gets its buffers PLACED
+# once - on its PLACEMENT_AFTER_USES-th use, for the edge buffer(s), then P, then the three [N,*] buffers, a few fresh allocations of that group are timed
+# with the forward itself (everything else held fixed; same bits from every candidate) and the fastest is kept for that (device, stream, shapes); the rest
+# goes back to torch's allocator.  Only where placement varies: every buffer below 1 GiB (larger blocks all land on one level), at least 64 MiB in all.
+# A graph scored once (inference.py:440) never gets here; a captured forward (hipGraph) keeps the graph pool's buffers.  GNNOME_TUNE_PLACEMENT=0: off.
+TUNE_PLACEMENT = _os.environ.get("GNNOME_TUNE_PLACEMENT", "1") != "0"
+PLACEMENT_AFTER_USES = 3
+PLACEMENT_CANDIDATES = 4
+PLACEMENT_MIN_TOTAL, PLACEMENT_MAX_BUFFER = 64 << 20, 1 << 30
+PLACEMENT_KEPT = 3          # (device, stream, shapes) entries that keep their buffers; the oldest placement is let go beyond that
+
+
+class _Placed:
+    __slots__ = ("uses", "tried", "bufs", "log")
+
+    def __init__(self):
+        self.uses, self.tried, self.bufs, self.log = 0, False, None, None
+
+
+_PLACED = {}
+
+
+def _placed_buffers(dev, shapes, run):
+    """name -> tensor for one forward: the kept set of this (device, stream, shapes) if there is one, transient allocations otherwise (freed, stream-ordered,
+    when the caller returns) - and on the PLACEMENT_AFTER_USES-th use of shapes whose placement varies, the set chosen as described above."""
+    mk = lambda name: torch.empty((max(shapes[name][0], 1), shapes[name][1]), dtype=torch.float32, device=dev)  # noqa: E731
+    sizes = [max(r, 1) * c * 4 for r, c in shapes.values()]
+    if not TUNE_PLACEMENT or sum(sizes) < PLACEMENT_MIN_TOTAL or max(sizes) >= PLACEMENT_MAX_BUFFER or torch.cuda.is_current_stream_capturing():
+        return {name: mk(name) for name in shapes}
+    stream = torch.cuda.current_stream(dev)
+    key = (dev.index, stream.cuda_stream) + tuple(sorted(shapes.items()))
+    st = _PLACED.get(key)
+    if st is None:
+        st = _PLACED[key] = _Placed()
+    if st.bufs is not None:
+        return st.bufs
+    st.uses += 1
+    cur = {name: mk(name) for name in shapes}
+    free = torch.cuda.mem_get_info(dev)[0]
+    if st.tried or st.uses < PLACEMENT_AFTER_USES or free < 2 * (PLACEMENT_CANDIDATES + 1) * sum(sizes):
+        return cur
+    st.tried = True
+
+    def time_of(t):
+        run(t)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(stream)
+        run(t)
+        run(t)
+        t1.record(stream)
+        t1.synchronize()
+        return t0.elapsed_time(t1) / 2
+
+    for _ in range(3):
+        run(cur)                                 # (the first forwards of a process run below the clock the later ones get)
+    best, log, rejected = time_of(cur), [], []
+    log.append(("start", best))
+    for group in (tuple(k for k in ("e0", "e1") if k in shapes), ("P",), ("h0", "h1", "PQ")):
+        for _ in range(PLACEMENT_CANDIDATES):
+            cand = dict(cur)
+            for name in group:
+                cand[name] = mk(name)            # fresh: the blocks of `cur` and of every rejected candidate are still held
+            t = time_of(cand)
+            log.append((group, t))
+            if t < best * 0.997:
+                rejected.extend(cur[name] for name in group)
+                cur, best = cand, t
+            else:
+                rejected.extend(cand[name] for name in group)
+    st.bufs, st.log = cur, log
+    del rejected, cand
+    torch.cuda.empty_cache()                     # the candidates that lost go back to the driver, not into torch's cache (one device synchronisation, once)
+    kept = [k for k, v in _PLACED.items() if v.bufs is not None]
+    for k in kept[:-PLACEMENT_KEPT]:
+        _PLACED[k].bufs = None                   # (a dict keeps insertion order: the oldest placements first)
+    return cur
 
 
 def edge_gate(e, B1h, B2h, views, W3, norm_kind, scale, shift, out=None, num_edges=None):

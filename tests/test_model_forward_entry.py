@@ -127,3 +127,52 @@ def test_separate_buffers_and_one_block_give_the_same_bits():
         assert empty.shape == (0, 1)
     finally:
         ops.FORWARD_BUFFERS = old
+
+
+def test_placed_buffers_keep_the_bits_and_are_kept_per_stream():
+    """ops._placed_buffers (round 6): from its third use on, a forward whose buffers' placement in HBM varies (each below 1 GiB, 64 MiB in all) runs in the
+    fastest of a few candidate allocations per buffer group - same logits before, while and after; one kept set per (device, stream, shapes); nothing is kept
+    under TUNE_PLACEMENT = False, for small graphs, or inside a captured forward."""
+    from gnnome_amd.capture import CapturedForward
+    n, e = 30000, 300000     # H = 128: 276 MB of buffers
+    g = make_graph(n, e, seed=7)
+    model = _model(128, 64, "batch")
+    x = torch.randn(n, 2, generator=torch.Generator().manual_seed(5)).to(dev())
+    ed = g["e"].to(dev())
+    views = views_for((g["src"], g["dst"], n), dev())
+    old = ops.TUNE_PLACEMENT, dict(ops._PLACED)
+    try:
+        ops._PLACED.clear()
+        ops.TUNE_PLACEMENT = True
+        outs = [model(views, x, ed).clone() for _ in range(ops.PLACEMENT_AFTER_USES + 2)]
+        assert all(torch.equal(o, outs[0]) for o in outs)
+        placed = [st for st in ops._PLACED.values() if st.bufs is not None]
+        assert len(placed) == 1 and placed[0].tried and len(placed[0].log) == 1 + 3 * ops.PLACEMENT_CANDIDATES
+        before = {k: t.data_ptr() for k, t in placed[0].bufs.items()}
+        assert len(set(before.values())) == len(before)                                              # six (five) distinct buffers
+        assert torch.equal(model(views, x, ed), outs[0]) and {k: t.data_ptr() for k, t in placed[0].bufs.items()} == before
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(ops.PLACEMENT_AFTER_USES + 1):
+                o = model(views, x, ed)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(o, outs[0])
+        sets = [st.bufs for st in ops._PLACED.values() if st.bufs is not None]
+        assert len(sets) == 2 and not ({t.data_ptr() for t in sets[0].values()} & {t.data_ptr() for t in sets[1].values()})   # one set per stream
+        cap = CapturedForward(model, views, x, ed)                                                    # a hipGraph keeps its own pool's buffers
+        assert torch.equal(cap(), outs[0]) and len([st for st in ops._PLACED.values() if st.bufs is not None]) == 2
+        ops._PLACED.clear()
+        ops.TUNE_PLACEMENT = False
+        for _ in range(ops.PLACEMENT_AFTER_USES + 2):
+            assert torch.equal(model(views, x, ed), outs[0])
+        assert not ops._PLACED
+        ops.TUNE_PLACEMENT = True
+        small = make_graph(2000, 20000, seed=8)                                                       # 18 MB of buffers: below the floor
+        for _ in range(ops.PLACEMENT_AFTER_USES + 2):
+            model((small["src"], small["dst"], 2000), torch.randn(2000, 2).to(dev()), small["e"].to(dev()))
+        assert not ops._PLACED
+    finally:
+        ops.TUNE_PLACEMENT = old[0]
+        ops._PLACED.clear()
+        ops._PLACED.update(old[1])
