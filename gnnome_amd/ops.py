@@ -500,7 +500,10 @@ def _placed_buffers(dev, shapes, run):
                 rejected.extend(cand[name] for name in group)
     st.bufs, st.log = cur, log
     del rejected, cand
-    torch.cuda.empty_cache()                     # the candidates that lost go back to the driver, not into torch's cache (one device synchronisation, once)
+    try:
+        torch.cuda.empty_cache()                 # the candidates that lost go back to the driver, not into torch's cache (one device synchronisation, once)
+    except RuntimeError:                         # (another thread is capturing a graph: the blocks stay in torch's cache)
+        pass
     kept = [k for k, v in _PLACED.items() if v.bufs is not None]
     for k in kept[:-PLACEMENT_KEPT]:
         _PLACED[k].bufs = None                   # (a dict keeps insertion order: the oldest placements first)
