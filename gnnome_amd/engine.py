@@ -440,7 +440,8 @@ def run_stack(ops, prep, views, x, e_raw, exchange=None, n_own=None, n_score=Non
         block = getattr(prep, "block", None)
         if block is None:
             block = prep.block = ops.ModelBlock(prep)
-        return one_call(block, views, x, e_raw, logits)
+        with ops.node_records_for(views, prep.hidden):   # (the aggregation's record form at the widths it pays for: ops.NODE_RECORDS_MAX_HIDDEN)
+            return one_call(block, views, x, e_raw, logits)
     h = encode_nodes(ops, views, x, prep.enc_node)
     e = encode_edges(ops, prep, views, e_raw)
     scratch = {}

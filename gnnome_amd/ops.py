@@ -81,7 +81,7 @@ class GraphViews:
     """In-edge / out-edge orderings of one edge list (see include/gnnome_hip.h, "graph views")."""
 
     __slots__ = ("num_nodes", "num_edges", "in_ptr", "srt_src", "srt_dst", "srt_eid", "out_ptr", "out_pos", "out_dst", "device",
-                 "transposed", "_range", "_bad", "node_perm", "node_gather", "_stream", "_c_block", "__weakref__")
+                 "transposed", "_range", "_bad", "node_perm", "node_gather", "_stream", "_c_block", "_records", "__weakref__")
 
     def __init__(self, src, dst, num_nodes, validate="now", node_perm=None):
         """node_perm (int64[N], optional): the views are built over RENUMBERED nodes, node_perm[caller's id] = internal id
@@ -108,7 +108,7 @@ class GraphViews:
                 self.check_range()
         self.num_nodes, self.num_edges, self.device, self.transposed = n, e, dev, False
         self.node_perm = self.node_gather = None
-        self._stream = self._c_block = None
+        self._stream = self._c_block = self._records = None
         if node_perm is not None:
             node_perm = node_perm.to(device=dev, dtype=torch.int64)
             if node_perm.numel() != n:
@@ -144,6 +144,19 @@ class GraphViews:
                 self._bad = f"edge endpoint out of range [0,{n}): min {lo}, max {hi}"
                 raise IndexError(self._bad)
             self._range = None
+
+    def node_records(self):
+        """records[N, 64] int32 (gnnome_build_node_records): per node its list pointers and the first 20 + 20 neighbour ids / out-edge positions in ONE
+        256-byte row, what the aggregation's record form reads instead of three dependent trips (see NODE_RECORDS).  Built on first use, one small launch;
+        shared with the reversed views (a function of the arrays, not of the roles the host gives them)."""
+        if self._records is None:
+            holder = [torch.empty((max(self.num_nodes, 1), 64), dtype=torch.int32, device=self.device)]
+            with _on(self.device):
+                _lib.check(_lib.load().gnnome_build_node_records(_ptr(self.in_ptr), _ptr(self.srt_src), _ptr(self.out_ptr), _ptr(self.out_pos),
+                                                                 _ptr(self.out_dst), self.num_nodes, _ptr(holder[0]), _stream(self.device)),
+                           "build_node_records")
+            self._records = holder   # (a list: reversed() copies the slot, both views then share the one tensor)
+        return self._records[0]
 
     def stream_schedule(self):
         """The streaming aggregation's schedule of this graph (StreamSchedule), built on first use - one host sync, once per graph;
@@ -389,6 +402,31 @@ _WS_BYTES = {}
 # the same buffers as allocations of their own (4.24 against 4.10 ms on one box, `tools/ab_one_call.sh`; profiles/r06_placement_*.txt).  So the one-call
 # forward takes its buffers one by one (gnnome_model_forward_buffers_f32); "block" = one workspace (gnnome_model_forward_f32), for A/B runs.
 FORWARD_BUFFERS = _os.environ.get("GNNOME_FORWARD_BUFFERS", "separate")
+
+
+# The aggregation's record form (round 6: csrc/node_aggregate.hip, REC): a node's pointers AND its first 20 + 20 neighbour ids from one 256-byte load.
+# Same bits; 0.120 against 0.135 ms per launch at H = 64 (1M edges), 0.2019 against 0.2054 at H = 128, level at 256 (profiles/r06_aggregation_node_records.txt):
+# on for the widths up to NODE_RECORDS_MAX_HIDDEN in whole-graph BatchNorm inference, 256 bytes per node of extra views.  GNNOME_NODE_RECORDS=0: off.
+NODE_RECORDS_MAX_HIDDEN = int(_os.environ.get("GNNOME_NODE_RECORDS", "64"))
+
+
+class node_records_for:
+    """`with ops.node_records_for(views, hidden):` - the calling thread's whole-range BatchNorm aggregations read `views.node_records()` for the duration
+    (gnnome_debug_node_records: a thread-local switch of the library), where the width qualifies; a no-op otherwise."""
+
+    def __init__(self, views, hidden):
+        self.on = (0 < hidden <= NODE_RECORDS_MAX_HIDDEN and isinstance(views, GraphViews) and views.num_nodes > 0 and views.num_edges > 0
+                   and not torch.cuda.is_current_stream_capturing())
+        self.views = views
+
+    def __enter__(self):
+        if self.on:
+            _lib.check(_lib.load().gnnome_debug_node_records(_ptr(self.views.node_records())), "debug_node_records")
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lib.load().gnnome_debug_node_records(None)
 
 
 def model_forward(block, views, x, e_raw, logits=None):

