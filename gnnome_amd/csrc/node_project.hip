@@ -114,35 +114,36 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, h8_t& p1,
 // of a quad write 64 contiguous bytes of one row, the two wave halves the two halves of a 128-byte line.
 __host__ __device__ constexpr int frag_col(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
 
-// W[Nout, K] (row stride ldw) -> planes in fragment order: [cb = col / 32][kc = k / 128][s = (k % 128) / 16][plane][lane][8], where lane =
-// i + 32 * ((k % 16) / 8) holds k % 8 = 0 .. 7 of column 32 cb + frag_col(i).  One thread per (cb, kc, s, lane).
+// W[Nout, K] (row stride ldw) -> planes in fragment order: [cb = col / 32][s = k / 16][plane][lane][8], where lane = i + 32 * ((k % 16) / 8) holds
+// k % 8 = 0 .. 7 of column 32 cb + frag_col(i) (for K = 128 / 256 that is [cb][kc = k / 128][(k % 128) / 16], the 16 KB chunks of the header).  One thread
+// per (cb, s, lane).
 __global__ __launch_bounds__(256) void k_weight_planes(const float* __restrict__ W, int ldw, int Nout, int K, uint4* __restrict__ planes) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int lane = t & 63, s = (t >> 6) & 7, rest = t >> 9, kchunks = K / 128;
-    const int kc = rest % kchunks, cb = rest / kchunks;
+    const int lane = t & 63, ksteps = K / 16, s = (t >> 6) % ksteps, cb = (t >> 6) / ksteps;
     if (cb * 32 >= Nout) return;
-    const int col = 32 * cb + frag_col(lane & 31), k = 128 * kc + 16 * s + 8 * (lane >> 5);
+    const int col = 32 * cb + frag_col(lane & 31), k = 16 * s + 8 * (lane >> 5);
     const float* w = W + (int64_t)col * ldw + k;
     h8_t p1, p2;
     split8(*reinterpret_cast<const f32x4*>(w), *reinterpret_cast<const f32x4*>(w + 4), p1, p2);
-    uint4* dst = planes + ((int64_t)(cb * kchunks + kc) * 16 + 2 * s) * 64 + lane;
+    uint4* dst = planes + ((int64_t)cb * ksteps + s) * 128 + lane;
     dst[0] = __builtin_bit_cast(uint4, p1);
     dst[64] = __builtin_bit_cast(uint4, p2);
 }
 
 constexpr int kMaxNout = 1536;
-constexpr int kGranuleBytes = 32768;
+constexpr int kGranuleBytes = 32768;   // (K = 64: 16 KB - two column blocks, as at K = 128)
 
-// K in {128, 256}; 4 waves; two 32 KB slots.  PROBE (measurement only; gnnome_set_tuning(2, 20) + gnnome_set_tuning(1, mask)): 1 no stores, 2 no MFMAs,
+// K in {64, 128, 256}; 4 waves; two granule slots.  PROBE (measurement only; gnnome_set_tuning(2, 20) + gnnome_set_tuning(1, mask)): 1 no stores, 2 no MFMAs,
 // 4 no DMA inside the loop, 8 no quad transpose (all four: wrong results), 16 (right results) no prefetch of the next row tile; 32 (right results): wave 0's cycle counters to gnnome_debug_gate_profile's
 // buffer ([workgroups][8] int64)
 template <int K, int PROBE = 0>
 __global__ __launch_bounds__(256, 2) void k_node_project(const float* __restrict__ A, int64_t M, int lda, const unsigned char* __restrict__ planes,
                                                           const float* __restrict__ bias, int Nout, float* __restrict__ C, int ldc, int64_t total_units,
                                                           long long* prof, int xp) {
-    constexpr int KS = K / 16, KC = K / 128, BPG = 2 / KC;   // k steps, k chunks per column block, column blocks per granule
-    static_assert(KC == 1 || KC == 2, "K is 128 or 256");
-    constexpr int NW = 4, NP = 32 / NW, NT = 64 * NW, TM = 32 * NW;   // waves; DMA pieces per wave and granule; threads; rows per tile
+    static_assert(K == 64 || K == 128 || K == 256, "K is 64, 128 or 256");
+    constexpr int KS = K / 16, GB = K == 64 ? kGranuleBytes / 2 : kGranuleBytes, SPG = GB / 2048, BPG = SPG / KS;   // k steps per column block; granule
+    // bytes; k steps per granule (2 KB each: two planes x 64 lanes x 16 bytes); column blocks per granule (2, 2, 1)
+    constexpr int NW = 4, NP = GB / 1024 / NW, NT = 64 * NW, TM = 32 * NW;   // waves; DMA pieces per wave and granule; threads; rows per tile
     constexpr int NSTORE = (PROBE & 1) ? 0 : 4 * BPG;   // vector-memory operations a wave issues per iteration after its DMA pieces
     __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * kGranuleBytes];
     __shared__ __attribute__((aligned(16))) float bias_lds[kMaxNout];
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_node_project(const float* __restrict
     int g = (int)(u0 % gpt);          // granule of the current unit
     int64_t tile = u0 / gpt;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) dma_piece(mine + (int64_t)g * kGranuleBytes + p * 1024, voff, ring0 + (NP * wave + p) * 1024);
+    for (int p = 0; p < NP; ++p) dma_piece(mine + (int64_t)g * GB + p * 1024, voff, ring0 + (NP * wave + p) * 1024);
     {
         float bv[kMaxNout / NT];
 #pragma unroll
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void k_node_project(const float* __restrict
 
     h8_t a1[KS], a2[KS];
     float* crow[4];
-    constexpr bool PREFETCH_ROWS = K == 128 && !(PROBE & 16);
+    constexpr bool PREFETCH_ROWS = K <= 128 && !(PROBE & 16);
     f32x4 raw[2 * KS];
     bool ahead = false;   // raw[] holds (requests for) the rows of the tile that starts with the next iteration
     auto request_rows = [&](f32x4 (&dst)[2 * KS], int64_t t) {
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(256, 2) void k_node_project(const float* __restrict
         }
         // (the last iteration fetches a granule nobody reads, into the slot nobody reads any more: unconditional requests keep the k steps one
         // basic block, and the accounting uniform)
-        const unsigned next_slot = ring0 + ((n + 1) & 1) * kGranuleBytes + (NP * wave) * 1024;
-        const unsigned char* next_src = mine + (int64_t)g_next * kGranuleBytes;
-        const unsigned char* slot = ring + (n & 1) * kGranuleBytes + 16 * lane;
+        const unsigned next_slot = ring0 + ((n + 1) & 1) * GB + (NP * wave) * 1024;
+        const unsigned char* next_src = mine + (int64_t)g_next * GB;
+        const unsigned char* slot = ring + (n & 1) * GB + 16 * lane;
         // W fragments two k steps ahead of the MFMAs that take them (hipcc by itself requests a step's pair only after the previous step's MFMAs)
         constexpr int AHEAD = 2;
         h8_t wq1[16], wq2[16];
@@ -278,28 +279,25 @@ __global__ __launch_bounds__(256, 2) void k_node_project(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) accM[r] = accC[r] = 0.f;
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const int step = (b * KC + kc) * 8 + s;   // 0 .. 15 inside the granule
-                    // this wave's pieces of the next granule, all of them BEFORE this iteration's first stores (the accounting above): spread over
-                    // the k steps of the granule's first column block
-                    constexpr int EVERY = 8 * KC / NP;
-                    if (!(PROBE & 4) && step % EVERY == 0 && step / EVERY < NP) dma_piece(next_src + (step / EVERY) * 1024, voff, next_slot + (step / EVERY) * 1024);
-                    if (step + AHEAD < 16) {
-                        wq1[step + AHEAD] = *reinterpret_cast<const h8_t*>(slot + (2 * (step + AHEAD)) * 1024);
-                        wq2[step + AHEAD] = *reinterpret_cast<const h8_t*>(slot + (2 * (step + AHEAD) + 1) * 1024);
-                    }
-                    const h8_t w1 = wq1[step], w2 = wq2[step];
-                    if (!(PROBE & 2)) {
-                        accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, a1[8 * kc + s], accM, 0, 0, 0);
-                        accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, a2[8 * kc + s], accC, 0, 0, 0);
-                        accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, a1[8 * kc + s], accC, 0, 0, 0);
-                    } else {
-                        accM[s] += (float)w1[0] + (float)w2[0] + (float)a1[8 * kc + s][0] + (float)a2[8 * kc + s][1];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // (keeps the requests above where they are: the scheduler sinks them to their first use otherwise)
+            for (int s = 0; s < KS; ++s) {
+                const int step = b * KS + s;   // 0 .. SPG - 1 inside the granule
+                // this wave's pieces of the next granule, all of them BEFORE this iteration's first stores (the accounting above): spread over
+                // the k steps of the granule's first column block
+                constexpr int EVERY = KS / NP;
+                if (!(PROBE & 4) && step % EVERY == 0 && step / EVERY < NP) dma_piece(next_src + (step / EVERY) * 1024, voff, next_slot + (step / EVERY) * 1024);
+                if (step + AHEAD < SPG) {
+                    wq1[step + AHEAD] = *reinterpret_cast<const h8_t*>(slot + (2 * (step + AHEAD)) * 1024);
+                    wq2[step + AHEAD] = *reinterpret_cast<const h8_t*>(slot + (2 * (step + AHEAD) + 1) * 1024);
                 }
+                const h8_t w1 = wq1[step], w2 = wq2[step];
+                if (!(PROBE & 2)) {
+                    accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, a1[s], accM, 0, 0, 0);
+                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, a2[s], accC, 0, 0, 0);
+                    accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, a1[s], accC, 0, 0, 0);
+                } else {
+                    accM[s % 16] += (float)w1[0] + (float)w2[0] + (float)a1[s][0] + (float)a2[s][1];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (keeps the requests above where they are: the scheduler sinks them to their first use otherwise)
             }
             // lane (j, h): accumulator 4 q + t = node row j, MFMA row 8 q + 4 h + t; transposed within the quad it becomes four row pieces of 16 bytes
             const int cb = g * BPG + b;
@@ -336,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void k_node_project(const float* __restrict
 
 template <int K, int PROBE>
 static int launch_project(const float* A, int64_t M, int lda, const void* planes, const float* bias, int Nout, float* C, int ldc, hipStream_t s) {
-    constexpr int BPG = K == 128 ? 2 : 1;
+    constexpr int BPG = K == 256 ? 1 : 2;
     const int64_t tiles = (M + 127) / 128, units = tiles * (Nout / (32 * BPG));
     const int64_t slots = 2 * persistent_grid();   // workgroups that are resident together: two per CU
     const int grid = (int)(units < slots ? units : slots);
@@ -346,21 +344,22 @@ static int launch_project(const float* A, int64_t M, int lda, const void* planes
     return GNNOME_OK;
 }
 
-bool project_supported(int K, int Nout) { return (K == 128 || K == 256) && Nout > 0 && Nout % (K == 128 ? 64 : 32) == 0 && Nout <= kMaxNout; }
+bool project_supported(int K, int Nout) { return (K == 64 || K == 128 || K == 256) && Nout > 0 && Nout % (K == 256 ? 32 : 64) == 0 && Nout <= kMaxNout; }
 
 int weight_planes_launch(const float* W, int ldw, int Nout, int K, void* planes, hipStream_t s) {
-    const int threads = Nout / 32 * (K / 128) * 8 * 64;
+    const int threads = Nout / 32 * (K / 16) * 64;
     hipLaunchKernelGGL(k_weight_planes, dim3((threads + 255) / 256), dim3(256), 0, s, W, ldw, Nout, K, reinterpret_cast<uint4*>(planes));
     GN_LAUNCH_CHECK();
     return GNNOME_OK;
 }
 
 int project_launch(const float* A, int64_t M, int K, int lda, const void* planes, const float* bias, int Nout, float* C, int ldc, hipStream_t s) {
-    const int probe = tuning(kTuneLinearVariant) == 20 ? (tuning(kTuneGateAblation) & 63) : 0;
+    const int probe = (K != 64 && tuning(kTuneLinearVariant) == 20) ? (tuning(kTuneGateAblation) & 63) : 0;
 #define GN_PROBE(P) \
     if (probe == P) return K == 128 ? launch_project<128, P>(A, M, lda, planes, bias, Nout, C, ldc, s) : launch_project<256, P>(A, M, lda, planes, bias, Nout, C, ldc, s);
     GN_PROBE(1) GN_PROBE(2) GN_PROBE(3) GN_PROBE(4) GN_PROBE(7) GN_PROBE(8) GN_PROBE(16) GN_PROBE(32) GN_PROBE(33) GN_PROBE(34) GN_PROBE(35) GN_PROBE(39)
 #undef GN_PROBE
+    if (K == 64) return launch_project<64, 0>(A, M, lda, planes, bias, Nout, C, ldc, s);   // (round 6, late: the shipped checkpoint's width; no probes)
     return K == 128 ? launch_project<128, 0>(A, M, lda, planes, bias, Nout, C, ldc, s) : launch_project<256, 0>(A, M, lda, planes, bias, Nout, C, ldc, s);
 }
 
@@ -371,7 +370,7 @@ int project_launch(const float* A, int64_t M, int K, int lda, const void* planes
 extern "C" int gnnome_weight_planes_f16(const float* W, int ldw, int Nout, int K, void* planes, void* stream) {
     using namespace gnnome;
     GN_REQUIRE(W && planes, "weight_planes: null pointer");
-    GN_REQUIRE(project_supported(K, Nout), "weight_planes: K=%d must be 128 or 256 and Nout=%d a multiple of 32 (K = 128: of 64) up to 1536", K, Nout);
+    GN_REQUIRE(project_supported(K, Nout), "weight_planes: K=%d must be 64, 128 or 256 and Nout=%d a multiple of 32 (K <= 128: of 64) up to 1536", K, Nout);
     GN_REQUIRE(ldw >= K && ldw % 4 == 0 && (uintptr_t)W % 16 == 0 && (uintptr_t)planes % 256 == 0, "weight_planes: bad stride / alignment");
     return weight_planes_launch(W, ldw, Nout, K, planes, (hipStream_t)stream);
 }
@@ -384,7 +383,7 @@ extern "C" int gnnome_linear_planes_f32(const float* A, int64_t M, int K, int ld
     GN_REQUIRE(M >= 0, "linear_planes: bad row count %lld", (long long)M);
     if (M == 0) return GNNOME_OK;
     GN_REQUIRE(A && planes && C, "linear_planes: null pointer");
-    GN_REQUIRE(project_supported(K, Nout), "linear_planes: K=%d must be 128 or 256 and Nout=%d a multiple of 32 (K = 128: of 64) up to 1536", K, Nout);
+    GN_REQUIRE(project_supported(K, Nout), "linear_planes: K=%d must be 64, 128 or 256 and Nout=%d a multiple of 32 (K <= 128: of 64) up to 1536", K, Nout);
     GN_REQUIRE(lda >= K && ldc >= Nout && lda % 4 == 0 && ldc % 4 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)C % 16 == 0 &&
                    (uintptr_t)planes % 256 == 0,
                "linear_planes: bad stride / alignment");
@@ -401,5 +400,5 @@ extern "C" int gnnome_linear_planes_route(int64_t M, int K, int Nout, int given_
     }();
     const int variant = tuning(kTuneLinearVariant);
     if (!enabled || M <= 0 || tuning(kTuneArith) != 0 || !(variant == 0 || variant == 9 || variant == 20) || !project_supported(K, Nout)) return 0;
-    return (given_planes || (Nout % 128 == 0 && (K == 256 || Nout >= 256))) ? 1 : 0;
+    return (given_planes || (K >= 128 && Nout % 128 == 0 && (K == 256 || Nout >= 256))) ? 1 : 0;   // (K = 64: only on the caller's planes)
 }

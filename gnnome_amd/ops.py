@@ -288,8 +288,8 @@ def encode(x, W1, b1, W2, b2, gather=None, rows=None):
 
 
 def planes_supported(K, Nout):
-    """Shapes gnnome_linear_planes_f32 is built for (the node projections: K = H in {128, 256}, Nout = 5H or 2 hs)."""
-    return K in (128, 256) and Nout % (64 if K == 128 else 32) == 0 and 0 < Nout <= 1536
+    """Shapes gnnome_linear_planes_f32 is built for (the node projections: K = H in {64, 128, 256}, Nout = 5H or 2 hs)."""
+    return K in (64, 128, 256) and Nout % (32 if K == 256 else 64) == 0 and 0 < Nout <= 1536
 
 
 def weight_planes(W):

@@ -137,12 +137,12 @@ int gnnome_linear_acc_f32(const float* A, int64_t M, int K, int lda, const float
  * (see gnnome_linear_f32), laid out in MFMA fragment order as 16 KB chunks [Nout / 32][K / 128][8 k steps][2 planes][64 lanes][8 halves] =
  * Nout * K * 4 bytes at `planes` (256-byte aligned); gnnome_linear_planes_f32 computes C[M, Nout] = A W^T + bias from them
  * (csrc/node_project.hip): a wave keeps its 32 rows of A as planes in registers for every output column, the chunks of W arrive from L2 in an
- * LDS ring by LDS-DMA, 16-byte row pieces leave straight from the accumulators.  K in {128, 256}, Nout % 32 == 0 (K = 128: % 64), Nout <= 1536;
+ * LDS ring by LDS-DMA, 16-byte row pieces leave straight from the accumulators.  K in {64, 128, 256}, Nout % 32 == 0 (K <= 128: % 64), Nout <= 1536;
  * lda, ldc % 4 == 0, A, C 16-byte aligned, C must not alias A; bias may be NULL.  A row's bits depend on that row and W alone (not on M).  Same
  * operand range as every fp16x3 product: an |element| >= 65504 makes its output row NaN.
  * gnnome_linear_planes_route: 1 when a product of this shape is to run on gnnome_linear_planes_f32 under the current tuning, 0 when it keeps
  * gnnome_linear_f32's routes - ONE rule for every host above the ABI (gnnome_amd.ops.linear, gnnome_model_forward_f32, the dispatcher operator
- * gnnome_hip::linear): the kernel's shapes; without planes from the caller (`given_planes` = 0) only the node projections' shapes, whole 128-column
+ * gnnome_hip::linear): the kernel's shapes; without planes from the caller (`given_planes` = 0) only the node projections' shapes at K >= 128, whole 128-column
  * blocks with K = 256 or Nout >= 256; not under gnnome_set_tuning(10, 1) (bf16x6) or a gnnome_set_tuning(2, .) variant of the older kernels; not
  * when the environment holds GNNOME_PLANES_LINEAR=0 (A/B against round 5's routes).  Alignment and aliasing stay the caller's to check. */
 int gnnome_weight_planes_f16(const float* W, int ldw, int Nout, int K, void* planes, void* stream);

@@ -35,7 +35,8 @@ def _planes_np(x):
 
 @pytest.mark.parametrize("m,k,nout", [(1, 128, 640), (31, 128, 640), (128, 128, 640), (129, 128, 640), (333, 128, 256), (5000, 128, 640),
                                       (100_003, 128, 640), (7, 256, 1280), (129, 256, 1280), (4097, 256, 1280), (60_001, 256, 1280),
-                                      (1000, 128, 128), (1000, 256, 128), (257, 128, 64), (300, 256, 64), (513, 128, 1536)])
+                                      (1000, 128, 128), (1000, 256, 128), (257, 128, 64), (300, 256, 64), (513, 128, 1536),
+                                      (1, 64, 320), (127, 64, 320), (129, 64, 320), (4099, 64, 320), (100_003, 64, 320), (999, 64, 128), (1500, 64, 64)])
 def test_linear_planes_against_fp64(m, k, nout):
     g = torch.Generator().manual_seed(m + k + nout)
     A, W, b = torch.randn(m, k, generator=g), torch.randn(nout, k, generator=g) / k ** 0.5, torch.randn(nout, generator=g)
@@ -56,7 +57,7 @@ def test_linear_planes_against_fp64(m, k, nout):
         assert torch.equal(ops.linear(Ad, Wd, bd), got)
 
 
-@pytest.mark.parametrize("k,nout", [(128, 640), (256, 1280)])
+@pytest.mark.parametrize("k,nout", [(64, 320), (128, 640), (256, 1280)])
 def test_linear_planes_rows_do_not_depend_on_the_launch(k, nout):
     """engine / dist cut the node range freely (owned rows, halo rows, pipeline chunks): a row's bits are a function of the row."""
     g = torch.Generator().manual_seed(k)
@@ -92,14 +93,15 @@ def test_linear_planes_strided_views_and_selector():
     assert torch.allclose(got.cpu(), W.cpu().t()[torch.arange(m) % k], rtol=2.0 ** -21, atol=1e-9)
 
 
-@pytest.mark.parametrize("k,nout", [(128, 640), (256, 1280)])
+@pytest.mark.parametrize("k,nout", [(64, 320), (128, 640), (256, 1280)])
 def test_linear_planes_out_of_range_row_is_loud(k, nout):
     g = torch.Generator().manual_seed(3)
     A = torch.randn(300, k, generator=g)
     A[17, 5] = 7.0e4       # beyond fp16
     A[200, k - 1] = float("nan")
     W = torch.randn(nout, k, generator=g) / k ** 0.5
-    got = ops.linear(A.to(dev()), W.to(dev()), None).cpu()
+    Wd = W.to(dev())
+    got = ops.linear(A.to(dev()), Wd, None, planes=ops.weight_planes(Wd)).cpu()
     bad = ~torch.isfinite(got).all(1)
     assert bad[17] and bad[200] and int(bad.sum()) == 2
     good = ~bad
@@ -107,10 +109,10 @@ def test_linear_planes_out_of_range_row_is_loud(k, nout):
 
 
 def test_linear_planes_rejects_what_it_is_not_built_for():
-    A = torch.randn(10, 64, device=dev())
-    W = torch.randn(640, 64, device=dev())
+    A = torch.randn(10, 32, device=dev())
+    W = torch.randn(640, 32, device=dev())
     with pytest.raises(Exception):
-        ops.weight_planes(W)            # K = 64
+        ops.weight_planes(W)            # K = 32
     W = torch.randn(100, 128, device=dev())
     with pytest.raises(Exception):
         ops.weight_planes(W)            # Nout % 32
