@@ -6,7 +6,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=${1:-3}
 ms() { python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(round(d['ms_per_step'],4))"; }
-for spec in "c2|" "c4shard|--workload c4shard" "10m|--workload 10m" "ecoli|--workload ecoli" "train_c2|--mode train" "train_c4shard|--workload c4shard --mode train --steps 5 --warmup 2"; do
+for spec in "c2|" "c4shard|--workload c4shard" "10m|--workload 10m" "parity64|--workload parity64" "ecoli|--workload ecoli" "train_c2|--mode train" "train_c4shard|--workload c4shard --mode train --steps 5 --warmup 2"; do
   name=${spec%%|*}; args=${spec#*|}
   for rnd in $(seq 1 $R); do
     a=$(cd build/ab_r05 && timeout 600 python bench.py --no-cpu-baseline --no-extras $args 2>/dev/null | ms)
